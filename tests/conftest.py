@@ -1,0 +1,23 @@
+"""pytest configuration: markers, paths, and on-demand build of the test-only CPU oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: longer CPU case")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    """The oracle is test infrastructure (oracle/): compile it once per session if it is missing/stale."""
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    yield
