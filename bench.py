@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py — Matom-steps/s of the miniMD hot path (LJ, full neighbor lists, double precision) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one MD timestep of BASELINE.json configs[1]: in.lj.miniMD, -s 80 per GPU (2,048,000 atoms per GPU,
+weak scaling: the global box is 160x80x80 / 160x160x80 / 160^3 unit cells at 2/4/8 GPUs), full neighbor list,
+re-neighboring every 20 steps, thermo every 100 — i.e. exactly the loop the reference times
+(Integrate::run, ref/ljs.cpp:470-472). Atoms are resident in HBM when the timed region starts.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_atom(kbar, ghost_ratio, real_bytes=8):
+    """compulsory HBM bytes of one LJ full-neighbor force launch per owned atom:
+    neighbor indices 4*K + numneigh 4 + x_i 3*real + type 4 + f_i 3*real + first touch of ghosts (3*real+4)*G/N"""
+    return 4.0 * kbar + 4 + 3 * real_bytes + 4 + 3 * real_bytes + ghost_ratio * (3 * real_bytes + 4)
+
+
+def cpu_baseline(size, nsteps):
+    """rank 0, N=1 only: the UNMODIFIED reference (oracle/_ref/miniMD_ref_dp, built from /root/reference by
+    oracle/Makefile) on this box's host cores, bounded sample of the same workload."""
+    exe = os.path.join(REPO, "oracle", "_ref", "miniMD_ref_dp")
+    cores = os.cpu_count() or 1
+    data = os.path.join(REPO, "data")
+    if os.path.exists(exe):
+        cmd = [exe, "-i", "in.lj.miniMD", "-s", str(size), "-n", str(nsteps), "--half_neigh", "0", "-t", str(cores)]
+        kind = "reference"
+    else:
+        exe = os.path.join(REPO, "oracle", "mmd_oracle_dp")
+        subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"], check=False)
+        cmd = [exe, "-i", "in.lj.miniMD", "-s", str(size), "-n", str(max(nsteps // 2, 1)), "--half_neigh", "0"]
+        kind, cores = "port", 1
+    try:
+        r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if "PERF_SUMMARY" in l and not l.startswith("#")][0].split()
+        return {"value": float(line[9]) / 1e6, "unit": "Matom-steps/s", "cores": cores, "kind": kind,
+                "sample": "%s, in.lj.miniMD -s %d --half_neigh 0 DP, %s steps, t_total %.2f s" % (
+                    "ref/ MPI-stub + OpenMP -t %d" % cores if kind == "reference" else "oracle C restatement, 1 thread",
+                    size, line[2], float(line[4]))}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "unit": "Matom-steps/s", "cores": cores, "kind": kind, "sample": "failed: %r" % (e,)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=80, help="unit cells per GPU edge (BASELINE configs[1]: 80)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    import torch
+    import minimd_amd
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+        torch.cuda.set_device(local_rank)
+        # data plane: the library's own RCCL communicator (ncclSend/ncclRecv halos over xGMI)
+        L = minimd_amd.load_library("dp")
+        obj = [None]
+        if rank == 0:
+            import ctypes
+            buf = ctypes.create_string_buffer(128)
+            assert L.mmd_comm_unique_id(buf) == 0, L.mmd_last_error()
+            obj = [buf.raw]
+        dist.broadcast_object_list(obj, src=0)
+        L.mmd_sim_set_unique_id(obj[0])
+
+    # weak scaling: per-GPU sub-box stays size^3 unit cells; Comm::setup factorises the ranks 1/2/4/8 ->
+    # 1x1x1 / 2x1x1 / 2x2x1 / 2x2x2 for these boxes (min surface, ref/comm.cpp:80-126)
+    dims = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
+    if dims is None:
+        dims = (world, 1, 1)
+    nx, ny, nz = (args.size * d for d in dims)
+    sim_args = ["-i", "in.lj.miniMD", "-nx", nx, "-ny", ny, "-nz", nz, "--half_neigh", "0", "-n", args.steps]
+    sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
+    natoms = sim.natoms()
+    sim.initial()
+    if args.warmup > 0:
+        sim.run_steps(args.warmup)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        sim.handle.sync()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    sim.run_steps(args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    tm = sim.handle.timers()
+    nlocal, nghost, _ = sim.handle.counts()
+    ninfo = sim.handle.neighbor_info()
+    kbar = ninfo["total"] / max(nlocal, 1)
+    bpa = algorithmic_bytes_per_atom(kbar, nghost / max(nlocal, 1))
+    k_ms = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
+    achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+    out = {
+        "metric": "Matom-steps/sec (LJ, full-neigh)", "value": natoms * args.steps / dt / 1e6, "unit": "Matom-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "in.lj.miniMD -s %d per GPU (global %dx%dx%d cells, %d atoms), full neighbor list, DP, "
+                               "reneigh 20, thermo 100" % (args.size, nx, ny, nz, natoms),
+                   "parallelism": "spatial %dx%dx%d, RCCL p2p halos" % dims},
+        "roofline": {"bound": "hbm", "kernel": "k_lj_full (ForceLJ::compute_fullneigh)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                     "kernel_ms": k_ms, "launches": tm["force_launches"], "bytes_per_atom": bpa, "atoms_per_launch": nlocal,
+                     "kbar": kbar, "ghost_ratio": nghost / max(nlocal, 1)},
+        "phases_s": {k: tm[k] for k in ("total", "comm", "force", "neigh", "extra")},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

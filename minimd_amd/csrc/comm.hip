@@ -1,0 +1,562 @@
+// minimd_amd/csrc/comm.hip — Comm (ref/comm.cpp): spatial decomposition, ghost-atom halo (communicate /
+// reverse_communicate), atom migration (exchange) and ghost-list construction (borders) with all per-atom
+// work in HIP kernels (ordered stream compaction, pack, unpack) and only counts crossing to the host.
+//
+// Transport between ranks is RCCL point-to-point (ncclSend/ncclRecv grouped per swap, xGMI) on the
+// handle's stream; a host-staged callback transport exists for tests (gloo). Swaps whose partner is this
+// rank (periodic images on a 1-wide processor grid) never touch a buffer: one kernel reads the source
+// atoms and writes the ghosts in place.
+//
+// Halo element = real4 {x,y,z,(real)type} so a remote swap is received straight into x[firstrecv...]
+// (unpack elided).
+#include <rccl/rccl.h>
+
+#include "device_utils.hpp"
+#include "mmd_internal.hpp"
+
+#define NCCL_TRY(expr)                                                                          \
+  do {                                                                                          \
+    ncclResult_t _r = (expr);                                                                   \
+    if(_r != ncclSuccess) {                                                                     \
+      mmd_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+      return -1;                                                                                \
+    }                                                                                           \
+  } while(0)
+
+// ---------------------------------------------------------------------------------------------------
+// Comm::setup (ref/comm.cpp:60-272) — host only
+// ---------------------------------------------------------------------------------------------------
+static int cart_rank(const int pg[3], int c0, int c1, int c2)
+{
+  // MPI_Cart_create(reorder = 0) numbering: row-major over (x,y,z), periodic wrap
+  c0 = (c0 % pg[0] + pg[0]) % pg[0];
+  c1 = (c1 % pg[1] + pg[1]) % pg[1];
+  c2 = (c2 % pg[2] + pg[2]) % pg[2];
+  return (c0 * pg[1] + c1) * pg[2] + c2;
+}
+
+extern "C" int mmd_comm_setup(mmd_handle* h, mmd_float cutneigh, int me, int nprocs)
+{
+  if(!h || nprocs < 1 || me < 0 || me >= nprocs) { mmd_set_error("mmd_comm_setup: bad arguments"); return -1; }
+  if(!(h->prd[0] > 0)) { mmd_set_error("mmd_comm_setup: box not set"); return -1; }
+  h->me = me;
+  h->nprocs = nprocs;
+  const real* prd = h->prd;
+  const real area[3] = {prd[0] * prd[1], prd[0] * prd[2], prd[1] * prd[2]};
+  real bestsurf = 2.0 * (area[0] + area[1] + area[2]);
+  int pg[3] = {0, 0, 0};
+  for(int ipx = 1; ipx <= nprocs; ipx++) {
+    if(nprocs % ipx) continue;
+    const int nremain = nprocs / ipx;
+    for(int ipy = 1; ipy <= nremain; ipy++) {
+      if(nremain % ipy) continue;
+      const int ipz = nremain / ipy;
+      const real surf = area[0] / ipx / ipy + area[1] / ipx / ipz + area[2] / ipy / ipz;
+      if(surf < bestsurf) { bestsurf = surf; pg[0] = ipx; pg[1] = ipy; pg[2] = ipz; }
+    }
+  }
+  if(pg[0] * pg[1] * pg[2] != nprocs) { mmd_set_error("ERROR: Bad grid of processors"); return -1; }
+  for(int d = 0; d < 3; d++) h->procgrid[d] = pg[d];
+  h->myloc[0] = me / (pg[1] * pg[2]);
+  h->myloc[1] = (me / pg[2]) % pg[1];
+  h->myloc[2] = me % pg[2];
+  for(int d = 0; d < 3; d++) {
+    int lo[3] = {h->myloc[0], h->myloc[1], h->myloc[2]}, hi[3] = {h->myloc[0], h->myloc[1], h->myloc[2]};
+    lo[d] -= 1; hi[d] += 1;
+    h->procneigh[d][0] = cart_rank(pg, lo[0], lo[1], lo[2]);
+    h->procneigh[d][1] = cart_rank(pg, hi[0], hi[1], hi[2]);
+    h->lo[d] = h->myloc[d] * prd[d] / pg[d];
+    h->hi[d] = (h->myloc[d] + 1) * prd[d] / pg[d];
+    h->need[d] = static_cast<int>(cutneigh * pg[d] / prd[d] + 1);
+  }
+  for(auto& s : h->swaps) s.sendlist.release();
+  h->swaps.clear();
+  for(int d = 0; d < 3; d++) {
+    for(int ineed = 0; ineed < 2 * h->need[d]; ineed++) {
+      Swap s;
+      s.dim = d;
+      s.pbc_any = 0; s.pbc[0] = s.pbc[1] = s.pbc[2] = 0;
+      real lo, hi;
+      if(ineed % 2 == 0) {
+        s.sendproc = h->procneigh[d][0]; s.recvproc = h->procneigh[d][1];
+        const int nbox = h->myloc[d] + ineed / 2;
+        lo = nbox * prd[d] / pg[d];
+        hi = h->lo[d] + cutneigh;
+        const real cap = (nbox + 1) * prd[d] / pg[d];
+        hi = hi < cap ? hi : cap;
+        if(h->myloc[d] == 0) { s.pbc_any = 1; s.pbc[d] = 1; }
+      } else {
+        s.sendproc = h->procneigh[d][1]; s.recvproc = h->procneigh[d][0];
+        const int nbox = h->myloc[d] - ineed / 2;
+        hi = (nbox + 1) * prd[d] / pg[d];
+        lo = h->hi[d] - cutneigh;
+        const real floor_ = nbox * prd[d] / pg[d];
+        lo = lo > floor_ ? lo : floor_;
+        if(h->myloc[d] == pg[d] - 1) { s.pbc_any = 1; s.pbc[d] = -1; }
+      }
+      s.slablo = lo; s.slabhi = hi;
+      h->swaps.push_back(std::move(s));
+    }
+  }
+  return 0;
+}
+
+extern "C" int mmd_comm_info(mmd_handle* h, int procgrid[3], int myloc[3], int procneigh[6], int need[3], int* nswap)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  for(int d = 0; d < 3; d++) {
+    if(procgrid) procgrid[d] = h->procgrid[d];
+    if(myloc) myloc[d] = h->myloc[d];
+    if(need) need[d] = h->need[d];
+    if(procneigh) { procneigh[2 * d] = h->procneigh[d][0]; procneigh[2 * d + 1] = h->procneigh[d][1]; }
+  }
+  if(nswap) *nswap = (int)h->swaps.size();
+  return 0;
+}
+
+extern "C" int mmd_comm_swap_info(mmd_handle* h, int iswap, double slab[2], int pbc[4], int procs[2], int counts[3])
+{
+  if(!h || iswap < 0 || iswap >= (int)h->swaps.size()) { mmd_set_error("mmd_comm_swap_info: bad swap index"); return -1; }
+  const Swap& s = h->swaps[iswap];
+  if(slab) { slab[0] = s.slablo; slab[1] = s.slabhi; }
+  if(pbc) { pbc[0] = s.pbc_any; pbc[1] = s.pbc[0]; pbc[2] = s.pbc[1]; pbc[3] = s.pbc[2]; }
+  if(procs) { procs[0] = s.sendproc; procs[1] = s.recvproc; }
+  if(counts) { counts[0] = s.sendnum; counts[1] = s.recvnum; counts[2] = s.firstrecv; }
+  return 0;
+}
+
+extern "C" int mmd_comm_download_lists(mmd_handle* h, int iswap, int* sendlist)
+{
+  if(!h || iswap < 0 || iswap >= (int)h->swaps.size() || !sendlist) { mmd_set_error("mmd_comm_download_lists: bad arguments"); return -1; }
+  const Swap& s = h->swaps[iswap];
+  if(s.sendnum) HIP_TRY(hipMemcpyAsync(sendlist, s.sendlist.p, (size_t)s.sendnum * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transport
+// ---------------------------------------------------------------------------------------------------
+extern "C" int mmd_comm_unique_id(unsigned char id[128])
+{
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  NCCL_TRY(ncclGetUniqueId(&u));
+  memcpy(id, &u, 128);
+  return 0;
+}
+
+extern "C" int mmd_comm_init_rccl(mmd_handle* h, const unsigned char id[128], int rank, int nranks)
+{
+  if(!h || !id) { mmd_set_error("mmd_comm_init_rccl: bad arguments"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  ncclUniqueId u;
+  memcpy(&u, id, 128);
+  ncclComm_t c;
+  NCCL_TRY(ncclCommInitRank(&c, nranks, u, rank));
+  h->rccl = (void*)c;
+  return 0;
+}
+
+extern "C" int mmd_comm_set_host_transport(mmd_handle* h, mmd_sendrecv_fn sr, mmd_allreduce_fn ar, void* ctx)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  h->host_sr = sr; h->host_ar = ar; h->host_ctx = ctx;
+  return 0;
+}
+
+// device buffers in, device buffers out; byte counts
+int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int dest, void* drecv, size_t nrecv, int src)
+{
+  if(h->rccl) {
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    NCCL_TRY(ncclGroupStart());
+    if(nsend) NCCL_TRY(ncclSend(dsend, nsend, ncclChar, dest, c, h->stream));
+    if(nrecv) NCCL_TRY(ncclRecv(drecv, nrecv, ncclChar, src, c, h->stream));
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+  }
+  if(h->host_sr) {
+    if(h->stage_send.size() < nsend + 8) h->stage_send.resize(nsend + 8);
+    if(h->stage_recv.size() < nrecv + 8) h->stage_recv.resize(nrecv + 8);
+    if(nsend) HIP_TRY(hipMemcpyAsync(h->stage_send.data(), dsend, nsend, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const long long got = h->host_sr(h->host_ctx, h->stage_send.data(), (long long)nsend, dest, h->stage_recv.data(), (long long)nrecv, src);
+    if(got != (long long)nrecv) { mmd_set_error("host transport: expected %zu bytes from rank %d, got %lld", nrecv, src, got); return -1; }
+    if(nrecv) HIP_TRY(hipMemcpyAsync(drecv, h->stage_recv.data(), nrecv, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  }
+  mmd_set_error("rank %d has a remote partner but no transport is attached (mmd_comm_init_rccl / mmd_comm_set_host_transport)", h->me);
+  return -1;
+}
+
+int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv, int src)
+{
+  if(h->rccl) {
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    h->h_flags[8] = nsend;
+    HIP_TRY(hipMemcpyAsync(h->d_flags + 8, h->h_flags + 8, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(ncclGroupStart());
+    NCCL_TRY(ncclSend(h->d_flags + 8, 1, ncclInt, dest, c, h->stream));
+    NCCL_TRY(ncclRecv(h->d_flags + 9, 1, ncclInt, src, c, h->stream));
+    NCCL_TRY(ncclGroupEnd());
+    HIP_TRY(hipMemcpyAsync(h->h_flags + 9, h->d_flags + 9, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *nrecv = h->h_flags[9];
+    return 0;
+  }
+  if(h->host_sr) {
+    int out = 0;
+    const long long got = h->host_sr(h->host_ctx, &nsend, sizeof(int), dest, &out, sizeof(int), src);
+    if(got != (long long)sizeof(int)) { mmd_set_error("host transport: count handshake failed"); return -1; }
+    *nrecv = out;
+    return 0;
+  }
+  mmd_set_error("rank %d has a remote partner but no transport is attached", h->me);
+  return -1;
+}
+
+// in-place sum over ranks of vals[0..n) (MPI_Allreduce SUM of the thermo scalars, ref/thermo.cpp:131,168,188)
+int mmd_transport_allreduce(mmd_handle* h, double* vals, int n)
+{
+  if(h->nprocs == 1) return 0;
+  if(h->rccl) {
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    HIP_TRY(hipMemcpyAsync(h->d_result + 8, vals, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(ncclAllReduce(h->d_result + 8, h->d_result + 8, n, ncclDouble, ncclSum, c, h->stream));
+    HIP_TRY(hipMemcpyAsync(vals, h->d_result + 8, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  }
+  if(h->host_ar) {
+    if(h->host_ar(h->host_ctx, vals, n)) { mmd_set_error("host transport: allreduce failed"); return -1; }
+    return 0;
+  }
+  mmd_set_error("no transport attached for allreduce");
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ordered stream compaction: out[] = ascending indices i in [first, first+n) with pred(i)
+// ---------------------------------------------------------------------------------------------------
+struct SlabPred {      // Comm::borders selection, closed slab (ref/comm.cpp:776)
+  const real4* x; int dim; real lo, hi;
+  __device__ bool operator()(int i) const { const real4 p = x[i]; const real c = dim == 0 ? p.x : (dim == 1 ? p.y : p.z); return c >= lo && c <= hi; }
+};
+struct LeavePred {     // Comm::exchange leavers, half-open box (ref/comm.cpp:440)
+  const real4* x; int dim; real lo, hi;
+  __device__ bool operator()(int i) const { const real4 p = x[i]; const real c = dim == 0 ? p.x : (dim == 1 ? p.y : p.z); return c < lo || c >= hi; }
+};
+struct StayPred {
+  const real4* x; int dim; real lo, hi;
+  __device__ bool operator()(int i) const { const real4 p = x[i]; const real c = dim == 0 ? p.x : (dim == 1 ? p.y : p.z); return !(c < lo || c >= hi); }
+};
+struct ExchRec {       // Atom::pack_exchange payload (ref/atom.cpp:228-239) + tag
+  real x, y, z, w, vx, vy, vz;
+  int tag, pad;
+};
+struct ArrivePred {    // arrivals that fall inside my box in this dimension (ref/comm.cpp:566-571)
+  const ExchRec* r; int dim; real lo, hi;
+  __device__ bool operator()(int i) const { const real c = dim == 0 ? r[i].x : (dim == 1 ? r[i].y : r[i].z); return c >= lo && c < hi; }
+};
+
+#define CP_TILE 1024
+template <class Pred>
+__global__ __launch_bounds__(256) void k_compact_count(Pred pred, int first, int n, int* __restrict__ tile_counts)
+{
+  __shared__ int lds[17];
+  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) if(base + k < n) c += pred(first + base + k) ? 1 : 0;
+  int tot;
+  block_incl_scan(c, lds, &tot);
+  if(threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+template <class Pred>
+__global__ __launch_bounds__(256) void k_compact_scatter(Pred pred, int first, int n, const int* __restrict__ tile_offsets,
+                                                         int* __restrict__ out)
+{
+  __shared__ int lds[17];
+  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  bool fl[4];
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) { fl[k] = base + k < n && pred(first + base + k); c += fl[k] ? 1 : 0; }
+  int tot;
+  const int inc = block_incl_scan(c, lds, &tot);
+  int pos = tile_offsets[blockIdx.x] + inc - c;
+#pragma unroll
+  for(int k = 0; k < 4; k++) if(fl[k]) out[pos++] = first + base + k;
+}
+
+template <class Pred>
+static int compact(mmd_handle* h, Pred pred, int first, int n, DevArr<int>& out, int* count)
+{
+  *count = 0;
+  if(n <= 0) return 0;
+  const int ntiles = div_up(n, CP_TILE);
+  MMD_TRY(h->flag_tmp.ensure((size_t)ntiles + 8, false, h->stream));
+  hipLaunchKernelGGL((k_compact_count<Pred>), dim3(ntiles), dim3(256), 0, h->stream, pred, first, n, h->flag_tmp.p);
+  int total = 0;
+  MMD_TRY(mmd_exclusive_scan(h, h->flag_tmp.p, ntiles, &total));
+  if(total) {
+    MMD_TRY(out.ensure((size_t)total + 8, false, h->stream));
+    hipLaunchKernelGGL((k_compact_scatter<Pred>), dim3(ntiles), dim3(256), 0, h->stream, pred, first, n, h->flag_tmp.p, out.p);
+  }
+  HIP_TRY(hipGetLastError());
+  *count = total;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Comm::communicate (ref/comm.cpp:276-317) — forward halo of positions
+// ---------------------------------------------------------------------------------------------------
+// pack (+ PBC shift) ; for a self swap `dst` is x + firstrecv: Atom::pack_comm + unpack_comm fused
+__global__ __launch_bounds__(256) void k_pack_comm(const real4* __restrict__ x, const int* __restrict__ list, int n,
+                                                   real sx, real sy, real sz, int pbc_any, real4* __restrict__ dst)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) return;
+  real4 p = x[list[i]];
+  if(pbc_any) { p.x += sx; p.y += sy; p.z += sz; }     // x + pbc_flag*prd, flag*prd is exact (flag in {-1,0,1})
+  dst[i] = p;
+}
+
+extern "C" int mmd_comm_communicate(mmd_handle* h)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  for(auto& s : h->swaps) {
+    const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
+    if(s.sendproc == h->me) {
+      if(s.sendnum)
+        hipLaunchKernelGGL(k_pack_comm, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->x.p, s.sendlist.p, s.sendnum,
+                           sx, sy, sz, s.pbc_any, h->x.p + s.firstrecv);
+    } else {
+      MMD_TRY(h->buf_send.ensure((size_t)4 * s.sendnum + 8, false, h->stream));
+      if(s.sendnum)
+        hipLaunchKernelGGL(k_pack_comm, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->x.p, s.sendlist.p, s.sendnum,
+                           sx, sy, sz, s.pbc_any, (real4*)h->buf_send.p);
+      MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)s.sendnum * sizeof(real4), s.sendproc, h->x.p + s.firstrecv,
+                                     (size_t)s.recvnum * sizeof(real4), s.recvproc));
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Comm::reverse_communicate (ref/comm.cpp:321-355) — ghost forces back to their owners
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unpack_reverse(real* __restrict__ f, const int* __restrict__ list, int n,
+                                                        const real* __restrict__ src)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) return;
+  const int j = list[i];
+  f[3 * (size_t)j + 0] += src[3 * (size_t)i + 0];
+  f[3 * (size_t)j + 1] += src[3 * (size_t)i + 1];
+  f[3 * (size_t)j + 2] += src[3 * (size_t)i + 2];
+}
+
+extern "C" int mmd_comm_reverse_communicate(mmd_handle* h)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  for(int is = (int)h->swaps.size() - 1; is >= 0; is--) {
+    Swap& s = h->swaps[is];
+    const real* ghost_f = h->f.p + 3 * (size_t)s.firstrecv;     // Atom::pack_reverse is a contiguous slice
+    if(s.sendproc == h->me) {
+      if(s.sendnum) hipLaunchKernelGGL(k_unpack_reverse, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->f.p, s.sendlist.p, s.sendnum, ghost_f);
+    } else {
+      MMD_TRY(h->buf_recv.ensure((size_t)3 * s.sendnum + 8, false, h->stream));
+      MMD_TRY(mmd_transport_sendrecv(h, ghost_f, (size_t)3 * s.recvnum * sizeof(real), s.recvproc, h->buf_recv.p,
+                                     (size_t)3 * s.sendnum * sizeof(real), s.sendproc));
+      if(s.sendnum) hipLaunchKernelGGL(k_unpack_reverse, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->f.p, s.sendlist.p, s.sendnum, h->buf_recv.p);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Comm::exchange (ref/comm.cpp:364-597) — PBC wrap + migration of atoms that left the sub-box
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_exchange(const real4* __restrict__ x, const real* __restrict__ v, const int* __restrict__ tag,
+                                                       const int* __restrict__ leavers, int n, ExchRec* __restrict__ out)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= n) return;
+  const int i = leavers[k];
+  const real4 p = x[i];
+  ExchRec r;
+  r.x = p.x; r.y = p.y; r.z = p.z; r.w = p.w;
+  r.vx = v[3 * (size_t)i + 0]; r.vy = v[3 * (size_t)i + 1]; r.vz = v[3 * (size_t)i + 2];
+  r.tag = tag[i]; r.pad = 0;
+  out[k] = r;
+}
+// the k-th hole (leaver below the new end) takes the k-th stayer of the tail: Atom::copy (ref/comm.cpp:491-509)
+__global__ __launch_bounds__(256) void k_fill_holes(real4* __restrict__ x, real* __restrict__ v, int* __restrict__ type, int* __restrict__ tag,
+                                                    const int* __restrict__ holes, const int* __restrict__ fillers, int n)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= n) return;
+  const int dst = holes[k], src = fillers[k];
+  x[dst] = x[src];
+  v[3 * (size_t)dst + 0] = v[3 * (size_t)src + 0]; v[3 * (size_t)dst + 1] = v[3 * (size_t)src + 1]; v[3 * (size_t)dst + 2] = v[3 * (size_t)src + 2];
+  type[dst] = type[src];
+  tag[dst] = tag[src];
+}
+__global__ __launch_bounds__(256) void k_unpack_exchange(const ExchRec* __restrict__ rec, const int* __restrict__ keep, int n, int first,
+                                                         real4* __restrict__ x, real* __restrict__ v, int* __restrict__ type, int* __restrict__ tag)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= n) return;
+  const ExchRec r = rec[keep[k]];
+  const int i = first + k;
+  x[i] = real4{r.x, r.y, r.z, r.w};
+  v[3 * (size_t)i + 0] = r.vx; v[3 * (size_t)i + 1] = r.vy; v[3 * (size_t)i + 2] = r.vz;
+  type[i] = (int)r.w;
+  tag[i] = r.tag;
+}
+
+extern "C" int mmd_comm_exchange(mmd_handle* h)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  MMD_TRY(mmd_atom_pbc(h));
+  h->nghost = 0;                       // ghost slots are reused by arrivals; borders() rebuilds them next
+  static_assert(sizeof(ExchRec) % sizeof(real) == 0, "ExchRec must be a whole number of reals");
+  const size_t rec_reals = sizeof(ExchRec) / sizeof(real);
+  DevArr<int> leavers, fillers, keep;
+  for(int d = 0; d < 3; d++) {
+    if(h->procgrid[d] == 1) continue;
+    const real lo = h->lo[d], hi = h->hi[d];
+    const int nlocal = h->nlocal;
+    int nsend = 0;
+    MMD_TRY(compact(h, LeavePred{h->x.p, d, lo, hi}, 0, nlocal, leavers, &nsend));
+    MMD_TRY(h->buf_send.ensure(rec_reals * nsend + 8, false, h->stream));
+    if(nsend) {
+      hipLaunchKernelGGL(k_pack_exchange, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->v.p, h->tag.p, leavers.p, nsend, (ExchRec*)h->buf_send.p);
+      int nfill = 0;
+      MMD_TRY(compact(h, StayPred{h->x.p, d, lo, hi}, nlocal - nsend, nsend, fillers, &nfill));
+      // leavers are ascending, so the holes (index < nlocal-nsend) are exactly its first nfill entries
+      if(nfill) hipLaunchKernelGGL(k_fill_holes, dim3(div_up(nfill, 256)), dim3(256), 0, h->stream, h->x.p, h->v.p, h->type.p, h->tag.p, leavers.p, fillers.p, nfill);
+      HIP_TRY(hipGetLastError());
+    }
+    h->nlocal = nlocal - nsend;
+    // send towards -1, receive from +1; and the other way round when the grid is wider than 2 (ref :521-543)
+    int nrecv1 = 0, nrecv2 = 0;
+    MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, h->procneigh[d][0], &nrecv1, h->procneigh[d][1]));
+    if(h->procgrid[d] > 2) MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, h->procneigh[d][1], &nrecv2, h->procneigh[d][0]));
+    const int nrecv = nrecv1 + nrecv2;
+    MMD_TRY(h->buf_recv.ensure(rec_reals * nrecv + 8, false, h->stream));
+    MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)nsend * sizeof(ExchRec), h->procneigh[d][0], h->buf_recv.p,
+                                   (size_t)nrecv1 * sizeof(ExchRec), h->procneigh[d][1]));
+    if(h->procgrid[d] > 2)
+      MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)nsend * sizeof(ExchRec), h->procneigh[d][1],
+                                     (ExchRec*)h->buf_recv.p + nrecv1, (size_t)nrecv2 * sizeof(ExchRec), h->procneigh[d][0]));
+    int nkeep = 0;
+    MMD_TRY(compact(h, ArrivePred{(const ExchRec*)h->buf_recv.p, d, lo, hi}, 0, nrecv, keep, &nkeep));
+    if(nkeep) {
+      MMD_TRY(mmd_ensure_atoms(h, h->nlocal + nkeep + 1, true));
+      hipLaunchKernelGGL(k_unpack_exchange, dim3(div_up(nkeep, 256)), dim3(256), 0, h->stream, (const ExchRec*)h->buf_recv.p, keep.p, nkeep,
+                         h->nlocal, h->x.p, h->v.p, h->type.p, h->tag.p);
+      HIP_TRY(hipGetLastError());
+      h->nlocal += nkeep;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  leavers.release(); fillers.release(); keep.release();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Comm::borders (ref/comm.cpp:700-883) — ghost atoms + send lists, swap by swap (later swaps forward
+// ghosts received by earlier ones, so the order x-,x+,y-,y+,z-,z+ is kept)
+// ---------------------------------------------------------------------------------------------------
+// image code of a ghost = (sx+2) + 5*(sy+2) + 25*(sz+2): accumulated periodic shifts in box lengths
+__device__ __forceinline__ int image_add(int code, int px, int py, int pz)
+{
+  const int sx = code % 5 + px, sy = (code / 5) % 5 + py, sz = code / 25 + pz;
+  return min(max(sx, 0), 4) + 5 * min(max(sy, 0), 4) + 25 * min(max(sz, 0), 4);
+}
+#define IMAGE_NONE 62      // (0,0,0)
+
+// Atom::pack_border (ref/atom.cpp:197-214): {x+shift, type} -> dst (real4), image code -> dst_img
+__global__ __launch_bounds__(256) void k_pack_border(const real4* __restrict__ x, const int* __restrict__ ghost_image, int nlocal,
+                                                     const int* __restrict__ list, int n, real sx, real sy, real sz, int pbc_any,
+                                                     int px, int py, int pz, real4* __restrict__ dst, int* __restrict__ dst_img)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= n) return;
+  const int i = list[k];
+  real4 p = x[i];
+  if(pbc_any) { p.x += sx; p.y += sy; p.z += sz; }
+  dst[k] = p;
+  const int code = i < nlocal ? IMAGE_NONE : ghost_image[i - nlocal];
+  dst_img[k] = image_add(code, px, py, pz);
+}
+// Atom::unpack_border tail (ref/atom.cpp:216-226): integer type array of the new ghosts
+__global__ __launch_bounds__(256) void k_ghost_types(const real4* __restrict__ x, int first, int n, int* __restrict__ type)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= n) return;
+  type[first + k] = (int)x[first + k].w;
+}
+
+extern "C" int mmd_comm_borders(mmd_handle* h)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  h->nghost = 0;
+  int iswap = 0;
+  MMD_TRY(h->ghost_image.ensure(1024, false, h->stream));
+  for(int d = 0; d < 3; d++) {
+    int nfirst = 0, nlast = 0;
+    for(int ineed = 0; ineed < 2 * h->need[d]; ineed++, iswap++) {
+      Swap& s = h->swaps[iswap];
+      if(ineed % 2 == 0) { nfirst = nlast; nlast = h->nlocal + h->nghost; }
+      int nsend = 0;
+      MMD_TRY(compact(h, SlabPred{h->x.p, d, s.slablo, s.slabhi}, nfirst, nlast - nfirst, s.sendlist, &nsend));
+      const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
+      const int nall = h->nlocal + h->nghost;
+      int nrecv = nsend;
+      if(s.sendproc == h->me) {
+        MMD_TRY(mmd_ensure_atoms(h, nall + nrecv + 1, true));
+        MMD_TRY(h->ghost_image.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
+        if(nsend)
+          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->nlocal,
+                             s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], h->x.p + nall,
+                             h->ghost_image.p + h->nghost);
+      } else {
+        // message = nsend real4 followed by nsend image codes
+        const size_t bytes_s = (size_t)nsend * (sizeof(real4) + sizeof(int));
+        MMD_TRY(h->buf_send.ensure(bytes_s / sizeof(real) + 8, false, h->stream));
+        int* simg = (int*)((real4*)h->buf_send.p + nsend);
+        if(nsend)
+          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->nlocal,
+                             s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], (real4*)h->buf_send.p, simg);
+        MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, s.sendproc, &nrecv, s.recvproc));
+        const size_t bytes_r = (size_t)nrecv * (sizeof(real4) + sizeof(int));
+        MMD_TRY(h->buf_recv.ensure(bytes_r / sizeof(real) + 8, false, h->stream));
+        MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, bytes_s, s.sendproc, h->buf_recv.p, bytes_r, s.recvproc));
+        MMD_TRY(mmd_ensure_atoms(h, nall + nrecv + 1, true));
+        MMD_TRY(h->ghost_image.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
+        if(nrecv) {
+          HIP_TRY(hipMemcpyAsync(h->x.p + nall, h->buf_recv.p, (size_t)nrecv * sizeof(real4), hipMemcpyDeviceToDevice, h->stream));
+          HIP_TRY(hipMemcpyAsync(h->ghost_image.p + h->nghost, (real4*)h->buf_recv.p + nrecv, (size_t)nrecv * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        }
+      }
+      if(nrecv) hipLaunchKernelGGL(k_ghost_types, dim3(div_up(nrecv, 256)), dim3(256), 0, h->stream, h->x.p, nall, nrecv, h->type.p);
+      HIP_TRY(hipGetLastError());
+      s.sendnum = nsend;
+      s.recvnum = nrecv;
+      s.firstrecv = nall;
+      h->nghost += nrecv;
+    }
+  }
+  MMD_TRY(mmd_set_dummy(h));
+  h->neigh_nlocal = 0;                 // any existing neighbor list is stale now
+  return 0;
+}

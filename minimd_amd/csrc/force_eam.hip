@@ -1,0 +1,292 @@
+// minimd_amd/csrc/force_eam.hip — ForceEAM::compute_fullneigh (ref/force_eam.cpp:274-449) as two HIP sweeps
+// over the wave-interleaved neighbor rows, with the derivative-of-embedding halo (ForceEAM::communicate,
+// ref/force_eam.cpp:851-913) between them.
+//
+//   sweep 1  k_eam_density : rho_i = sum_j rho(r_ij) (cubic spline), fp_i = F'(rho_i), [EV] E_embed
+//   halo     fp of owned atoms -> ghosts (same send lists as Comm::communicate, 1 scalar per atom)
+//   sweep 2  k_eam_force   : f_i = -sum_j (fp_i rho' + fp_j rho' + phi') / r * del ; [EV] phi/2, virial
+//
+// The spline knots used inside the pair loops are re-packed per sweep and staged in LDS
+// (sweep 1: 4 coeffs/knot = 16 KB DP; sweep 2: 3 rho' + 7 z2r coeffs padded to 12 = 48 KB DP), since every
+// lane looks up a different knot each iteration; the per-atom embedding lookup reads HBM/L2 directly.
+// All type pairs share one table in miniMD (ref/force_eam.cpp:753-760) — verified at setup; otherwise the
+// general kernels index the per-pair tables in global memory.
+#include "device_utils.hpp"
+#include "mmd_internal.hpp"
+
+#define EAM_MAX_KNOTS 1024
+
+// ---- sweep 1 --------------------------------------------------------------------------------------
+template <int EV, int UNIFORM>
+__global__ __launch_bounds__(MMD_BLOCK) void k_eam_density(const real4* __restrict__ x, const int* __restrict__ neigh,
+                                                           const int* __restrict__ wave_max, int nlocal, int maxneighs,
+                                                           const real* __restrict__ rhor_spline, const real* __restrict__ frho_spline,
+                                                           const real* __restrict__ cutforcesq, int ntypes, int nr, int nrho,
+                                                           int nr_tot, int nrho_tot, real rdr, real rdrho,
+                                                           real* __restrict__ fp, double* __restrict__ partials)
+{
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  real* s_tab = (real*)s_raw;                           // [knot][4] : coeffs 3..6 of rhor_spline (UNIFORM only)
+  __shared__ double s_red[16];
+  if(UNIFORM) {
+    for(int t = threadIdx.x; t < (nr + 1) * 4; t += blockDim.x) s_tab[t] = rhor_spline[(t >> 2) * 7 + 3 + (t & 3)];
+    __syncthreads();
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = i >> 6, lane = threadIdx.x & 63;
+  const bool owned = i < nlocal;
+  const real4 xi = x[owned ? i : nlocal - 1];
+  const int ti = (int)xi.w;
+  const int nwaves = (nlocal + 63) >> 6;
+  const int kmax = w < nwaves ? __builtin_amdgcn_readfirstlane(wave_max[w]) : 0;
+  const int* __restrict__ np = neigh + ((size_t)w * maxneighs) * 64 + lane;
+  const real cut0 = cutforcesq[0];
+  real rhoi = 0;
+  for(int k = 0; k < kmax; k += MMD_UNROLL) {
+    int j[MMD_UNROLL];
+    real4 xj[MMD_UNROLL];
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) j[u] = np[(size_t)(k + u) * 64];
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) xj[u] = x[j[u]];
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) {
+      const real dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
+      const real rsq = dx * dx + dy * dy + dz * dz;
+      const int tij = UNIFORM ? 0 : ti * ntypes + (int)xj[u].w;
+      const real cut = UNIFORM ? cut0 : cutforcesq[tij];
+      if(rsq < cut) {
+        real p = sqrt(rsq) * rdr + (real)1.0;
+        int m = (int)p;
+        m = m < nr - 1 ? m : nr - 1;
+        p -= m;
+        p = p < (real)1.0 ? p : (real)1.0;
+        real c3, c4, c5, c6;
+        if(UNIFORM) { const real* c = &s_tab[m * 4]; c3 = c[0]; c4 = c[1]; c5 = c[2]; c6 = c[3]; }
+        else { const real* c = &rhor_spline[(size_t)tij * nr_tot + m * 7]; c3 = c[3]; c4 = c[4]; c5 = c[5]; c6 = c[6]; }
+        rhoi += ((c3 * p + c4) * p + c5) * p + c6;
+      }
+    }
+  }
+  double e_acc = 0;
+  if(owned) {
+    const int tii = UNIFORM ? 0 : ti * ti;              // sic (ref/force_eam.cpp:337)
+    real p = (real)1.0 * rhoi * rdrho + (real)1.0;
+    int m = (int)p;
+    m = max(1, min(m, nrho - 1));
+    p -= m;
+    p = p < (real)1.0 ? p : (real)1.0;
+    const real* c = &frho_spline[(size_t)tii * nrho_tot + m * 7];
+    fp[i] = (c[0] * p + c[1]) * p + c[2];
+    if(EV) e_acc = (double)(((c[3] * p + c[4]) * p + c[5]) * p + c[6]);
+  }
+  if(EV) {
+    const double es = block_sum(e_acc, s_red);
+    if(threadIdx.x == 0) partials[3 * (size_t)blockIdx.x] = es;
+  }
+}
+
+// ---- sweep 2 --------------------------------------------------------------------------------------
+template <int EV, int UNIFORM>
+__global__ __launch_bounds__(MMD_BLOCK) void k_eam_force(const real4* __restrict__ x, const int* __restrict__ neigh,
+                                                         const int* __restrict__ wave_max, int nlocal, int maxneighs,
+                                                         const real* __restrict__ rhor_spline, const real* __restrict__ z2r_spline,
+                                                         const real* __restrict__ cutforcesq, int ntypes, int nr, int nr_tot, real rdr,
+                                                         const real* __restrict__ fp, real* __restrict__ f, double* __restrict__ partials)
+{
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  real* s_tab = (real*)s_raw;                           // [knot][12]: rhor 0..2, z2r 0..6, pad (UNIFORM only)
+  __shared__ double s_red[16];
+  if(UNIFORM) {
+    for(int t = threadIdx.x; t < (nr + 1) * 12; t += blockDim.x) {
+      const int m = t / 12, c = t % 12;
+      s_tab[t] = c < 3 ? rhor_spline[m * 7 + c] : (c < 10 ? z2r_spline[m * 7 + (c - 3)] : (real)0);
+    }
+    __syncthreads();
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = i >> 6, lane = threadIdx.x & 63;
+  const bool owned = i < nlocal;
+  const real4 xi = x[owned ? i : nlocal - 1];
+  const real fpi = fp[owned ? i : nlocal - 1];
+  const int ti = (int)xi.w;
+  const int nwaves = (nlocal + 63) >> 6;
+  const int kmax = w < nwaves ? __builtin_amdgcn_readfirstlane(wave_max[w]) : 0;
+  const int* __restrict__ np = neigh + ((size_t)w * maxneighs) * 64 + lane;
+  const real cut0 = cutforcesq[0];
+  real fx = 0, fy = 0, fz = 0;
+  double e_acc = 0, v_acc = 0;
+  for(int k = 0; k < kmax; k += MMD_UNROLL) {
+    int j[MMD_UNROLL];
+    real4 xj[MMD_UNROLL];
+    real fpj[MMD_UNROLL];
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) j[u] = np[(size_t)(k + u) * 64];
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) { xj[u] = x[j[u]]; fpj[u] = fp[j[u]]; }
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) {
+      const real dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
+      const real rsq = dx * dx + dy * dy + dz * dz;
+      const int tij = UNIFORM ? 0 : ti * ntypes + (int)xj[u].w;
+      const real cut = UNIFORM ? cut0 : cutforcesq[tij];
+      if(rsq < cut) {
+        const real r = sqrt(rsq);
+        real p = r * rdr + (real)1.0;
+        int m = (int)p;
+        m = m < nr - 1 ? m : nr - 1;
+        p -= m;
+        p = p < (real)1.0 ? p : (real)1.0;
+        real r0, r1, r2, z0, z1, z2c, z3, z4, z5, z6;
+        if(UNIFORM) {
+          const real* c = &s_tab[m * 12];
+          r0 = c[0]; r1 = c[1]; r2 = c[2]; z0 = c[3]; z1 = c[4]; z2c = c[5]; z3 = c[6]; z4 = c[7]; z5 = c[8]; z6 = c[9];
+        } else {
+          const real* cr = &rhor_spline[(size_t)tij * nr_tot + m * 7];
+          const real* cz = &z2r_spline[(size_t)tij * nr_tot + m * 7];
+          r0 = cr[0]; r1 = cr[1]; r2 = cr[2]; z0 = cz[0]; z1 = cz[1]; z2c = cz[2]; z3 = cz[3]; z4 = cz[4]; z5 = cz[5]; z6 = cz[6];
+        }
+        const real rhoip = (r0 * p + r1) * p + r2;
+        const real z2p = (z0 * p + z1) * p + z2c;
+        const real z2 = ((z3 * p + z4) * p + z5) * p + z6;
+        const real recip = (real)1.0 / r;
+        const real phi = z2 * recip;
+        const real phip = z2p * recip - phi * recip;
+        const real psip = fpi * rhoip + fpj[u] * rhoip + phip;
+        real fpair = -psip * recip;
+        fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
+        if(EV) {
+          fpair *= (real)0.5;
+          v_acc += (double)(dx * dx * fpair + dy * dy * fpair + dz * dz * fpair);
+          e_acc += (double)((real)0.5 * phi);
+        }
+      }
+    }
+  }
+  if(owned) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
+  if(EV) {
+    const double es = block_sum(e_acc, s_red);
+    const double vs = block_sum(v_acc, s_red);
+    if(threadIdx.x == 0) { partials[3 * (size_t)blockIdx.x + 1] = es; partials[3 * (size_t)blockIdx.x + 2] = vs; }
+  }
+}
+
+// eng_vdwl = 2*(E_embed + sum phi/2) (ref/force_eam.cpp:446), virial = sum
+__global__ __launch_bounds__(1024) void k_eam_sum(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
+{
+  __shared__ double s_red[16];
+  double a = 0, b = 0, c = 0;
+  for(int k = threadIdx.x; k < nblocks; k += blockDim.x) { a += partials[3 * (size_t)k]; b += partials[3 * (size_t)k + 1]; c += partials[3 * (size_t)k + 2]; }
+  const double ta = block_sum(a, s_red), tb = block_sum(b, s_red), tc = block_sum(c, s_red);
+  if(threadIdx.x == 0) { out[0] = 2.0 * (ta + tb); out[1] = tc; }
+}
+
+__global__ __launch_bounds__(256) void k_fp_self(real* __restrict__ fp, const int* __restrict__ list, int n, int first)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n) fp[first + i] = fp[list[i]];
+}
+__global__ __launch_bounds__(256) void k_fp_pack(const real* __restrict__ fp, const int* __restrict__ list, int n, real* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n) out[i] = fp[list[i]];
+}
+
+// ForceEAM::communicate (ref/force_eam.cpp:851-887): one scalar per send-list atom, swap by swap
+static int eam_fp_halo(mmd_handle* h)
+{
+  for(auto& s : h->swaps) {
+    if(s.sendproc == h->me) {
+      if(s.sendnum) hipLaunchKernelGGL(k_fp_self, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->fp.p, s.sendlist.p, s.sendnum, s.firstrecv);
+    } else {
+      MMD_TRY(h->buf_send.ensure((size_t)s.sendnum + 8, false, h->stream));
+      if(s.sendnum) hipLaunchKernelGGL(k_fp_pack, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->fp.p, s.sendlist.p, s.sendnum, h->buf_send.p);
+      MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)s.sendnum * sizeof(real), s.sendproc, h->fp.p + s.firstrecv,
+                                     (size_t)s.recvnum * sizeof(real), s.recvproc));
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mmd_force_eam_setup(mmd_handle* h, int ntypes, int nr, int nrho, int nr_tot, int nrho_tot, mmd_float rdr,
+                                   mmd_float rdrho, const mmd_float* rhor_spline, const mmd_float* frho_spline,
+                                   const mmd_float* z2r_spline, const mmd_float* cutforcesq)
+{
+  if(!h || ntypes < 1 || !rhor_spline || !frho_spline || !z2r_spline || !cutforcesq) { mmd_set_error("mmd_force_eam_setup: bad arguments"); return -1; }
+  if((nr + 1) * 7 > nr_tot || (nrho + 1) * 7 > nrho_tot) { mmd_set_error("mmd_force_eam_setup: table strides too small"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  h->style = 1;
+  h->ntypes = ntypes;
+  h->nr = nr; h->nrho = nrho; h->nr_tot = nr_tot; h->nrho_tot = nrho_tot; h->rdr = rdr; h->rdrho = rdrho;
+  const int nt2 = ntypes * ntypes;
+  bool uni = nr + 1 <= EAM_MAX_KNOTS;
+  for(int t = 1; t < nt2 && uni; t++) {
+    if(cutforcesq[t] != cutforcesq[0]) uni = false;
+    if(memcmp(rhor_spline + (size_t)t * nr_tot, rhor_spline, sizeof(real) * (nr + 1) * 7)) uni = false;
+    if(memcmp(z2r_spline + (size_t)t * nr_tot, z2r_spline, sizeof(real) * (nr + 1) * 7)) uni = false;
+    if(memcmp(frho_spline + (size_t)t * nrho_tot, frho_spline, sizeof(real) * (nrho + 1) * 7)) uni = false;
+  }
+  h->eam_uniform = uni;
+  h->h_cutforcesq.assign(cutforcesq, cutforcesq + nt2);
+  MMD_TRY(h->rhor_spline.ensure((size_t)nt2 * nr_tot, false, h->stream));
+  MMD_TRY(h->z2r_spline.ensure((size_t)nt2 * nr_tot, false, h->stream));
+  MMD_TRY(h->frho_spline.ensure((size_t)nt2 * nrho_tot, false, h->stream));
+  MMD_TRY(h->lj_tables.ensure((size_t)nt2 + 8, false, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->rhor_spline.p, rhor_spline, sizeof(real) * (size_t)nt2 * nr_tot, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->z2r_spline.p, z2r_spline, sizeof(real) * (size_t)nt2 * nr_tot, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->frho_spline.p, frho_spline, sizeof(real) * (size_t)nt2 * nrho_tot, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->lj_tables.p, cutforcesq, sizeof(real) * nt2, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
+{
+  if(h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_force_compute: neighbor list is stale (build or upload one first)"); return -1; }
+  if(h->halfneigh) { mmd_set_error("EAM with half neighbor lists is not implemented on the device yet (use --half_neigh 0)"); return -1; }
+  const int nlocal = h->nlocal, nall = nlocal + h->nghost;
+  if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
+  const int nblocks = div_up(nlocal, MMD_BLOCK);
+  MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
+  MMD_TRY(h->partials.ensure((size_t)3 * nblocks + 8, false, h->stream));
+  const size_t lds1 = h->eam_uniform ? (size_t)(h->nr + 1) * 4 * sizeof(real) : 0;
+  const size_t lds2 = h->eam_uniform ? (size_t)(h->nr + 1) * 12 * sizeof(real) : 0;
+#define D(EVv, Uv)                                                                                                        \
+  hipLaunchKernelGGL((k_eam_density<EVv, Uv>), dim3(nblocks), dim3(MMD_BLOCK), lds1, h->stream, h->x.p, h->neigh.p,       \
+                     h->wave_max.p, nlocal, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->lj_tables.p, h->ntypes,  \
+                     h->nr, h->nrho, h->nr_tot, h->nrho_tot, h->rdr, h->rdrho, h->fp.p, h->partials.p)
+#define FK(EVv, Uv)                                                                                                       \
+  hipLaunchKernelGGL((k_eam_force<EVv, Uv>), dim3(nblocks), dim3(MMD_BLOCK), lds2, h->stream, h->x.p, h->neigh.p,         \
+                     h->wave_max.p, nlocal, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->lj_tables.p, h->ntypes,   \
+                     h->nr, h->nr_tot, h->rdr, h->fp.p, h->f.p, h->partials.p)
+  const bool ev = evflag != 0, uni = h->eam_uniform;
+  if(ev && uni) D(1, 1); else if(ev) D(1, 0); else if(uni) D(0, 1); else D(0, 0);
+  HIP_TRY(hipGetLastError());
+  MMD_TRY(eam_fp_halo(h));
+  if(ev && uni) FK(1, 1); else if(ev) FK(1, 0); else if(uni) FK(0, 1); else FK(0, 0);
+#undef D
+#undef FK
+  HIP_TRY(hipGetLastError());
+  if(evflag) {
+    hipLaunchKernelGGL(k_eam_sum, dim3(1), dim3(1024), 0, h->stream, h->partials.p, nblocks, h->d_result);
+    HIP_TRY(hipGetLastError());
+    if(eng || vir) {
+      HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if(eng) *eng = h->h_result[0];
+      if(vir) *vir = h->h_result[1];
+    }
+  }
+  return 0;
+}
+
+extern "C" int mmd_force_eam_download_fp(mmd_handle* h, mmd_float* fp)
+{
+  if(!h || !fp) { mmd_set_error("mmd_force_eam_download_fp: bad arguments"); return -1; }
+  const int nall = h->nlocal + h->nghost;
+  if(h->fp.cap < (size_t)nall) { mmd_set_error("mmd_force_eam_download_fp: no EAM force has been computed"); return -1; }
+  HIP_TRY(hipMemcpyAsync(fp, h->fp.p, (size_t)nall * sizeof(real), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}

@@ -1,0 +1,95 @@
+// minimd_amd/csrc/integrate.hip — Integrate::initialIntegrate/finalIntegrate (ref/integrate.cpp:46-68) and the
+// kinetic-energy sum of Thermo::temperature (ref/thermo.cpp:151-157). Pure HBM streams; compiled with
+// -ffp-contract=off so v += dtforce*f ; x += dt*v round exactly like the reference.
+#include "device_utils.hpp"
+#include "mmd_internal.hpp"
+
+__global__ __launch_bounds__(256) void k_initial_integrate(real4* __restrict__ x, real* __restrict__ v, const real* __restrict__ f,
+                                                           int n, real dt, real dtforce)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) return;
+  real4 p = x[i];
+  real vx = v[3 * (size_t)i + 0], vy = v[3 * (size_t)i + 1], vz = v[3 * (size_t)i + 2];
+  vx += dtforce * f[3 * (size_t)i + 0];
+  vy += dtforce * f[3 * (size_t)i + 1];
+  vz += dtforce * f[3 * (size_t)i + 2];
+  p.x += dt * vx; p.y += dt * vy; p.z += dt * vz;
+  v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
+  x[i] = p;
+}
+
+__global__ __launch_bounds__(256) void k_final_integrate(real* __restrict__ v, const real* __restrict__ f, int n, real dtforce)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= 3 * n) return;
+  v[i] += dtforce * f[i];
+}
+
+__global__ __launch_bounds__(256) void k_temperature(const real* __restrict__ v, int n, real mass, double* __restrict__ partials)
+{
+  __shared__ double s_red[16];
+  double t = 0;
+  for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const real vx = v[3 * (size_t)i + 0], vy = v[3 * (size_t)i + 1], vz = v[3 * (size_t)i + 2];
+    t += (double)((vx * vx + vy * vy + vz * vz) * mass);
+  }
+  const double s = block_sum(t, s_red);
+  if(threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(1024) void k_sum1(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
+{
+  __shared__ double s_red[16];
+  double s = 0;
+  for(int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[b];
+  const double t = block_sum(s, s_red);
+  if(threadIdx.x == 0) *out = t;
+}
+
+extern "C" int mmd_integrate_setup(mmd_handle* h, mmd_float dt, mmd_float dtforce, int neigh_every, int sort_every)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  if(neigh_every < 1) { mmd_set_error("mmd_integrate_setup: neigh_every must be >= 1"); return -1; }
+  h->dt = dt; h->dtforce = dtforce; h->neigh_every = neigh_every; h->sort_every = sort_every;
+  return 0;
+}
+
+extern "C" int mmd_integrate_initial(mmd_handle* h)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  if(h->nlocal)
+    hipLaunchKernelGGL(k_initial_integrate, dim3(div_up(h->nlocal, 256)), dim3(256), 0, h->stream, h->x.p, h->v.p, h->f.p, h->nlocal, h->dt, h->dtforce);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mmd_integrate_final(mmd_handle* h)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  if(h->nlocal)
+    hipLaunchKernelGGL(k_final_integrate, dim3(div_up(3LL * h->nlocal, 256)), dim3(256), 0, h->stream, h->v.p, h->f.p, h->nlocal, h->dtforce);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// enqueue the reduction; result lands in h->d_result[slot]
+int mmd_temperature_async(mmd_handle* h, int slot)
+{
+  const int nb = 1024;
+  MMD_TRY(h->partials.ensure((size_t)nb + 8, false, h->stream));
+  hipLaunchKernelGGL(k_temperature, dim3(nb), dim3(256), 0, h->stream, h->v.p, h->nlocal, h->mass, h->partials.p);
+  hipLaunchKernelGGL(k_sum1, dim3(1), dim3(1024), 0, h->stream, h->partials.p, nb, h->d_result + slot);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mmd_thermo_temperature(mmd_handle* h, double* sum_mv2)
+{
+  if(!h || !sum_mv2) { mmd_set_error("mmd_thermo_temperature: bad arguments"); return -1; }
+  MMD_TRY(mmd_temperature_async(h, 2));
+  HIP_TRY(hipMemcpyAsync(h->h_result + 2, h->d_result + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *sum_mv2 = h->h_result[2];
+  return 0;
+}

@@ -1,0 +1,188 @@
+// minimd_amd/csrc/mmd_internal.hpp — internal state of one device handle (not part of the C-ABI).
+//
+// Data layout in HBM (gfx950, one handle per GPU):
+//   x      real4[nmax+1]   position + type packed in .w ((real)type): ONE 32-byte (DP) / 16-byte (SP)
+//                          aligned gather per neighbor in the force kernels; slot [nlocal+nghost] is the
+//                          far-away "dummy" atom that pads neighbor rows (never inside any cutoff)
+//   v, f   real[3*nmax]    AoS stride 3 (streamed only, never gathered)
+//   type, tag int[nmax]
+//   neigh  int[nwaves*maxneighs*64]  wave-interleaved neighbor rows: entry k of atom i lives at
+//                          ((i>>6)*maxneighs + k)*64 + (i&63) so the 64 lanes of a wavefront read one
+//                          coalesced 256-byte line per k;  rows are padded with the dummy index up to the
+//                          wavefront's longest row (rounded up to the unroll factor)
+//   bins   bin_start[mbins+1], binned[nall]: counting-sorted atom indices, bins numbered block-major
+//                          (2x2x2 bins = one block = ~one wavefront of atoms) for L1/L2 locality
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mmd.h"
+
+typedef mmd_float real;
+#if MMD_PRECISION == 1
+typedef float4 real4;
+#else
+typedef double4 real4;
+#endif
+
+#define MMD_WAVE 64
+#define MMD_UNROLL 4            // neighbor rows are padded to a multiple of this
+#define MMD_BLOCK 256
+
+void mmd_set_error(const char* fmt, ...);
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if(_e != hipSuccess) {                                                                         \
+      mmd_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));     \
+      return -1;                                                                                   \
+    }                                                                                              \
+  } while(0)
+#define MMD_TRY(expr)                  \
+  do {                                 \
+    int _r = (expr);                   \
+    if(_r < 0) return _r;              \
+  } while(0)
+
+// growable device array
+template <typename T>
+struct DevArr {
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n, bool preserve, hipStream_t s, size_t preserve_count = (size_t)-1)
+  {
+    if(n <= cap) return 0;
+    size_t ncap = n + n / 8 + 1024;
+    T* q = nullptr;
+    HIP_TRY(hipMalloc((void**)&q, ncap * sizeof(T)));
+    if(preserve && p && cap) {
+      size_t cnt = preserve_count == (size_t)-1 ? cap : (preserve_count < cap ? preserve_count : cap);
+      if(cnt) HIP_TRY(hipMemcpyAsync(q, p, cnt * sizeof(T), hipMemcpyDeviceToDevice, s));
+    }
+    if(p) {
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipFree(p));
+    }
+    p = q;
+    cap = ncap;
+    return 0;
+  }
+  void release()
+  {
+    if(p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct LJParams {            // uniform-table fast path (all type pairs identical, checked at setup)
+  real cutforcesq, sigma6, epsilon;
+};
+
+struct BinGeom {             // Neighbor::setup result (ref/neighbor.cpp:318-452) + block-major numbering
+  real prd[3], bininv[3], binsize[3];
+  int nbin[3], mbinlo[3], mbin[3];
+  int nblk[3];               // 2x2x2-bin blocks per dimension
+  int reach[3];              // stencil reach in BLOCKS (covers ref's next{x,y,z} bins)
+  int mbins;                 // nblk[0]*nblk[1]*nblk[2]*8
+};
+
+struct Swap {                // one of the 2*sum(need) swaps of Comm::setup (ref/comm.cpp:208-269)
+  int dim;
+  real slablo, slabhi;
+  int pbc_any, pbc[3];
+  int sendproc, recvproc;
+  int sendnum = 0, recvnum = 0, firstrecv = 0;
+  DevArr<int> sendlist;
+};
+
+struct EventPair { hipEvent_t a, b; };
+
+struct mmd_handle {
+  int device = 0;
+  bool host_only = false;    // geometry-only handle (mmd_create(-2)): no GPU, host functions only
+  hipStream_t stream = nullptr, comm_stream = nullptr;
+  hipDeviceProp_t prop;
+  // ---- Atom
+  real prd[3] = {0, 0, 0}, lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  real mass = 1;
+  int nlocal = 0, nghost = 0, nmax = 0;
+  DevArr<real4> x, x_alt;
+  DevArr<real> v, v_alt, f;
+  DevArr<int> type, type_alt, tag, tag_alt;
+  // ---- Neighbor
+  bool neigh_ready = false;
+  real cutneigh = 0, cutneighsq = 0;
+  int halfneigh = 0, ghost_newton = 0, ntypes = 1;
+  BinGeom bg;
+  DevArr<int> bin_count, bin_start, binned, scan_tmp, atom_bin;
+  int maxneighs = 100;       // row stride (multiple of MMD_UNROLL)
+  DevArr<int> neigh, numneigh, wave_max;
+  int neigh_nlocal = 0;      // nlocal the list was built for
+  long long total_neigh = 0;
+  int max_row = 0;
+  DevArr<int> ghost_image;   // per ghost: packed periodic-image code (half lists with ghost newton)
+  // ---- Force
+  int style = 0;             // 0 LJ, 1 EAM
+  bool lj_uniform = true;
+  LJParams lj;
+  DevArr<real> lj_tables;    // [3][ntypes*ntypes]: cutforcesq, sigma6, epsilon
+  std::vector<real> h_cutforcesq;
+  // EAM
+  int nr = 0, nrho = 0, nr_tot = 0, nrho_tot = 0;
+  real rdr = 0, rdrho = 0;
+  bool eam_uniform = true;
+  DevArr<real> rhor_spline, frho_spline, z2r_spline, fp, rho;
+  // ---- Comm
+  int me = 0, nprocs = 1;
+  int procgrid[3] = {1, 1, 1}, myloc[3] = {0, 0, 0}, procneigh[3][2] = {{0, 0}, {0, 0}, {0, 0}}, need[3] = {1, 1, 1};
+  std::vector<Swap> swaps;
+  DevArr<real> buf_send, buf_recv;
+  void* rccl = nullptr;      // ncclComm_t
+  mmd_sendrecv_fn host_sr = nullptr;
+  mmd_allreduce_fn host_ar = nullptr;
+  void* host_ctx = nullptr;
+  std::vector<char> stage_send, stage_recv;
+  DevArr<int> flag_tmp;
+  // ---- Integrate
+  real dt = 0, dtforce = 0;
+  int neigh_every = 20, sort_every = 20;
+  // ---- reductions
+  DevArr<double> partials;   // per-block partial sums
+  double* h_result = nullptr;  // pinned host: [0..7]
+  double* d_result = nullptr;
+  int* h_flags = nullptr;      // pinned host ints
+  int* d_flags = nullptr;
+  // ---- timers (ref/timer.h:35-40) + GPU events around the force kernel
+  double timer[5] = {0, 0, 0, 0, 0};
+  std::vector<EventPair> ev_pool;
+  size_t ev_used = 0;
+  double force_ms = 0;
+  int force_launches = 0;
+  bool time_force_events = true;
+  // ---- options
+  int opt_exact_div = 0;
+  int opt_force_block = MMD_BLOCK;
+};
+
+// ---- shared device/host helpers implemented across the .hip files
+int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve);
+int mmd_set_dummy(mmd_handle* h);
+int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host);   // in-place, returns total
+int mmd_bin_atoms(mmd_handle* h, int count);
+int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir);
+int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir);
+int mmd_zero_forces(mmd_handle* h, int n);
+int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int dest, void* drecv, size_t nrecv, int src);
+int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv, int src);
+int mmd_transport_allreduce(mmd_handle* h, double* vals, int n);
+double mmd_wall();
+
+static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }

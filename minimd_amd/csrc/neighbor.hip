@@ -1,0 +1,433 @@
+// minimd_amd/csrc/neighbor.hip — Neighbor::setup / binatoms / build (ref/neighbor.cpp) as HIP kernels.
+//
+// Design (MI355X-first, not a translation of the reference's per-atom stencil walk):
+//  * bins keep the reference's geometry (binsize = prd/nbin, ghost margins, ref/neighbor.cpp:349-391) but
+//    are numbered block-major: 2x2x2 bins form a block (~57 atoms at LJ liquid density = one wavefront)
+//    and the bins of a block are consecutive, so a counting sort by bin id makes every block a contiguous
+//    slice of `binned[]`, and the blocks of one x-row contiguous too.
+//  * binning = atomic histogram + exclusive scan + atomic fill + in-bin index sort (=> deterministic
+//    order, identical to the reference run single-threaded inside each bin).
+//  * build = one wavefront per block: the candidate atoms of the (2R+1)^3 surrounding blocks are staged
+//    ONCE into LDS (contiguous slices, coalesced loads), then every lane (= one owned atom of the block)
+//    walks the staged candidates with broadcast LDS reads and appends hits to its wave-interleaved row.
+//    Distance test is evaluated exactly like the reference (no FMA contraction: this file is compiled
+//    with -ffp-contract=off; `rsq <= cutneighsq`, ref/neighbor.cpp:165,179), so rows equal the
+//    reference's as sets; the stencil always covers the full cutoff sphere.
+//  * overflow protocol as the reference's (ref/neighbor.cpp:184-208): rows count past maxneighs but store
+//    guarded; the host reads the maximum, grows maxneighs to 1.2*max and relaunches.
+#include "device_utils.hpp"
+#include "mmd_internal.hpp"
+
+#define NB_SMALL 1.0e-6
+
+#if MMD_PRECISION == 1
+#define NB_CAP 3328
+#else
+#define NB_CAP 1664
+#endif
+
+struct __align__(16) Cand {      // one staged candidate: 32 B (DP) / 16+8 -> padded 32 B (SP keeps 24 -> 32)
+  real x, y, z;
+  int idx;
+  int info;                      // 0 skip, 1 keep, 2 compare coordinates (ghost, unshifted), 3 compare index (owned)
+#if MMD_PRECISION == 1
+  int pad0, pad1, pad2;
+#endif
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Neighbor::setup (ref/neighbor.cpp:318-452)
+// ---------------------------------------------------------------------------------------------------
+extern "C" int mmd_neighbor_setup(mmd_handle* h, const int nbin[3], mmd_float cutneigh, int halfneigh, int ghost_newton,
+                                  int ntypes)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  if(nbin[0] < 1 || nbin[1] < 1 || nbin[2] < 1 || !(cutneigh > 0)) { mmd_set_error("mmd_neighbor_setup: bad bins/cutoff"); return -1; }
+  if(!(h->prd[0] > 0)) { mmd_set_error("mmd_neighbor_setup: box not set"); return -1; }
+  BinGeom& g = h->bg;
+  h->cutneigh = cutneigh;
+  h->cutneighsq = cutneigh * cutneigh;
+  h->halfneigh = halfneigh;
+  h->ghost_newton = ghost_newton;
+  h->ntypes = ntypes;
+  for(int d = 0; d < 3; d++) {
+    g.prd[d] = h->prd[d];
+    g.nbin[d] = nbin[d];
+    g.binsize[d] = h->prd[d] / nbin[d];
+    g.bininv[d] = 1.0 / g.binsize[d];
+    real coord = h->lo[d] - cutneigh - NB_SMALL * h->prd[d];
+    int lo = static_cast<int>(coord * g.bininv[d]);
+    if(coord < 0.0) lo -= 1;
+    coord = h->hi[d] + cutneigh + NB_SMALL * h->prd[d];
+    int hi = static_cast<int>(coord * g.bininv[d]);
+    lo -= 1; hi += 1;                      // one extra bin each side, as the reference
+    g.mbinlo[d] = lo;
+    g.mbin[d] = hi - lo + 1;
+    g.nblk[d] = (g.mbin[d] + 1) >> 1;
+    int next = static_cast<int>(cutneigh * g.bininv[d]);
+    if(next * g.binsize[d] < cutneigh) next++;   // full coverage (the reference shaves 0.1% here, :405-415)
+    g.reach[d] = (next + 1) >> 1;
+  }
+  const long long mb = 8LL * g.nblk[0] * g.nblk[1] * g.nblk[2];
+  if(mb > 2000000000LL) { mmd_set_error("mmd_neighbor_setup: too many bins"); return -1; }
+  g.mbins = (int)mb;
+  h->neigh_ready = true;
+  h->neigh_nlocal = 0;
+  if(h->host_only) return 0;
+  MMD_TRY(h->bin_count.ensure((size_t)g.mbins + 2, false, h->stream));
+  MMD_TRY(h->bin_start.ensure((size_t)g.mbins + 2, false, h->stream));
+  h->neigh_ready = true;
+  h->neigh_nlocal = 0;
+  return 0;
+}
+
+// coord -> (ix,iy,iz) exactly as Neighbor::coord2bin (ref/neighbor.cpp:274-297), then block-major id
+__device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
+{
+  int ix, iy, iz;
+  if(x >= g.prd[0]) ix = (int)((x - g.prd[0]) * g.bininv[0]) + g.nbin[0] - g.mbinlo[0];
+  else if(x >= (real)0.0) ix = (int)(x * g.bininv[0]) - g.mbinlo[0];
+  else ix = (int)(x * g.bininv[0]) - g.mbinlo[0] - 1;
+  if(y >= g.prd[1]) iy = (int)((y - g.prd[1]) * g.bininv[1]) + g.nbin[1] - g.mbinlo[1];
+  else if(y >= (real)0.0) iy = (int)(y * g.bininv[1]) - g.mbinlo[1];
+  else iy = (int)(y * g.bininv[1]) - g.mbinlo[1] - 1;
+  if(z >= g.prd[2]) iz = (int)((z - g.prd[2]) * g.bininv[2]) + g.nbin[2] - g.mbinlo[2];
+  else if(z >= (real)0.0) iz = (int)(z * g.bininv[2]) - g.mbinlo[2];
+  else iz = (int)(z * g.bininv[2]) - g.mbinlo[2] - 1;
+  ix = min(max(ix, 0), g.mbin[0] - 1);
+  iy = min(max(iy, 0), g.mbin[1] - 1);
+  iz = min(max(iz, 0), g.mbin[2] - 1);
+  const int blk = ((iz >> 1) * g.nblk[1] + (iy >> 1)) * g.nblk[0] + (ix >> 1);
+  return blk * 8 + ((iz & 1) << 2 | (iy & 1) << 1 | (ix & 1));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Neighbor::binatoms (ref/neighbor.cpp:215-268): histogram, scan, fill, in-bin sort
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_bin_count(const real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ bin_count)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) return;
+  const real4 p = x[i];
+  const int b = bin_of(g, p.x, p.y, p.z);
+  atom_bin[i] = b;
+  atomicAdd(&bin_count[b], 1);
+}
+
+__global__ void k_bin_fill(const int* __restrict__ atom_bin, int n, const int* __restrict__ bin_start, int* __restrict__ cursor,
+                           int* __restrict__ binned)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) return;
+  const int b = atom_bin[i];
+  const int slot = atomicAdd(&cursor[b], 1);
+  binned[bin_start[b] + slot] = i;
+}
+
+// one thread per bin: insertion sort of its (short) slice -> ascending atom index, run-to-run identical
+__global__ void k_bin_sort(const int* __restrict__ bin_start, int mbins, int* __restrict__ binned)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= mbins) return;
+  const int s = bin_start[b], e = bin_start[b + 1];
+  for(int a = s + 1; a < e; a++) {
+    const int key = binned[a];
+    int c = a - 1;
+    while(c >= s && binned[c] > key) { binned[c + 1] = binned[c]; c--; }
+    binned[c + 1] = key;
+  }
+}
+
+int mmd_bin_atoms(mmd_handle* h, int count)
+{
+  const int n = count < 0 ? h->nlocal + h->nghost : count;
+  const BinGeom& g = h->bg;
+  MMD_TRY(h->atom_bin.ensure((size_t)n + 1, false, h->stream));
+  MMD_TRY(h->binned.ensure((size_t)n + 1, false, h->stream));
+  HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
+  if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->bin_count.p);
+  HIP_TRY(hipMemcpyAsync(h->bin_start.p, h->bin_count.p, ((size_t)g.mbins + 1) * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  MMD_TRY(mmd_exclusive_scan(h, h->bin_start.p, g.mbins, nullptr));
+  HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));   // reused as fill cursor
+  if(n) hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->atom_bin.p, n, h->bin_start.p, h->bin_count.p, h->binned.p);
+  hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Neighbor::build (ref/neighbor.cpp:79-213)
+// ---------------------------------------------------------------------------------------------------
+// MODE 0: full list (every j != i).  MODE 1: half, no ghost newton (keep j > i; ghosts always, ref :171).
+// MODE 2: half with ghost newton: every pair stored once globally — owned j: j > i; ghost j that is a
+//         periodic image: by the sign of its image vector (the mirrored pair carries the opposite one);
+//         unshifted ghost (other rank's atom): (z,y,x) lexicographic order as ref/neighbor.cpp:155-157.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_build(const real4* __restrict__ x, const int* __restrict__ binned,
+                                              const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
+                                              BinGeom g, int nlocal, real cutneighsq, int maxneighs,
+                                              int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags)
+{
+  __shared__ Cand cand[NB_CAP];
+  __shared__ int rng_start[128], rng_pref[129];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
+  if(a0 == a1) return;                                      // empty block (uniform exit)
+  const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
+
+  // candidate slices: for every (dz,dy) one contiguous run of blocks [bx-R, bx+R] (clamped to the grid)
+  int nr = 0;
+  if(lane == 0) {
+    int pref = 0;
+    const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
+    for(int dz = -g.reach[2]; dz <= g.reach[2]; dz++) {
+      const int z = bz + dz;
+      if(z < 0 || z >= g.nblk[2]) continue;
+      for(int dy = -g.reach[1]; dy <= g.reach[1]; dy++) {
+        const int y = by + dy;
+        if(y < 0 || y >= g.nblk[1]) continue;
+        const int row = (z * g.nblk[1] + y) * g.nblk[0];
+        const int s = bin_start[(row + x0) * 8], e = bin_start[(row + x1) * 8 + 8];
+        if(e > s && nr < 128) { rng_start[nr] = s; rng_pref[nr] = pref; pref += e - s; nr++; }
+      }
+    }
+    rng_pref[nr] = pref;
+    rng_pref[128] = nr;                                     // publish the slice count through LDS
+  }
+  __syncthreads();
+  nr = rng_pref[128];
+  const int total = rng_pref[nr];
+
+  // the owned atoms of this block, in chunks of 64 (usually one chunk)
+  for(int c0 = a0; c0 < a1; c0 += 64) {
+    const int me_pos = c0 + lane;
+    int i = me_pos < a1 ? binned[me_pos] : -1;
+    if(i >= nlocal) i = -1;                                 // ghosts get no row
+    const unsigned long long any = __ballot(i >= 0);
+    if(any == 0ULL) continue;
+    real4 xi = x[i >= 0 ? i : 0];
+    int n = 0;
+    const size_t rowbase = i >= 0 ? ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63) : 0;
+
+    for(int t0 = 0; t0 < total; t0 += NB_CAP) {
+      const int tn = min(NB_CAP, total - t0);
+      __syncthreads();
+      // ---- stage candidates t0 .. t0+tn into LDS (independent iterations: loads overlap)
+      for(int t = lane; t < tn; t += 64) {
+        const int gt = t0 + t;
+        int r = 0;
+        while(r + 1 < nr && rng_pref[r + 1] <= gt) r++;
+        const int j = binned[rng_start[r] + (gt - rng_pref[r])];
+        const real4 p = x[j];
+        Cand cd;
+        cd.x = p.x; cd.y = p.y; cd.z = p.z; cd.idx = j;
+        if(MODE == 0) cd.info = 1;
+        else if(MODE == 1) cd.info = j >= nlocal ? 1 : 3;
+        else {
+          if(j < nlocal) cd.info = 3;
+          else {
+            const int code = ghost_image[j - nlocal];        // (sx+2) + 5*(sy+2) + 25*(sz+2), 62 = unshifted
+            const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
+            if(sx == 0 && sy == 0 && sz == 0) cd.info = 2;
+            else cd.info = (sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0)))) ? 1 : 0;
+          }
+        }
+        cand[t] = cd;
+      }
+      __syncthreads();
+      // ---- every lane tests every staged candidate (LDS broadcast reads)
+      if(i >= 0) {
+#pragma unroll 4
+        for(int t = 0; t < tn; t++) {
+          const Cand cd = cand[t];
+          const real dx = xi.x - cd.x, dy = xi.y - cd.y, dz = xi.z - cd.z;
+          const real rsq = dx * dx + dy * dy + dz * dz;
+          bool keep = rsq <= cutneighsq && cd.idx != i;
+          if(MODE != 0) {
+            bool ok = cd.info == 1;
+            if(cd.info == 3) ok = cd.idx > i;
+            if(MODE == 2 && cd.info == 2)
+              ok = !(cd.z < xi.z || (cd.z == xi.z && cd.y < xi.y) || (cd.z == xi.z && cd.y == xi.y && cd.x < xi.x));
+            keep = keep && ok;
+          }
+          if(keep) {
+            if(n < maxneighs) neigh[rowbase + (size_t)n * 64] = cd.idx;
+            n++;
+          }
+        }
+      }
+    }
+    if(i >= 0) numneigh[i] = n;
+    const int wmax = wave_max_i(i >= 0 ? n : 0);
+    if(lane == 0) atomicMax(&flags[0], wmax);
+  }
+}
+
+// pad every row with the dummy atom up to its wavefront's longest row (rounded up to the unroll factor)
+// so the force kernels run a wave-uniform, branch-free neighbor loop.
+__global__ __launch_bounds__(256) void k_pad_rows(int nlocal, int nwaves, int maxneighs, int dummy,
+                                                  int* __restrict__ neigh, const int* __restrict__ numneigh,
+                                                  int* __restrict__ wave_max, unsigned long long* __restrict__ total)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = i >> 6;
+  if(w >= nwaves) return;
+  const int n = i < nlocal ? numneigh[i] : 0;
+  int m = wave_max_i(n);
+  m = (m + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
+  if(m > maxneighs) m = maxneighs;
+  const size_t rowbase = ((size_t)w * maxneighs) * 64 + (i & 63);
+  for(int k = n; k < m; k++) neigh[rowbase + (size_t)k * 64] = dummy;
+  if((i & 63) == 0) wave_max[w] = m;
+  const long long s = wave_sum((long long)n);
+  if((i & 63) == 0 && s) atomicAdd(total, (unsigned long long)s);
+}
+
+extern "C" int mmd_neighbor_build(mmd_handle* h)
+{
+  if(!h || !h->neigh_ready) { mmd_set_error("mmd_neighbor_build: call mmd_neighbor_setup first"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  const int nlocal = h->nlocal, nall = h->nlocal + h->nghost;
+  const int nwaves = div_up(nlocal, 64);
+  const BinGeom& g = h->bg;
+  if(h->halfneigh && h->ghost_newton && h->ghost_image.cap < (size_t)h->nghost + 1) {
+    mmd_set_error("mmd_neighbor_build: half lists with ghost newton need ghosts created by mmd_comm_borders");
+    return -1;
+  }
+  MMD_TRY(mmd_bin_atoms(h, -1));
+  MMD_TRY(h->numneigh.ensure((size_t)nlocal + 64, false, h->stream));
+  MMD_TRY(h->wave_max.ensure((size_t)nwaves + 1, false, h->stream));
+  const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
+  for(int attempt = 0; attempt < 8; attempt++) {
+    MMD_TRY(h->neigh.ensure((size_t)nwaves * h->maxneighs * 64 + 64, false, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
+    const int mode = !h->halfneigh ? 0 : (h->ghost_newton ? 2 : 1);
+#define LAUNCH_BUILD(M)                                                                                              \
+  hipLaunchKernelGGL(k_build<M>, dim3(nblocks), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,        \
+                     h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags)
+    if(nlocal) {
+      if(mode == 0) LAUNCH_BUILD(0);
+      else if(mode == 1) LAUNCH_BUILD(1);
+      else LAUNCH_BUILD(2);
+    }
+#undef LAUNCH_BUILD
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int maxn = h->h_flags[0];
+    h->max_row = maxn;
+    if(maxn >= h->maxneighs) {                      // ref/neighbor.cpp:186-208
+      int m = (int)(maxn * 1.2);
+      m = (m + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
+      h->maxneighs = m;
+      continue;
+    }
+    // pad + statistics
+    HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
+    if(nwaves)
+      hipLaunchKernelGGL(k_pad_rows, dim3(div_up(nwaves * 64, 256)), dim3(256), 0, h->stream, nlocal, nwaves, h->maxneighs, nall,
+                         h->neigh.p, h->numneigh.p, h->wave_max.p, (unsigned long long*)h->d_result);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    unsigned long long tot;
+    memcpy(&tot, h->h_result, sizeof(tot));
+    h->total_neigh = (long long)tot;
+    h->neigh_nlocal = nlocal;
+    return 0;
+  }
+  mmd_set_error("mmd_neighbor_build: neighbor rows keep overflowing (maxneighs=%d)", h->maxneighs);
+  return -1;
+}
+
+extern "C" int mmd_neighbor_geometry(mmd_handle* h, int mbin[3], int mbinlo[3], int nblk[3], int reach[3])
+{
+  if(!h || !h->neigh_ready) { mmd_set_error("mmd_neighbor_geometry: call mmd_neighbor_setup first"); return -1; }
+  for(int d = 0; d < 3; d++) {
+    if(mbin) mbin[d] = h->bg.mbin[d];
+    if(mbinlo) mbinlo[d] = h->bg.mbinlo[d];
+    if(nblk) nblk[d] = h->bg.nblk[d];
+    if(reach) reach[d] = h->bg.reach[d];
+  }
+  return 0;
+}
+
+extern "C" int mmd_neighbor_info(mmd_handle* h, int* maxneighs, int* mbins, long long* total_neigh, int* max_row)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  if(maxneighs) *maxneighs = h->maxneighs;
+  if(mbins) *mbins = h->bg.mbins;
+  if(total_neigh) *total_neigh = h->total_neigh;
+  if(max_row) *max_row = h->max_row;
+  return 0;
+}
+
+// ---- layout conversion to/from the reference's row-major rows (ref/neighbor.cpp:128) ----------------
+__global__ void k_rows_to_ref(const int* __restrict__ neigh, const int* __restrict__ numneigh, int nlocal, int stride_dev,
+                              int* __restrict__ out, int stride_ref)
+{
+  const int i = blockIdx.x;
+  if(i >= nlocal) return;
+  const int n = min(numneigh[i], stride_ref);
+  const size_t rowbase = ((size_t)(i >> 6) * stride_dev) * 64 + (i & 63);
+  for(int k = threadIdx.x; k < n; k += blockDim.x) out[(size_t)i * stride_ref + k] = neigh[rowbase + (size_t)k * 64];
+}
+__global__ void k_rows_from_ref(const int* __restrict__ in, const int* __restrict__ numneigh, int nlocal, int stride_ref,
+                                int* __restrict__ neigh, int stride_dev)
+{
+  const int i = blockIdx.x;
+  if(i >= nlocal) return;
+  const int n = numneigh[i];
+  const size_t rowbase = ((size_t)(i >> 6) * stride_dev) * 64 + (i & 63);
+  for(int k = threadIdx.x; k < n; k += blockDim.x) neigh[rowbase + (size_t)k * 64] = in[(size_t)i * stride_ref + k];
+}
+
+extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneighs, int* numneigh)
+{
+  if(!h || h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_neighbor_download: no neighbor list for the current atoms"); return -1; }
+  const int n = h->nlocal;
+  if(numneigh) HIP_TRY(hipMemcpyAsync(numneigh, h->numneigh.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if(neighbors && n) {
+    DevArr<int> tmp;
+    MMD_TRY(tmp.ensure((size_t)n * maxneighs, false, h->stream));
+    hipLaunchKernelGGL(k_rows_to_ref, dim3(n), dim3(64), 0, h->stream, h->neigh.p, h->numneigh.p, n, h->maxneighs, tmp.p, maxneighs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(neighbors, tmp.p, (size_t)n * maxneighs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    tmp.release();
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int mmd_neighbor_upload(mmd_handle* h, const int* neighbors, int maxneighs, const int* numneigh, int nlocal)
+{
+  if(!h || !neighbors || !numneigh || nlocal != h->nlocal) { mmd_set_error("mmd_neighbor_upload: bad arguments (nlocal mismatch?)"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  const int nwaves = div_up(nlocal, 64);
+  int maxn = 0;
+  for(int i = 0; i < nlocal; i++) maxn = numneigh[i] > maxn ? numneigh[i] : maxn;
+  if(maxn > maxneighs) { mmd_set_error("mmd_neighbor_upload: a row is longer than the stride"); return -1; }
+  int m = (maxn + MMD_UNROLL) / MMD_UNROLL * MMD_UNROLL;
+  if(m > h->maxneighs) h->maxneighs = m;
+  MMD_TRY(h->numneigh.ensure((size_t)nlocal + 64, false, h->stream));
+  MMD_TRY(h->wave_max.ensure((size_t)nwaves + 1, false, h->stream));
+  MMD_TRY(h->neigh.ensure((size_t)nwaves * h->maxneighs * 64 + 64, false, h->stream));
+  DevArr<int> tmp;
+  MMD_TRY(tmp.ensure((size_t)nlocal * maxneighs + 1, false, h->stream));
+  HIP_TRY(hipMemcpyAsync(tmp.p, neighbors, (size_t)nlocal * maxneighs * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->numneigh.p, numneigh, (size_t)nlocal * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if(nlocal) {
+    hipLaunchKernelGGL(k_rows_from_ref, dim3(nlocal), dim3(64), 0, h->stream, tmp.p, h->numneigh.p, nlocal, maxneighs, h->neigh.p, h->maxneighs);
+    HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
+    hipLaunchKernelGGL(k_pad_rows, dim3(div_up(nwaves * 64, 256)), dim3(256), 0, h->stream, nlocal, nwaves, h->maxneighs,
+                       h->nlocal + h->nghost, h->neigh.p, h->numneigh.p, h->wave_max.p, (unsigned long long*)h->d_result);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  tmp.release();
+  h->neigh_nlocal = nlocal;
+  h->max_row = maxn;
+  return 0;
+}

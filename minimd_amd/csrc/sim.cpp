@@ -1,0 +1,407 @@
+// minimd_amd/csrc/sim.cpp — whole-program twin of ref/ljs.cpp main(): same command line, same input deck,
+// same stdout grammar (banner, "# Timestep T U P Time" rows, PERF_SUMMARY), driving the device handle
+// through the C-ABI of include/mmd.h. One process per GPU; ranks come from RANK/WORLD_SIZE/LOCAL_RANK.
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mmd_internal.hpp"
+
+struct ThermoScales {      // Thermo::setup (ref/thermo.cpp:42-72)
+  mmd_float t_scale, e_scale, p_scale, mvv2e, dof_boltz;
+};
+
+struct mmd_sim {
+  mmd_handle* h = nullptr;
+  mmd_input in;
+  std::string input_file = "in.lj.miniMD";
+  int me = 0, nprocs = 1, quiet = 0;
+  int num_threads = 1, ntypes = 4, halfneigh = 1, ghost_newton = 1, sort = -1, yaml_output = 0;
+  int nbin[3] = {1, 1, 1};
+  int natoms = 0;
+  int sort_every = 0;
+  mmd_float prd[3], mass = 1, dt = 0, dtforce = 0;
+  ThermoScales th;
+  int steps_done = 0;        // steps integrated so far (bench slices)
+  double t_run_start = 0;
+  // thermo history
+  std::vector<int> row_step;
+  std::vector<double> row_t, row_u, row_p;
+  double last_timers[5] = {0, 0, 0, 0, 0};
+};
+
+static bool g_have_id = false;
+static unsigned char g_id[128];
+
+extern "C" int mmd_sim_set_unique_id(const unsigned char id[128])
+{
+  memcpy(g_id, id, 128);
+  g_have_id = true;
+  return 0;
+}
+
+// minimal rendezvous for the stand-alone executable: rank 0 serves the 128-byte RCCL id on
+// MASTER_ADDR:(MASTER_PORT+17) to the other ranks (torchrun exports both variables)
+static int exchange_id_tcp(int rank, int nranks, unsigned char id[128])
+{
+  const char* addr = getenv("MASTER_ADDR");
+  const char* port_s = getenv("MASTER_PORT");
+  if(!addr) addr = "127.0.0.1";
+  const int port = (port_s ? atoi(port_s) : 29500) + 17;
+  if(rank == 0) {
+    MMD_TRY(mmd_comm_unique_id(id));
+    int ls = socket(AF_INET, SOCK_STREAM, 0);
+    int one = 1;
+    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons(port);
+    if(bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || listen(ls, nranks) != 0) { mmd_set_error("rendezvous: cannot listen on port %d", port); close(ls); return -1; }
+    for(int k = 1; k < nranks; k++) {
+      int cs = accept(ls, nullptr, nullptr);
+      if(cs < 0 || write(cs, id, 128) != 128) { mmd_set_error("rendezvous: send failed"); close(ls); return -1; }
+      close(cs);
+    }
+    close(ls);
+    return 0;
+  }
+  for(int attempt = 0; attempt < 600; attempt++) {
+    int s = socket(AF_INET, SOCK_STREAM, 0);
+    sockaddr_in sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sin_family = AF_INET; sa.sin_port = htons(port);
+    hostent* he = gethostbyname(addr);
+    if(he) memcpy(&sa.sin_addr, he->h_addr_list[0], he->h_length); else inet_pton(AF_INET, addr, &sa.sin_addr);
+    if(connect(s, (sockaddr*)&sa, sizeof(sa)) == 0) {
+      size_t got = 0;
+      while(got < 128) { ssize_t r = read(s, id + got, 128 - got); if(r <= 0) break; got += r; }
+      close(s);
+      if(got == 128) return 0;
+    } else close(s);
+    usleep(100000);
+  }
+  mmd_set_error("rendezvous: rank %d could not reach %s:%d", rank, addr, port);
+  return -1;
+}
+
+static bool is_flag(const char* a, const char* s1, const char* s2 = nullptr) { return !strcmp(a, s1) || (s2 && !strcmp(a, s2)); }
+
+static void print_help()
+{
+  printf("\n%s\n\n", mmd_variant_string());
+  printf("miniMD-HIP: the per-timestep path of Mantevo miniMD (LJ/EAM forces over neighbor lists, binned neighbor\n"
+         "build, velocity-Verlet) as native MI355X HIP kernels. Same options and input deck as miniMD-Reference:\n\n");
+  printf("  -i / --input_file <file>   input deck (default in.lj.miniMD)\n  -n / --nsteps <int>        number of timesteps\n"
+         "  -s / --size <int>          unit cells per dimension;  -nx/-ny/-nz <int> per dimension\n"
+         "  --ntypes <int>             number of atom types (default 4)\n  -b / --neigh_bins <int>    bins per dimension\n"
+         "  --half_neigh <int>         1 half neighbor lists (default), 0 full lists\n"
+         "  -gn / --ghost_newton <int> Newton's third law across ghosts (half lists; default 1, EAM forces 0)\n"
+         "  --sort <n>                 re-sort atoms every n steps (default: every re-neighboring, 0 never)\n"
+         "  -u / --units <lj|metal>    -p / --force <lj|eam>    -t / --num_threads <int> (accepted, unused)\n"
+         "  -o / --yaml_output <int>   --yaml_screen   -f / --data_file <file>   -h / --help\n\n");
+}
+
+static void thermo_setup(mmd_sim* s)
+{
+  ThermoScales& t = s->th;
+  if(s->in.units == 0) {
+    t.mvv2e = 1.0;
+    t.dof_boltz = (s->natoms * 3 - 3);
+    t.t_scale = t.mvv2e / t.dof_boltz;
+    t.p_scale = 1.0 / 3 / s->prd[0] / s->prd[1] / s->prd[2];
+    t.e_scale = 0.5;
+  } else {
+    t.mvv2e = 1.036427e-04;
+    t.dof_boltz = (s->natoms * 3 - 3) * 8.617343e-05;
+    t.t_scale = t.mvv2e / t.dof_boltz;
+    t.p_scale = 1.602176e+06 / 3 / s->prd[0] / s->prd[1] / s->prd[2];
+    t.e_scale = 524287.985533;
+    s->dtforce /= t.mvv2e;                        // ref/thermo.cpp:69
+  }
+}
+
+// Thermo::compute row (ref/thermo.cpp:74-194) from globally reduced raw sums
+static void thermo_row(void* ctx, int step, double sum_mv2, double eng_vdwl, double virial)
+{
+  mmd_sim* s = (mmd_sim*)ctx;
+  const ThermoScales& th = s->th;
+  const mmd_float t = (mmd_float)sum_mv2 * th.t_scale;
+  mmd_float e_act = (mmd_float)eng_vdwl;
+  if(s->halfneigh) e_act *= 2.0;
+  e_act *= th.e_scale;
+  const mmd_float eng = e_act / s->natoms;
+  const mmd_float p = (t * th.dof_boltz + (mmd_float)virial) * th.p_scale;
+  s->row_step.push_back(step); s->row_t.push_back(t); s->row_u.push_back(eng); s->row_p.push_back(p);
+  if(s->me == 0 && !s->quiet) {
+    fprintf(stdout, "%i %e %e %e %6.3lf\n", step, (double)t, (double)eng, (double)p, step == 0 ? 0.0 : mmd_wall() - s->t_run_start);
+    fflush(stdout);
+  }
+}
+
+extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
+{
+  if(!out) { mmd_set_error("mmd_sim_create: out is NULL"); return -1; }
+  *out = nullptr;
+  mmd_sim* s = new mmd_sim();
+  s->quiet = quiet;
+  const char* e;
+  if((e = getenv("RANK"))) s->me = atoi(e);
+  if((e = getenv("WORLD_SIZE"))) s->nprocs = atoi(e);
+  if(s->nprocs < 1) s->nprocs = 1;
+  for(int i = 0; i < argc; i++)
+    if(is_flag(argv[i], "-i", "--input_file") && i + 1 < argc) s->input_file = argv[++i];
+  if(mmd_input_read(&s->in, s->input_file.c_str())) {
+    if(s->me == 0 && !quiet) printf("%s\n", mmd_last_error());
+    delete s;
+    return -1;
+  }
+  int num_steps = -1, system_size = -1, nx = -1, ny = -1, nz = -1, neighbor_size = -1;
+  for(int i = 0; i < argc; i++) {
+    const char* a = argv[i];
+    const bool has = i + 1 < argc;
+    if(is_flag(a, "-t", "--num_threads") && has) s->num_threads = atoi(argv[++i]);
+    else if(is_flag(a, "--teams") && has) ++i;
+    else if(is_flag(a, "-n", "--nsteps") && has) num_steps = atoi(argv[++i]);
+    else if(is_flag(a, "-s", "--size") && has) system_size = atoi(argv[++i]);
+    else if(is_flag(a, "-nx") && has) nx = atoi(argv[++i]);
+    else if(is_flag(a, "-ny") && has) ny = atoi(argv[++i]);
+    else if(is_flag(a, "-nz") && has) nz = atoi(argv[++i]);
+    else if(is_flag(a, "--ntypes") && has) s->ntypes = atoi(argv[++i]);
+    else if(is_flag(a, "-b", "--neigh_bins") && has) neighbor_size = atoi(argv[++i]);
+    else if(is_flag(a, "--half_neigh") && has) s->halfneigh = atoi(argv[++i]);
+    else if(is_flag(a, "-sse") && has) ++i;
+    else if(is_flag(a, "--sort") && has) s->sort = atoi(argv[++i]);
+    else if(is_flag(a, "-o", "--yaml_output") && has) s->yaml_output = atoi(argv[++i]);
+    else if(is_flag(a, "-f", "--data_file") && has) { s->in.has_datafile = 1; strncpy(s->in.datafile, argv[++i], sizeof(s->in.datafile) - 1); }
+    else if(is_flag(a, "-u", "--units") && has) s->in.units = strcmp(argv[++i], "metal") == 0 ? 1 : 0;
+    else if(is_flag(a, "-p", "--force") && has) s->in.forcetype = strcmp(argv[++i], "eam") == 0 ? 1 : 0;
+    else if(is_flag(a, "-gn", "--ghost_newton") && has) s->ghost_newton = atoi(argv[++i]);
+    else if(is_flag(a, "-h", "--help")) { if(s->me == 0) print_help(); delete s; return 1; }
+    // unknown flags are ignored, like the reference (run_one_test passes -dm)
+  }
+  if(s->in.has_datafile) { mmd_set_error("LAMMPS data files (-f) are not supported yet"); if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
+  if(s->halfneigh < 0) { mmd_set_error("--half_neigh -1 (original miniMD force) is not available in the HIP variant"); if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
+  if(s->in.forcetype == 1 && s->ghost_newton == 1) {
+    if(s->me == 0 && !quiet) printf("# EAM currently requires '--ghost_newton 0'; Changing setting now.\n");
+    s->ghost_newton = 0;
+  }
+  if(num_steps > 0) s->in.ntimes = num_steps;
+  if(system_size > 0) s->in.nx = s->in.ny = s->in.nz = system_size;
+  if(nx > 0) {
+    s->in.nx = nx;
+    if(ny > 0) s->in.ny = ny; else if(system_size < 0) s->in.ny = nx;
+    if(nz > 0) s->in.nz = nz; else if(system_size < 0) s->in.nz = nx;
+  }
+  if(neighbor_size > 0) s->nbin[0] = s->nbin[1] = s->nbin[2] = neighbor_size;
+  else {
+    const mmd_float neighscale = 5.0 / 6.0;       // evaluated in MMD_float (ref/ljs.cpp:357-362)
+    s->nbin[0] = neighscale * s->in.nx; s->nbin[1] = neighscale * s->in.ny; s->nbin[2] = neighscale * s->in.nz;
+  }
+  for(int d = 0; d < 3; d++) if(s->nbin[d] == 0) s->nbin[d] = 1;
+  s->sort_every = s->sort > 0 ? s->sort : (s->sort < 0 ? s->in.neigh_every : 0);
+  s->dt = s->in.dt;
+
+  if(s->me == 0 && !quiet) printf("# Create System:\n");
+  if(mmd_create(-1, &s->h)) { if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
+  mmd_handle* h = s->h;
+#define SIM_TRY(expr) do { if((expr) < 0) { if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); mmd_sim_destroy(s); return -1; } } while(0)
+  mmd_create_box(s->in.nx, s->in.ny, s->in.nz, s->in.rho, s->prd);
+  { const mmd_float zero[3] = {0, 0, 0}; SIM_TRY(mmd_atom_set_box(h, s->prd, zero, s->prd)); }
+  SIM_TRY(mmd_comm_setup(h, s->in.neigh_cut, s->me, s->nprocs));
+  if(s->nprocs > 1) {
+    unsigned char id[128];
+    if(g_have_id) memcpy(id, g_id, 128); else SIM_TRY(exchange_id_tcp(s->me, s->nprocs, id));
+    SIM_TRY(mmd_comm_init_rccl(h, id, s->me, s->nprocs));
+  }
+  SIM_TRY(mmd_neighbor_setup(h, s->nbin, s->in.neigh_cut, s->halfneigh, s->ghost_newton, s->ntypes));
+  s->dtforce = 0.5 * s->dt;                        // Integrate::setup (ref/integrate.cpp:41-44)
+  const int nt2 = s->ntypes * s->ntypes;
+  if(s->in.forcetype == 0) {
+    std::vector<mmd_float> cut(nt2), s6(nt2), eps(nt2);
+    for(int i = 0; i < nt2; i++) {                 // ref/ljs.cpp:299-305, ref/force_lj.cpp:65-69
+      const mmd_float sg = s->in.sigma;
+      eps[i] = s->in.epsilon; s6[i] = sg * sg * sg * sg * sg * sg; cut[i] = s->in.force_cut * s->in.force_cut;
+    }
+    SIM_TRY(mmd_force_lj_setup(h, s->ntypes, cut.data(), s6.data(), eps.data()));
+  } else {
+    int nr, nrho, nr_tot, nrho_tot;
+    mmd_float rdr, rdrho, cutmax, mass;
+    SIM_TRY(mmd_eam_tables_from_file("Cu_u6.eam", s->ntypes, &nr, &nrho, &nr_tot, &nrho_tot, &rdr, &rdrho, &cutmax, &mass, nullptr, nullptr, nullptr));
+    std::vector<mmd_float> rhor((size_t)nt2 * nr_tot), frho((size_t)nt2 * nrho_tot), z2r((size_t)nt2 * nr_tot), cut(nt2, cutmax * cutmax);
+    SIM_TRY(mmd_eam_tables_from_file("Cu_u6.eam", s->ntypes, &nr, &nrho, &nr_tot, &nrho_tot, &rdr, &rdrho, &cutmax, &mass, rhor.data(), frho.data(), z2r.data()));
+    SIM_TRY(mmd_force_eam_setup(h, s->ntypes, nr, nrho, nr_tot, nrho_tot, rdr, rdrho, rhor.data(), frho.data(), z2r.data(), cut.data()));
+    s->mass = mass;                                // ref/ljs.cpp:403
+    s->in.force_cut = cutmax;
+  }
+  SIM_TRY(mmd_atom_set_mass(h, s->mass));
+  // create_atoms (ref/setup.cpp:315-450) for my sub-box
+  int nlocal = 0;
+  SIM_TRY(mmd_create_atoms(s->in.nx, s->in.ny, s->in.nz, s->in.rho, h->lo, h->hi, s->ntypes, nullptr, nullptr, nullptr, nullptr, &nlocal));
+  std::vector<mmd_float> x((size_t)3 * nlocal + 3), v((size_t)3 * nlocal + 3);
+  std::vector<int> type(nlocal + 1), tag(nlocal + 1);
+  SIM_TRY(mmd_create_atoms(s->in.nx, s->in.ny, s->in.nz, s->in.rho, h->lo, h->hi, s->ntypes, x.data(), v.data(), type.data(), tag.data(), &nlocal));
+  s->natoms = 4 * s->in.nx * s->in.ny * s->in.nz;
+  { double cnt = nlocal; SIM_TRY(mmd_transport_allreduce(h, &cnt, 1));
+    if((long long)cnt != s->natoms) { mmd_set_error("Created incorrect # of atoms"); if(s->me == 0 && !quiet) printf("%s\n", mmd_last_error()); mmd_sim_destroy(s); return -1; } }
+  thermo_setup(s);
+  // create_velocity (ref/setup.cpp:454-494): remove centre-of-mass motion, rescale to t_request
+  {
+    double vtot[3] = {0, 0, 0};
+    for(int i = 0; i < nlocal; i++) for(int d = 0; d < 3; d++) vtot[d] += v[3 * (size_t)i + d];
+    SIM_TRY(mmd_transport_allreduce(h, vtot, 3));
+    for(int d = 0; d < 3; d++) vtot[d] /= s->natoms;
+    for(int i = 0; i < nlocal; i++) for(int d = 0; d < 3; d++) v[3 * (size_t)i + d] -= vtot[d];
+    mmd_float t_act = 0;
+    for(int i = 0; i < nlocal; i++) {
+      const mmd_float vx = v[3 * (size_t)i], vy = v[3 * (size_t)i + 1], vz = v[3 * (size_t)i + 2];
+      t_act += (vx * vx + vy * vy + vz * vz) * s->mass;
+    }
+    double tsum = t_act;
+    SIM_TRY(mmd_transport_allreduce(h, &tsum, 1));
+    const double t = (mmd_float)tsum * s->th.t_scale;
+    const double factor = sqrt(s->in.t_request / t);
+    for(size_t i = 0; i < (size_t)3 * nlocal; i++) v[i] *= factor;
+  }
+  SIM_TRY(mmd_atom_upload(h, x.data(), v.data(), type.data(), tag.data(), nlocal, 0));
+  // dtforce chain: 0.5*dt [/mvv2e] /mass (ref/integrate.cpp:43,80-81; ref/thermo.cpp:69)
+  SIM_TRY(mmd_integrate_setup(h, s->dt, s->dtforce / s->mass, s->in.neigh_every, s->sort_every));
+#undef SIM_TRY
+  if(s->me == 0 && !quiet) {
+    printf("# Done .... \n");
+    fprintf(stdout, "# %s output ...\n", mmd_variant_string());
+    fprintf(stdout, "# Run Settings: \n");
+    fprintf(stdout, "\t# MPI processes: %i\n", s->nprocs);
+    fprintf(stdout, "\t# OpenMP threads: %i\n", s->num_threads);
+    fprintf(stdout, "\t# Inputfile: %s\n", s->input_file.c_str());
+    fprintf(stdout, "\t# Datafile: %s\n", "None");
+    fprintf(stdout, "# Physics Settings: \n");
+    fprintf(stdout, "\t# ForceStyle: %s\n", s->in.forcetype == 0 ? "LJ" : "EAM");
+    fprintf(stdout, "\t# Force Parameters: %2.2lf %2.2lf\n", (double)s->in.epsilon, (double)s->in.sigma);
+    fprintf(stdout, "\t# Units: %s\n", s->in.units == 0 ? "LJ" : "METAL");
+    fprintf(stdout, "\t# Atoms: %i\n", s->natoms);
+    fprintf(stdout, "\t# Atom types: %i\n", s->ntypes);
+    fprintf(stdout, "\t# System size: %2.2lf %2.2lf %2.2lf (unit cells: %i %i %i)\n", (double)s->prd[0], (double)s->prd[1], (double)s->prd[2], s->in.nx, s->in.ny, s->in.nz);
+    fprintf(stdout, "\t# Density: %lf\n", (double)s->in.rho);
+    fprintf(stdout, "\t# Force cutoff: %lf\n", (double)s->in.force_cut);
+    fprintf(stdout, "\t# Timestep size: %lf\n", (double)s->dt);
+    fprintf(stdout, "# Technical Settings: \n");
+    fprintf(stdout, "\t# Neigh cutoff: %lf\n", (double)s->in.neigh_cut);
+    fprintf(stdout, "\t# Half neighborlists: %i\n", s->halfneigh);
+    fprintf(stdout, "\t# Neighbor bins: %i %i %i\n", s->nbin[0], s->nbin[1], s->nbin[2]);
+    fprintf(stdout, "\t# Neighbor frequency: %i\n", s->in.neigh_every);
+    fprintf(stdout, "\t# Sorting frequency: %i\n", s->sort_every);
+    fprintf(stdout, "\t# Thermo frequency: %i\n", s->in.thermo_nstat);
+    fprintf(stdout, "\t# Ghost Newton: %i\n", s->ghost_newton);
+    fprintf(stdout, "\t# Use intrinsics: %i\n", 0);
+    fprintf(stdout, "\t# Do safe exchange: %i\n", 0);
+    fprintf(stdout, "\t# Size of float: %i\n\n", (int)sizeof(mmd_float));
+  }
+  *out = s;
+  return 0;
+}
+
+// force (evflag=1) + thermo row for `step`, globally reduced
+static int force_and_row(mmd_sim* s, int step)
+{
+  mmd_handle* h = s->h;
+  double eng = 0, vir = 0, mv2 = 0;
+  MMD_TRY(mmd_force_compute(h, 1, &eng, &vir));
+  if(s->halfneigh && s->ghost_newton) MMD_TRY(mmd_comm_reverse_communicate(h));
+  MMD_TRY(mmd_thermo_temperature(h, &mv2));
+  double vals[3] = {mv2, eng, vir};
+  MMD_TRY(mmd_transport_allreduce(h, vals, 3));
+  thermo_row(s, step, vals[0], vals[1], vals[2]);
+  return 0;
+}
+
+extern "C" int mmd_sim_initial(mmd_sim* s)
+{
+  if(!s) { mmd_set_error("null sim"); return -1; }
+  mmd_handle* h = s->h;
+  MMD_TRY(mmd_comm_exchange(h));
+  if(s->sort > 0) MMD_TRY(mmd_atom_sort(h));
+  MMD_TRY(mmd_comm_borders(h));
+  MMD_TRY(mmd_neighbor_build(h));
+  if(s->me == 0 && !s->quiet) { printf("# Starting dynamics ...\n"); printf("# Timestep T U P Time\n"); }
+  s->row_step.clear(); s->row_t.clear(); s->row_u.clear(); s->row_p.clear();
+  MMD_TRY(force_and_row(s, 0));
+  s->steps_done = 0;
+  return 0;
+}
+
+extern "C" int mmd_sim_run(mmd_sim* s)
+{
+  if(!s) { mmd_set_error("null sim"); return -1; }
+  mmd_handle* h = s->h;
+  const int nstat = s->in.thermo_nstat;
+  s->t_run_start = mmd_wall();
+  MMD_TRY(mmd_integrate_run(h, s->steps_done, s->in.ntimes, nstat, thermo_row, s));
+  MMD_TRY(mmd_timers(h, s->last_timers, nullptr, nullptr));
+  s->steps_done += s->in.ntimes;
+  // ref/ljs.cpp:477-483 + Thermo::compute(-1) gating (ref/thermo.cpp:80)
+  if(!(nstat > 0 && s->in.ntimes % nstat == 0)) MMD_TRY(force_and_row(s, s->in.ntimes));
+  else { MMD_TRY(mmd_force_compute(h, 1, nullptr, nullptr)); if(s->halfneigh && s->ghost_newton) MMD_TRY(mmd_comm_reverse_communicate(h)); }
+  return 0;
+}
+
+extern "C" int mmd_sim_run_steps(mmd_sim* s, int nsteps, double* seconds)
+{
+  if(!s || nsteps < 0) { mmd_set_error("mmd_sim_run_steps: bad arguments"); return -1; }
+  mmd_handle* h = s->h;
+  MMD_TRY(mmd_sync(h));
+  const double t0 = mmd_wall();
+  s->t_run_start = t0;
+  MMD_TRY(mmd_integrate_run(h, s->steps_done, nsteps, s->in.thermo_nstat, thermo_row, s));
+  MMD_TRY(mmd_sync(h));
+  if(seconds) *seconds = mmd_wall() - t0;
+  MMD_TRY(mmd_timers(h, s->last_timers, nullptr, nullptr));
+  s->steps_done += nsteps;
+  return 0;
+}
+
+extern "C" int mmd_sim_print_perf(mmd_sim* s)
+{
+  if(!s) { mmd_set_error("null sim"); return -1; }
+  if(s->me != 0 || s->quiet) return 0;
+  const double* t = s->last_timers;
+  const double other = t[0] - t[2] - t[3] - t[1];
+  printf("\n\n");
+  printf("# Performance Summary:\n");
+  printf("# MPI_proc OMP_threads nsteps natoms t_total t_force t_neigh t_comm t_other performance perf/thread grep_string t_extra\n");
+  printf("%i %i %i %i %lf %lf %lf %lf %lf %lf %lf PERF_SUMMARY %lf\n\n\n", s->nprocs, s->num_threads, s->in.ntimes, s->natoms, t[0], t[2],
+         t[3], t[1], other, 1.0 * s->natoms * s->in.ntimes / t[0], 1.0 * s->natoms * s->in.ntimes / t[0] / s->nprocs / s->num_threads, t[4]);
+  return 0;
+}
+
+extern "C" int mmd_sim_rows(mmd_sim* s, int* nrows, int* steps, double* t, double* u, double* p, int maxrows)
+{
+  if(!s || !nrows) { mmd_set_error("mmd_sim_rows: bad arguments"); return -1; }
+  *nrows = (int)s->row_step.size();
+  for(int i = 0; i < *nrows && i < maxrows; i++) {
+    if(steps) steps[i] = s->row_step[i];
+    if(t) t[i] = s->row_t[i];
+    if(u) u[i] = s->row_u[i];
+    if(p) p[i] = s->row_p[i];
+  }
+  return 0;
+}
+
+extern "C" int mmd_sim_natoms(mmd_sim* s) { return s ? s->natoms : -1; }
+extern "C" mmd_handle* mmd_sim_handle(mmd_sim* s) { return s ? s->h : nullptr; }
+
+extern "C" int mmd_sim_destroy(mmd_sim* s)
+{
+  if(!s) return 0;
+  if(s->h) mmd_destroy(s->h);
+  delete s;
+  return 0;
+}

@@ -1,0 +1,125 @@
+// minimd_amd/csrc/util.hip — error text, wall clock, device exclusive scan, capacity management.
+#include <time.h>
+
+#include "device_utils.hpp"
+#include "mmd_internal.hpp"
+
+static thread_local char g_err[1024] = "";
+void mmd_set_error(const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mmd_last_error(void) { return g_err; }
+
+double mmd_wall()
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// in-place exclusive scan of int[n]: (1) per-tile totals, (2) one workgroup scans the tile totals,
+// (3) per-tile scan + offset.  Tiles of 1024 elements, 256 threads x 4 items.
+// ---------------------------------------------------------------------------------------------------
+#define SCAN_TILE 1024
+
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const int* __restrict__ d, int n, int* __restrict__ sums)
+{
+  __shared__ int lds[17];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  int s = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) if(base + k < n) s += d[base + k];
+  int tot;
+  block_incl_scan(s, lds, &tot);
+  if(threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ sums, int ntiles, int* __restrict__ total)
+{
+  __shared__ int lds[17];
+  int carry = 0;
+  for(int b = 0; b < ntiles; b += 1024) {
+    const int i = b + threadIdx.x;
+    const int v = i < ntiles ? sums[i] : 0;
+    int tot;
+    const int inc = block_incl_scan(v, lds, &tot);
+    if(i < ntiles) sums[i] = carry + inc - v;
+    carry += tot;
+  }
+  if(threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ d, int n, const int* __restrict__ sums)
+{
+  __shared__ int lds[17];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  int v[4];
+  int s = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) { v[k] = base + k < n ? d[base + k] : 0; s += v[k]; }
+  int tot;
+  const int inc = block_incl_scan(s, lds, &tot);
+  int run = sums[blockIdx.x] + inc - s;
+#pragma unroll
+  for(int k = 0; k < 4; k++) {
+    if(base + k < n) d[base + k] = run;
+    run += v[k];
+  }
+}
+
+// d[n] must be writable: the grand total is also stored there (bin_start[mbins] convention)
+int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host)
+{
+  const int ntiles = div_up(n, SCAN_TILE);
+  MMD_TRY(h->scan_tmp.ensure((size_t)ntiles + 8, false, h->stream));
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, h->stream, data, n, h->scan_tmp.p);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, h->scan_tmp.p, ntiles, data + n);
+  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, h->stream, data, n, h->scan_tmp.p);
+  HIP_TRY(hipGetLastError());
+  if(total_host) {
+    HIP_TRY(hipMemcpyAsync(h->h_flags, data + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *total_host = h->h_flags[0];
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-atom capacity (Atom::growarray, ref/atom.cpp:71-84) — +1 slot for the dummy atom
+// ---------------------------------------------------------------------------------------------------
+int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve)
+{
+  if(n + 1 <= h->nmax) return 0;
+  const size_t keep = (size_t)h->nlocal + h->nghost + 1;
+  const size_t want = (size_t)n + 1;
+  MMD_TRY(h->x.ensure(want, preserve, h->stream, keep));
+  MMD_TRY(h->v.ensure(3 * want, preserve, h->stream, 3 * keep));
+  MMD_TRY(h->f.ensure(3 * want, preserve, h->stream, 3 * keep));
+  MMD_TRY(h->type.ensure(want, preserve, h->stream, keep));
+  MMD_TRY(h->tag.ensure(want, preserve, h->stream, keep));
+  size_t c = h->x.cap;
+  if(h->v.cap / 3 < c) c = h->v.cap / 3;
+  if(h->f.cap / 3 < c) c = h->f.cap / 3;
+  if(h->type.cap < c) c = h->type.cap;
+  if(h->tag.cap < c) c = h->tag.cap;
+  h->nmax = (int)c;
+  return 0;
+}
+
+__global__ void k_set_dummy(real4* x, int slot)
+{
+  // far outside any cutoff, finite in float and double after squaring and summing
+  x[slot] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
+}
+
+int mmd_set_dummy(mmd_handle* h)
+{
+  hipLaunchKernelGGL(k_set_dummy, dim3(1), dim3(1), 0, h->stream, h->x.p, h->nlocal + h->nghost);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
