@@ -1,0 +1,184 @@
+"""CPU-only tests of the product's host side (no GPU, no compute calls): the C-ABI library loads and exports
+every symbol include/mmd.h declares; host logic (input deck, lattice, EAM tables, Comm::setup and
+Neighbor::setup geometry) is bit-identical to the oracle's; the product refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import minimd_amd
+from minimd_amd import api
+from oracle_lib import Oracle
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(REPO, "data")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not (os.path.exists(api.lib_path("dp")) and os.path.exists(api.lib_path("sp"))):
+        api.build()
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_library_exports_every_declared_symbol(prec):
+    hdr = open(os.path.join(REPO, "include", "mmd.h")).read()
+    declared = set(re.findall(r"\b(mmd_[a-z0-9_]+)\s*\(", hdr)) - {"mmd_sendrecv_fn", "mmd_allreduce_fn", "mmd_thermo_fn"}
+    L = api.load_library(prec)
+    import ctypes
+    raw = ctypes.CDLL(api.lib_path(prec))
+    missing = [s for s in sorted(declared) if not hasattr(raw, s)]
+    assert not missing, missing
+    assert L.mmd_float_size() == (8 if prec == "dp" else 4)
+    assert len(declared) >= 55
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(minimd_amd.MMDError, match="no HIP device"):
+        minimd_amd.Handle()
+    with pytest.raises(minimd_amd.MMDError):
+        minimd_amd.Sim(["-s", 4, "-n", 1])
+
+
+def test_product_never_references_the_oracle():
+    """the oracle is test infrastructure: nothing under minimd_amd/ or include/ may mention it"""
+    bad = []
+    for root in ("minimd_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle_lib|libmmd_oracle|mmd_oracle\.|orc_[a-z]+\(", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("prec,deck", [("dp", "in.lj.miniMD"), ("dp", "in.eam.miniMD"), ("sp", "in.lj.miniMD")])
+def test_input_deck_equals_oracle(prec, deck):
+    inp = api.input_read(os.path.join(DATA, deck), prec)
+    o = Oracle(["-i", deck, "-s", 4, "-n", 1, "--half_neigh", 0], precision=prec)
+    assert (inp.nx, inp.ny, inp.nz) == (32, 32, 32)
+    assert inp.dt == o.param("dt") and inp.rho == o.param("rho") and inp.t_request == o.param("t_request")
+    assert inp.neigh_cut == o.param("cutneigh") and inp.neigh_every == int(o.param("neigh_every"))
+    assert inp.thermo_nstat == int(o.param("nstat")) and inp.units == int(o.param("units")) and inp.forcetype == int(o.param("forcetype"))
+    if deck == "in.lj.miniMD":
+        assert inp.force_cut == o.param("cutforce")
+    o.close()
+
+
+def test_input_errors_are_reported_not_fatal(tmp_path):
+    with pytest.raises(minimd_amd.MMDError, match="Cannot open"):
+        api.input_read(str(tmp_path / "nope"))
+    p = tmp_path / "bad.deck"
+    p.write_text("t\n\nfurlongs\nnone\nlj\n1 1\n4 4 4\n1\n0.005\n1.44\n0.8\n20\n2.5 0.3\n100\n")
+    with pytest.raises(minimd_amd.MMDError, match="Unknown units"):
+        api.input_read(str(p))
+    p.write_text("short\n")
+    with pytest.raises(minimd_amd.MMDError):
+        api.input_read(str(p))
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("dims", [(4, 4, 4), (5, 3, 6)])
+def test_create_atoms_equals_oracle(prec, dims):
+    o = Oracle(["-nx", dims[0], "-ny", dims[1], "-nz", dims[2], "-n", 1, "--half_neigh", 0], precision=prec)
+    prd = api.create_box(*dims, o.param("rho"), prec)
+    box = o.box()
+    np.testing.assert_array_equal(prd, np.array(box[:3], dtype=prd.dtype))
+    x, v, t, tag = api.create_atoms(*dims, o.param("rho"), [0, 0, 0], prd, o.ntypes(), prec)
+    assert len(x) == o.natoms() == 4 * dims[0] * dims[1] * dims[2]
+    np.testing.assert_array_equal(x, o.x()[: o.nlocal()])
+    np.testing.assert_array_equal(t, o.type()[: o.nlocal()])
+    np.testing.assert_array_equal(tag, o.tag())
+    # raw velocities -> the oracle's after centre-of-mass removal and rescaling (same order of operations)
+    vv = v.astype(np.float64)
+    vtot = np.array([sum(vv[:, d].tolist()) for d in range(3)]) / len(x)       # sequential sums like the reference
+    vv = (v.astype(np.float64) - vtot).astype(v.dtype)
+    np.testing.assert_allclose(vv / np.abs(vv).max(), o.v() / np.abs(o.v()).max(), rtol=0, atol=2e-6 if prec == "sp" else 1e-13)
+    o.close()
+
+
+def test_create_atoms_subboxes_partition_the_lattice():
+    """every rank's sub-box creates its own atoms; together they are exactly the single-rank set"""
+    dims, rho = (6, 4, 5), 0.8442
+    prd = api.create_box(*dims, rho)
+    x_all, _, _, tag_all = api.create_atoms(*dims, rho, [0, 0, 0], prd)
+    tags = []
+    for ix in range(2):
+        for iz in range(3):
+            lo = [ix * prd[0] / 2, 0.0, iz * prd[2] / 3]
+            hi = [(ix + 1) * prd[0] / 2, prd[1], (iz + 1) * prd[2] / 3]
+            x, v, t, tag = api.create_atoms(*dims, rho, lo, hi)
+            assert np.all((x >= np.array(lo)) & (x < np.array(hi)))
+            tags.append(tag)
+    tags = np.concatenate(tags)
+    assert len(tags) == len(tag_all) and set(tags.tolist()) == set(tag_all.tolist())
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_eam_tables_equal_oracle(prec):
+    t = api.eam_tables_from_file(os.path.join(DATA, "Cu_u6.eam"), 4, prec)
+    o = Oracle(["-i", "in.eam.miniMD", "-s", 4, "-n", 1, "--half_neigh", 0], precision=prec)
+    ot = o.eam_tables()
+    for k in ("nr", "nrho", "nr_tot", "nrho_tot"):
+        assert t[k] == ot[k], k
+    assert t["rdr"] == ot["rdr"] and t["rdrho"] == ot["rdrho"] and t["mass"] == ot["mass"]
+    for k in ("rhor_spline", "z2r_spline", "frho_spline", "cutforcesq"):
+        np.testing.assert_array_equal(t[k], ot[k])
+    o.close()
+
+
+def test_eam_missing_file_is_an_error():
+    with pytest.raises(minimd_amd.MMDError, match="Can't open EAM"):
+        api.eam_tables_from_file("/nonexistent/Cu_u6.eam")
+
+
+@pytest.mark.parametrize("nprocs", [1, 2, 3, 4, 6, 8, 12])
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 8, 8), (6, 10, 14)])
+def test_comm_setup_geometry_equals_oracle(nprocs, dims):
+    """Comm::setup (ref/comm.cpp:60-272): grid, neighbors, sub-boxes, slabs, PBC flags — every rank"""
+    o = Oracle(["-nx", dims[0], "-ny", dims[1], "-nz", dims[2], "-n", 1, "--half_neigh", 0], nprocs=nprocs)
+    cut = o.param("cutneigh")
+    for me in range(nprocs):
+        h = minimd_amd.Handle(device=-2)
+        box = o.box(me)
+        h.set_box(box[:3])
+        h.comm_setup(cut, me, nprocs)
+        info = h.comm_info()
+        assert list(info["procgrid"]) == o.procgrid()
+        prd, lo, hi = h.get_box()
+        assert [lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]] == box[3:]
+        assert info["nswap"] == o.nswap(me)
+        for s in range(info["nswap"]):
+            a, b = h.swap_info(s), o.swap_info(me, s)
+            for k in ("slablo", "slabhi", "pbc_any", "pbc", "sendproc", "recvproc"):
+                assert a[k] == b[k], (me, s, k, a, b)
+        h.close()
+    o.close()
+
+
+@pytest.mark.parametrize("args", [["-s", 4], ["-s", 10], ["-s", 32], ["-s", 80], ["-nx", 7, "-ny", 5, "-nz", 6], ["-s", 8, "-b", 3],
+                                  ["-i", "in.eam.miniMD", "-s", 8]])
+def test_neighbor_geometry_equals_oracle(args):
+    """Neighbor::setup bin grid (ref/neighbor.cpp:349-391); plus: the block stencil covers the cutoff"""
+    o = Oracle(args + ["-n", 1, "--half_neigh", 0])
+    import ctypes as C
+    mb, lo, ns = (C.c_int * 3)(), (C.c_int * 3)(), C.c_int()
+    o.lib.orc_bin_geometry(o.w, 0, mb, lo, C.byref(ns))
+    h = minimd_amd.Handle(device=-2)
+    box = o.box()
+    h.set_box(box[:3])
+    h.comm_setup(o.param("cutneigh"), 0, 1)
+    h.neighbor_setup(o.nbins(), o.param("cutneigh"), 0, 1, 4)
+    g = h.neighbor_geometry()
+    assert list(g["mbin"]) == list(mb) and list(g["mbinlo"]) == list(lo)
+    for d in range(3):
+        binsize = box[d] / o.nbins()[d]
+        # a block is 2 bins wide: reach blocks on each side must span >= cutneigh beyond any atom of the block
+        assert g["reach"][d] * 2 * binsize >= o.param("cutneigh") - 1e-12 or (2 * g["reach"][d] - 1) * binsize >= o.param("cutneigh")
+        assert (2 * g["reach"][d] - 1) * binsize + binsize >= o.param("cutneigh")
+    h.close(); o.close()
