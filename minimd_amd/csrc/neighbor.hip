@@ -7,9 +7,10 @@
 //    slice of `binned[]`, and the blocks of one x-row contiguous too.
 //  * binning = atomic histogram + exclusive scan + atomic fill + in-bin index sort (=> deterministic
 //    order, identical to the reference run single-threaded inside each bin).
-//  * build = one wavefront per block: the candidate atoms of the (2R+1)^3 surrounding blocks are staged
-//    ONCE into LDS (contiguous slices, coalesced loads), then every lane (= one owned atom of the block)
-//    walks the staged candidates with broadcast LDS reads and appends hits to its wave-interleaved row.
+//  * build = one wavefront per block: the candidate atoms of the (2R+1)^3 surrounding blocks (contiguous
+//    slices of `binned`, coalesced loads) are held transposed in registers and every owned atom of the
+//    block is tested against 64 candidates per VALU pass; hits are appended in candidate order with
+//    ballot/mbcnt (see k_build). Bin slices of a block are located through a small LDS table.
 //    Distance test is evaluated exactly like the reference (no FMA contraction: this file is compiled
 //    with -ffp-contract=off; `rsq <= cutneighsq`, ref/neighbor.cpp:165,179), so rows equal the
 //    reference's as sets; the stencil always covers the full cutoff sphere.
@@ -19,21 +20,6 @@
 #include "mmd_internal.hpp"
 
 #define NB_SMALL 1.0e-6
-
-#if MMD_PRECISION == 1
-#define NB_CAP 3328
-#else
-#define NB_CAP 1664
-#endif
-
-struct __align__(16) Cand {      // one staged candidate: 32 B (DP) / 16+8 -> padded 32 B (SP keeps 24 -> 32)
-  real x, y, z;
-  int idx;
-  int info;                      // 0 skip, 1 keep, 2 compare coordinates (ghost, unshifted), 3 compare index (owned)
-#if MMD_PRECISION == 1
-  int pad0, pad1, pad2;
-#endif
-};
 
 // ---------------------------------------------------------------------------------------------------
 // Neighbor::setup (ref/neighbor.cpp:318-452)
@@ -162,14 +148,30 @@ int mmd_bin_atoms(mmd_handle* h, int count)
 // MODE 2: half with ghost newton: every pair stored once globally — owned j: j > i; ghost j that is a
 //         periodic image: by the sign of its image vector (the mirrored pair carries the opposite one);
 //         unshifted ghost (other rank's atom): (z,y,x) lexicographic order as ref/neighbor.cpp:155-157.
+//
+// Work decomposition (one wavefront per 2x2x2-bin block):
+//   * the ~27 blocks x ~57 atoms of candidates are loaded ONCE into REGISTERS, transposed: lane l holds
+//     candidates l, l+64, l+128, ... (NB_CHUNKS chunks; independent coalesced loads -> deep memory parallelism);
+//   * the block's owned atoms are then visited one at a time (wave-uniform: position arrives through the
+//     scalar cache), every lane testing its own candidate of each chunk; the hits of a chunk are appended
+//     IN CANDIDATE ORDER with ballot + mbcnt prefix (no atomics, deterministic), 64 tests per VALU pass.
+//   No LDS traffic in the hot loop, ~2 waves/SIMD (DP) instead of 3 waves/CU for the LDS-broadcast form.
+#if MMD_PRECISION == 1
+#define NB_CHUNKS 32
+#else
+#define NB_CHUNKS 28
+#endif
+#define NB_MAXA 512            // owned atoms of one block handled per pass (counts live in LDS)
+#define NB_IDX_MASK 0x1FFFFFFF // candidate word = index | info << 29
+
 template <int MODE>
-__global__ __launch_bounds__(64) void k_build(const real4* __restrict__ x, const int* __restrict__ binned,
-                                              const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
-                                              BinGeom g, int nlocal, real cutneighsq, int maxneighs,
-                                              int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags)
+__global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, const int* __restrict__ binned,
+                                                 const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
+                                                 BinGeom g, int nlocal, real cutneighsq, int maxneighs,
+                                                 int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags)
 {
-  __shared__ Cand cand[NB_CAP];
-  __shared__ int rng_start[128], rng_pref[129];
+  __shared__ int rng_start[128], rng_pref[130];
+  __shared__ int cnt[NB_MAXA];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
@@ -177,9 +179,8 @@ __global__ __launch_bounds__(64) void k_build(const real4* __restrict__ x, const
   const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
 
   // candidate slices: for every (dz,dy) one contiguous run of blocks [bx-R, bx+R] (clamped to the grid)
-  int nr = 0;
   if(lane == 0) {
-    int pref = 0;
+    int nr = 0, pref = 0;
     const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
     for(int dz = -g.reach[2]; dz <= g.reach[2]; dz++) {
       const int z = bz + dz;
@@ -193,74 +194,91 @@ __global__ __launch_bounds__(64) void k_build(const real4* __restrict__ x, const
       }
     }
     rng_pref[nr] = pref;
-    rng_pref[128] = nr;                                     // publish the slice count through LDS
+    rng_pref[129] = nr;
   }
   __syncthreads();
-  nr = rng_pref[128];
+  const int nr = rng_pref[129];
   const int total = rng_pref[nr];
 
-  // the owned atoms of this block, in chunks of 64 (usually one chunk)
-  for(int c0 = a0; c0 < a1; c0 += 64) {
-    const int me_pos = c0 + lane;
-    int i = me_pos < a1 ? binned[me_pos] : -1;
-    if(i >= nlocal) i = -1;                                 // ghosts get no row
-    const unsigned long long any = __ballot(i >= 0);
-    if(any == 0ULL) continue;
-    real4 xi = x[i >= 0 ? i : 0];
-    int n = 0;
-    const size_t rowbase = i >= 0 ? ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63) : 0;
+  for(int ab = a0; ab < a1; ab += NB_MAXA) {                // (one pass unless a block holds > NB_MAXA atoms)
+    const int ae = min(ab + NB_MAXA, a1);
+    for(int t = lane; t < ae - ab; t += 64) cnt[t] = 0;
+    __syncthreads();
 
-    for(int t0 = 0; t0 < total; t0 += NB_CAP) {
-      const int tn = min(NB_CAP, total - t0);
-      __syncthreads();
-      // ---- stage candidates t0 .. t0+tn into LDS (independent iterations: loads overlap)
-      for(int t = lane; t < tn; t += 64) {
-        const int gt = t0 + t;
-        int r = 0;
-        while(r + 1 < nr && rng_pref[r + 1] <= gt) r++;
-        const int j = binned[rng_start[r] + (gt - rng_pref[r])];
-        const real4 p = x[j];
-        Cand cd;
-        cd.x = p.x; cd.y = p.y; cd.z = p.z; cd.idx = j;
-        if(MODE == 0) cd.info = 1;
-        else if(MODE == 1) cd.info = j >= nlocal ? 1 : 3;
-        else {
-          if(j < nlocal) cd.info = 3;
-          else {
-            const int code = ghost_image[j - nlocal];        // (sx+2) + 5*(sy+2) + 25*(sz+2), 62 = unshifted
-            const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
-            if(sx == 0 && sy == 0 && sz == 0) cd.info = 2;
-            else cd.info = (sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0)))) ? 1 : 0;
+    for(int t0 = 0; t0 < total; t0 += NB_CHUNKS * 64) {     // (one pass unless > NB_CHUNKS*64 candidates)
+      // ---- transpose-load the candidates of this pass into registers
+      real cx[NB_CHUNKS], cy[NB_CHUNKS], cz[NB_CHUNKS];
+      unsigned cw[NB_CHUNKS];
+#pragma unroll
+      for(int c = 0; c < NB_CHUNKS; c++) {
+        const int gt = t0 + c * 64 + lane;
+        cx[c] = (real)1.0e15; cy[c] = (real)1.0e15; cz[c] = (real)1.0e15; cw[c] = NB_IDX_MASK;   // never a hit
+        if(gt < total) {
+          int r = 0;
+          while(r + 1 < nr && rng_pref[r + 1] <= gt) r++;
+          const int j = binned[rng_start[r] + (gt - rng_pref[r])];
+          const real4 p = x[j];
+          cx[c] = p.x; cy[c] = p.y; cz[c] = p.z;
+          unsigned info = 1;
+          if(MODE == 1) info = j >= nlocal ? 1 : 3;
+          if(MODE == 2) {
+            if(j < nlocal) info = 3;
+            else {
+              const int code = ghost_image[j - nlocal];      // (sx+2) + 5*(sy+2) + 25*(sz+2), 62 = unshifted
+              const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
+              if(sx == 0 && sy == 0 && sz == 0) info = 2;
+              else info = (sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0)))) ? 1 : 0;
+            }
           }
-        }
-        cand[t] = cd;
-      }
-      __syncthreads();
-      // ---- every lane tests every staged candidate (LDS broadcast reads)
-      if(i >= 0) {
-#pragma unroll 4
-        for(int t = 0; t < tn; t++) {
-          const Cand cd = cand[t];
-          const real dx = xi.x - cd.x, dy = xi.y - cd.y, dz = xi.z - cd.z;
-          const real rsq = dx * dx + dy * dy + dz * dz;
-          bool keep = rsq <= cutneighsq && cd.idx != i;
-          if(MODE != 0) {
-            bool ok = cd.info == 1;
-            if(cd.info == 3) ok = cd.idx > i;
-            if(MODE == 2 && cd.info == 2)
-              ok = !(cd.z < xi.z || (cd.z == xi.z && cd.y < xi.y) || (cd.z == xi.z && cd.y == xi.y && cd.x < xi.x));
-            keep = keep && ok;
-          }
-          if(keep) {
-            if(n < maxneighs) neigh[rowbase + (size_t)n * 64] = cd.idx;
-            n++;
-          }
+          cw[c] = (unsigned)j | (info << 29);
         }
       }
+      const int nchunks = min(NB_CHUNKS, (total - t0 + 63) >> 6);
+
+      // ---- owned atoms of the block, one per iteration (wave-uniform)
+      for(int a = ab; a < ae; a++) {
+        const int i = __builtin_amdgcn_readfirstlane(binned[a]);
+        if(i >= nlocal) continue;                            // ghosts get no row
+        const real4 xi = x[i];                               // uniform address: scalar load
+        const real xix = xi.x, xiy = xi.y, xiz = xi.z;
+        int n = cnt[a - ab];
+        const size_t rowbase = ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63);
+#pragma unroll
+        for(int c = 0; c < NB_CHUNKS; c++) {
+          if(c < nchunks) {
+            const real dx = xix - cx[c], dy = xiy - cy[c], dz = xiz - cz[c];
+            const real rsq = dx * dx + dy * dy + dz * dz;
+            const int j = (int)(cw[c] & NB_IDX_MASK);
+            bool keep = rsq <= cutneighsq && j != i;
+            if(MODE != 0) {
+              const unsigned info = cw[c] >> 29;
+              bool ok = info == 1;
+              if(info == 3) ok = j > i;
+              if(MODE == 2 && info == 2)
+                ok = !(cz[c] < xiz || (cz[c] == xiz && cy[c] < xiy) || (cz[c] == xiz && cy[c] == xiy && cx[c] < xix));
+              keep = keep && ok;
+            }
+            const unsigned long long m = __ballot(keep);
+            if(m) {
+              const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+              if(keep && pos < maxneighs) neigh[rowbase + (size_t)pos * 64] = j;
+              n += __popcll(m);
+            }
+          }
+        }
+        if(lane == 0) cnt[a - ab] = n;
+      }
+      __syncthreads();
     }
-    if(i >= 0) numneigh[i] = n;
-    const int wmax = wave_max_i(i >= 0 ? n : 0);
+    // ---- row lengths
+    int wmax = 0;
+    for(int t = lane; t < ae - ab; t += 64) {
+      const int i = binned[ab + t];
+      if(i < nlocal) { numneigh[i] = cnt[t]; wmax = max(wmax, cnt[t]); }
+    }
+    wmax = wave_max_i(wmax);
     if(lane == 0) atomicMax(&flags[0], wmax);
+    __syncthreads();
   }
 }
 
