@@ -175,6 +175,7 @@ extern "C" int mmd_atom_sort(mmd_handle* h)
   std::swap(h->v, h->v_alt);
   std::swap(h->type, h->type_alt);
   std::swap(h->tag, h->tag_alt);
-  // capacities of the swapped-in arrays are identical by construction; ghosts are rebuilt by borders next
+  h->neigh_nlocal = 0;            // atom indices changed: any neighbor list is stale
+  h->tiles_ready = false;
   return 0;
 }

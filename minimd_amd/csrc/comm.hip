@@ -558,5 +558,6 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   }
   MMD_TRY(mmd_set_dummy(h));
   h->neigh_nlocal = 0;                 // any existing neighbor list is stale now
+  h->tiles_ready = false;
   return 0;
 }

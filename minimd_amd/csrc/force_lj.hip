@@ -46,7 +46,7 @@ template <int EV, int UNIFORM, bool EXACT>
 __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__ x, const int* __restrict__ neigh,
                                                        const int* __restrict__ wave_max, int nlocal, int maxneighs,
                                                        LJParams P, LJTables T, real* __restrict__ f,
-                                                       double* __restrict__ partials)
+                                                       double* __restrict__ partials, int ablate)
 {
   __shared__ real s_cut[UNIFORM ? 1 : LJ_MAX_TYPES2], s_s6[UNIFORM ? 1 : LJ_MAX_TYPES2], s_eps[UNIFORM ? 1 : LJ_MAX_TYPES2];
   __shared__ double s_red[16];
@@ -73,6 +73,15 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
     real4 xj[MMD_UNROLL];
 #pragma unroll
     for(int u = 0; u < MMD_UNROLL; u++) j[u] = np[(size_t)(k + u) * 64];
+    if(ablate) {                               // profiling only (results invalid)
+#pragma unroll
+      for(int u = 0; u < MMD_UNROLL; u++) {
+        if(ablate & 4) j[u] = __builtin_amdgcn_readfirstlane(j[u]);                   // 1 line per gather
+        if(ablate & 8) j[u] = __builtin_amdgcn_readfirstlane(j[u]) + (lane >> 2);     // 16 lines, 4 lanes each
+        if(ablate & 16) j[u] = __builtin_amdgcn_readfirstlane(j[u]) + lane;           // 16 lines contiguous (2 KB)
+        if(ablate & 32) j[u] = (i + 64 * (k + u)) % nlocal;                            // no index dependency, contiguous
+      }
+    }
 #pragma unroll
     for(int u = 0; u < MMD_UNROLL; u++) xj[u] = x[j[u]];
 #pragma unroll
@@ -100,6 +109,145 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
     const double es = block_sum(e_acc, s_red);
     const double vs = block_sum(v_acc, s_red);
     if(threadIdx.x == 0) { partials[2 * (size_t)blockIdx.x] = es; partials[2 * (size_t)blockIdx.x + 1] = vs; }
+  }
+}
+
+
+// ---- full neighbor list, block-local ("tile") form: positions of the block's candidate atoms are staged
+// in LDS once per workgroup and every pair gathers from LDS instead of the L1/TA path -------------------
+// One workgroup = one tile (<= 64 owned atoms of one 2x2x2-bin block) x LJ_TILE_WAVES wavefronts; wave w
+// handles the neighbor-row slice k in [w*kmax/W, (w+1)*kmax/W) of the same 64 atoms, partial forces are
+// combined through LDS. The candidate sequence is rebuilt exactly like k_build's (same bin_start/binned
+// arrays, valid until the next re-neighboring) so the 16-bit slots of nl16 index straight into LDS.
+#define LJ_TILE_WAVES 4
+#define LJ_TILE_THREADS (64 * LJ_TILE_WAVES)
+#define LJ_STAGE 8            // candidates staged per thread and batch (independent load pairs in flight)
+
+// slices of binned[] that hold the candidates of block (bx,by,bz): lane r < nrows handles the x-row
+// (dy,dz) = r; lengths are prefix-summed with a wavefront scan. Must enumerate exactly like k_build.
+__device__ __forceinline__ int tile_ranges(const BinGeom& g, const int* __restrict__ bin_start, int bx, int by, int bz, int lane,
+                                           int* rng_start, int* rng_pref)
+{
+  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
+  const int nrows = ny * nz;                     // <= 64 guaranteed by the host
+  int len = 0, start = 0;
+  if(lane < nrows) {
+    const int z = bz + lane / ny - g.reach[2], y = by + lane % ny - g.reach[1];
+    if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
+      const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
+      const int row = (z * g.nblk[1] + y) * g.nblk[0];
+      start = bin_start[(row + x0) * 8];
+      len = bin_start[(row + x1) * 8 + 8] - start;
+    }
+  }
+  const int incl = wave_incl_scan(len);
+  if(lane < nrows) { rng_start[lane] = start; rng_pref[lane] = incl - len; }
+  if(lane == nrows - 1) rng_pref[nrows] = incl;
+  return nrows;
+}
+
+template <int EV, bool EXACT>
+__global__ __launch_bounds__(LJ_TILE_THREADS) void k_lj_full_tile(
+    const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ bin_start, BinGeom g,
+    const int* __restrict__ tile_block, const int* __restrict__ tile_first, const int* __restrict__ tile_max,
+    const unsigned short* __restrict__ nl16, int nlocal, int maxneighs, LJParams P, real* __restrict__ f,
+    double* __restrict__ partials, int ablate)
+{
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  __shared__ int rng_start[64], rng_pref[66];
+  __shared__ real s_f[3 * 64 * (LJ_TILE_WAVES - 1) + 3];
+  __shared__ double s_red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tile = blockIdx.x;
+  const int b = tile_block[tile];
+  const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
+  if(wv == 0) tile_ranges(g, bin_start, bx, by, bz, lane, rng_start, rng_pref);
+  // my atom and my slice of its neighbor row: issue these loads before the staging barrier
+  const int a = tile_first[tile] + lane;
+  const int a1 = bin_start[b * 8 + 8];
+  int i = a < a1 ? binned[a] : -1;
+  if(i >= nlocal) i = -1;
+  const real4 xi = x[i >= 0 ? i : 0];
+  const int kmax = (ablate & 2) ? 0 : tile_max[tile];
+  const int per = ((kmax / MMD_UNROLL + LJ_TILE_WAVES - 1) / LJ_TILE_WAVES) * MMD_UNROLL;
+  const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
+  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  int s_nxt[MMD_UNROLL];
+#pragma unroll
+  for(int u = 0; u < MMD_UNROLL; u++) s_nxt[u] = k0 < k1 ? np[(size_t)(k0 + u) * 64] : 0;
+  __syncthreads();
+  const int nr = (2 * g.reach[1] + 1) * (2 * g.reach[2] + 1);
+  const int total = rng_pref[nr];
+  real* sx = (real*)s_raw;                       // SoA: 8-byte (4-byte SP) gathers spread over all banks
+  real* sy = sx + (total + 1);
+  real* sz = sy + (total + 1);
+  int rr = 0;                                   // candidate slots grow with u: the slice search never restarts
+  for(int tb = tid; tb <= total && !(ablate & 1); tb += LJ_STAGE * LJ_TILE_THREADS) {
+    int jj[LJ_STAGE];
+#pragma unroll
+    for(int u = 0; u < LJ_STAGE; u++) {
+      const int t = tb + u * LJ_TILE_THREADS;
+      jj[u] = -1;
+      if(t < total) {
+        while(rr + 1 < nr && rng_pref[rr + 1] <= t) rr++;
+        jj[u] = binned[rng_start[rr] + (t - rng_pref[rr])];
+      }
+    }
+    real4 pp[LJ_STAGE];
+#pragma unroll
+    for(int u = 0; u < LJ_STAGE; u++) pp[u] = jj[u] >= 0 ? x[jj[u]] : real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
+#pragma unroll
+    for(int u = 0; u < LJ_STAGE; u++) {
+      const int t = tb + u * LJ_TILE_THREADS;
+      if(t <= total) { sx[t] = pp[u].x; sy[t] = pp[u].y; sz[t] = pp[u].z; }     // slot `total` = padding dummy
+    }
+  }
+  __syncthreads();
+
+  real fx = 0, fy = 0, fz = 0;
+  double e_acc = 0, v_acc = 0;
+  const real c48 = (real)48.0 * P.epsilon;
+  for(int k = k0; k < k1; k += MMD_UNROLL) {
+    int s[MMD_UNROLL];
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) s[u] = s_nxt[u];
+    if(k + MMD_UNROLL < k1) {                    // prefetch the next slots under this trip's arithmetic
+#pragma unroll
+      for(int u = 0; u < MMD_UNROLL; u++) s_nxt[u] = np[(size_t)(k + MMD_UNROLL + u) * 64];
+    }
+    real xj[MMD_UNROLL], yj[MMD_UNROLL], zj[MMD_UNROLL];
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) { xj[u] = sx[s[u]]; yj[u] = sy[s[u]]; zj[u] = sz[s[u]]; }
+#pragma unroll
+    for(int u = 0; u < MMD_UNROLL; u++) {
+      const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
+      const real rsq = dx * dx + dy * dy + dz * dz;
+      const real sr2 = recip<EXACT>(rsq);
+      const real sr6 = sr2 * sr2 * sr2 * P.sigma6;
+      real force = c48 * sr6 * (sr6 - (real)0.5) * sr2;
+      const bool in = rsq < P.cutforcesq;
+      force = in ? force : (real)0;
+      fx += dx * force; fy += dy * force; fz += dz * force;
+      if(EV) {
+        const real en = in ? sr6 * (sr6 - (real)1.0) * P.epsilon : (real)0;
+        e_acc += (double)en;
+        v_acc += (double)(rsq * force);
+      }
+    }
+  }
+  // combine the wave slices
+  if(wv > 0) { real* d = s_f + 3 * 64 * (wv - 1); d[lane] = fx; d[64 + lane] = fy; d[128 + lane] = fz; }
+  __syncthreads();
+  if(wv == 0 && i >= 0) {
+#pragma unroll
+    for(int q = 0; q < LJ_TILE_WAVES - 1; q++) { const real* d = s_f + 3 * 64 * q; fx += d[lane]; fy += d[64 + lane]; fz += d[128 + lane]; }
+    f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz;
+  }
+  if(EV) {
+    if(i < 0) { e_acc = 0; v_acc = 0; }
+    const double es = block_sum(e_acc, s_red);
+    const double vs = block_sum(v_acc, s_red);
+    if(tid == 0) { partials[2 * (size_t)blockIdx.x] = es; partials[2 * (size_t)blockIdx.x + 1] = vs; }
   }
 }
 
@@ -219,7 +367,7 @@ template <int EV, int UNIFORM, bool EXACT>
 static void launch_full(mmd_handle* h, int nblocks, const LJTables& T)
 {
   hipLaunchKernelGGL((k_lj_full<EV, UNIFORM, EXACT>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
-                     h->wave_max.p, h->nlocal, h->maxneighs, h->lj, T, h->f.p, h->partials.p);
+                     h->wave_max.p, h->nlocal, h->maxneighs, h->lj, T, h->f.p, h->partials.p, h->opt_ablate);
 }
 template <int EV, int GN, int UNIFORM, bool EXACT>
 static void launch_half(mmd_handle* h, int nblocks, const LJTables& T)
@@ -240,7 +388,19 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   MMD_TRY(h->partials.ensure((size_t)2 * nblocks + 8, false, h->stream));
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   const int ev = evflag ? 1 : 0, uni = h->lj_uniform ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
-  if(!h->halfneigh) {
+  int nsum = nblocks;
+  const size_t tile_lds = (size_t)3 * (h->tile_tmax + 1) * sizeof(real);
+  const bool rows_ok = (2 * h->bg.reach[1] + 1) * (2 * h->bg.reach[2] + 1) <= 64;
+  if(!h->halfneigh && h->tiles_ready && h->opt_tiles && uni && rows_ok && tile_lds <= 150 * 1024) {
+    nsum = h->ntiles;
+    MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
+#define TK(EVv, Xv) if(ev == EVv && ex == Xv)                                                                                \
+    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0)>), dim3(h->ntiles), dim3(LJ_TILE_THREADS), tile_lds, h->stream, h->x.p,  \
+                       h->binned.p, h->bin_start.p, h->bg, h->tile_block.p, h->tile_first.p, h->tile_max.p, h->nl16.p, nlocal,   \
+                       h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
+    TK(0, 0); TK(0, 1); TK(1, 0); TK(1, 1);
+#undef TK
+  } else if(!h->halfneigh) {
 #define F(EVv, Uv, Xv) if(ev == EVv && uni == Uv && ex == Xv) launch_full<EVv, Uv, (Xv != 0)>(h, nblocks, T)
     F(0, 0, 0); F(0, 0, 1); F(0, 1, 0); F(0, 1, 1); F(1, 0, 0); F(1, 0, 1); F(1, 1, 0); F(1, 1, 1);
 #undef F
@@ -255,7 +415,7 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   HIP_TRY(hipGetLastError());
   if(evflag) {
     // reference conventions: full lists visit both directions, then eng*4 and virial*0.5 (force_lj.cpp:441-442)
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->partials.p, nblocks, 2, h->d_result,
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->partials.p, nsum, 2, h->d_result,
                        h->halfneigh ? 1.0 : 4.0, h->halfneigh ? 1.0 : 0.5);
     HIP_TRY(hipGetLastError());
     if(eng || vir) {

@@ -89,6 +89,7 @@ struct LJParams {            // uniform-table fast path (all type pairs identica
 struct BinGeom {             // Neighbor::setup result (ref/neighbor.cpp:318-452) + block-major numbering
   real prd[3], bininv[3], binsize[3];
   int nbin[3], mbinlo[3], mbin[3];
+  int blkshift[3];           // parity shift so that the periodic box edge falls on a block boundary
   int nblk[3];               // 2x2x2-bin blocks per dimension
   int reach[3];              // stencil reach in BLOCKS (covers ref's next{x,y,z} bins)
   int mbins;                 // nblk[0]*nblk[1]*nblk[2]*8
@@ -129,6 +130,15 @@ struct mmd_handle {
   long long total_neigh = 0;
   int max_row = 0;
   DevArr<int> ghost_image;   // per ghost: packed periodic-image code (half lists with ghost newton)
+  // block-local ("tile") neighbor list used by the LDS force kernels: a tile = up to 64 consecutive
+  // entries of binned[] inside one block; nl16[(tile*maxneighs + k)*64 + lane] = slot of the neighbor in
+  // the block's candidate sequence (the order in which k_build walks the surrounding blocks)
+  bool tiles_ready = false;
+  int ntiles = 0, tile_tmax = 0;          // tile_tmax: largest candidate count of any block (LDS sizing)
+  DevArr<int> tile_of_block, tile_block, tile_first, tile_max, blk_ncand;
+  DevArr<unsigned short> nl16;
+  int opt_tiles = 1;
+  int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)
   // ---- Force
   int style = 0;             // 0 LJ, 1 EAM
   bool lj_uniform = true;

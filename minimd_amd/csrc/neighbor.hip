@@ -49,7 +49,8 @@ extern "C" int mmd_neighbor_setup(mmd_handle* h, const int nbin[3], mmd_float cu
     lo -= 1; hi += 1;                      // one extra bin each side, as the reference
     g.mbinlo[d] = lo;
     g.mbin[d] = hi - lo + 1;
-    g.nblk[d] = (g.mbin[d] + 1) >> 1;
+    g.blkshift[d] = (-g.mbinlo[d]) & 1;          // bin of coordinate 0 gets an even shifted index
+    g.nblk[d] = (g.mbin[d] + g.blkshift[d] + 1) >> 1;
     int next = static_cast<int>(cutneigh * g.bininv[d]);
     if(next * g.binsize[d] < cutneigh) next++;   // full coverage (the reference shaves 0.1% here, :405-415)
     g.reach[d] = (next + 1) >> 1;
@@ -83,6 +84,7 @@ __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
   ix = min(max(ix, 0), g.mbin[0] - 1);
   iy = min(max(iy, 0), g.mbin[1] - 1);
   iz = min(max(iz, 0), g.mbin[2] - 1);
+  ix += g.blkshift[0]; iy += g.blkshift[1]; iz += g.blkshift[2];
   const int blk = ((iz >> 1) * g.nblk[1] + (iy >> 1)) * g.nblk[0] + (ix >> 1);
   return blk * 8 + ((iz & 1) << 2 | (iy & 1) << 1 | (ix & 1));
 }
@@ -168,7 +170,9 @@ template <int MODE>
 __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, const int* __restrict__ binned,
                                                  const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
                                                  BinGeom g, int nlocal, real cutneighsq, int maxneighs,
-                                                 int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags)
+                                                 int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags,
+                                                 const int* __restrict__ tile_of_block, unsigned short* __restrict__ nl16,
+                                                 int* __restrict__ blk_ncand)
 {
   __shared__ int rng_start[128], rng_pref[130];
   __shared__ int cnt[NB_MAXA];
@@ -178,27 +182,36 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
   if(a0 == a1) return;                                      // empty block (uniform exit)
   const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
 
-  // candidate slices: for every (dz,dy) one contiguous run of blocks [bx-R, bx+R] (clamped to the grid)
-  if(lane == 0) {
-    int nr = 0, pref = 0;
-    const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
-    for(int dz = -g.reach[2]; dz <= g.reach[2]; dz++) {
-      const int z = bz + dz;
-      if(z < 0 || z >= g.nblk[2]) continue;
-      for(int dy = -g.reach[1]; dy <= g.reach[1]; dy++) {
-        const int y = by + dy;
-        if(y < 0 || y >= g.nblk[1]) continue;
+  // candidate slices: for every (dz,dy) one contiguous run of blocks [bx-R, bx+R] (clamped to the grid);
+  // lane r handles row r (<= 128 rows: two passes of the wavefront), lengths prefix-summed by a wave scan
+  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
+  const int nr = min(ny * nz, 128);
+  int carry = 0;
+  for(int r0 = 0; r0 < nr; r0 += 64) {
+    const int r = r0 + lane;
+    int len = 0, start = 0;
+    if(r < nr) {
+      const int z = bz + r / ny - g.reach[2], y = by + r % ny - g.reach[1];
+      if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
+        const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
         const int row = (z * g.nblk[1] + y) * g.nblk[0];
-        const int s = bin_start[(row + x0) * 8], e = bin_start[(row + x1) * 8 + 8];
-        if(e > s && nr < 128) { rng_start[nr] = s; rng_pref[nr] = pref; pref += e - s; nr++; }
+        start = bin_start[(row + x0) * 8];
+        len = bin_start[(row + x1) * 8 + 8] - start;
       }
     }
-    rng_pref[nr] = pref;
-    rng_pref[129] = nr;
+    const int incl = wave_incl_scan(len);
+    if(r < nr) { rng_start[r] = start; rng_pref[r] = carry + incl - len; }
+    carry += __shfl(incl, 63, 64);
   }
+  if(lane == 0) rng_pref[nr] = carry;
   __syncthreads();
-  const int nr = rng_pref[129];
   const int total = rng_pref[nr];
+  const bool tiles = nl16 != nullptr && total < 65535;       // 16-bit candidate slots (slot `total` = dummy)
+  const int tile0 = tiles ? tile_of_block[b] : 0;
+  if(lane == 0) {
+    if(nl16 != nullptr) blk_ncand[b] = total;
+    atomicMax(&flags[1], total);
+  }
 
   for(int ab = a0; ab < a1; ab += NB_MAXA) {                // (one pass unless a block holds > NB_MAXA atoms)
     const int ae = min(ab + NB_MAXA, a1);
@@ -209,12 +222,12 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
       // ---- transpose-load the candidates of this pass into registers
       real cx[NB_CHUNKS], cy[NB_CHUNKS], cz[NB_CHUNKS];
       unsigned cw[NB_CHUNKS];
+      int r = 0;                               // slots grow with c: the slice search never restarts
 #pragma unroll
       for(int c = 0; c < NB_CHUNKS; c++) {
         const int gt = t0 + c * 64 + lane;
         cx[c] = (real)1.0e15; cy[c] = (real)1.0e15; cz[c] = (real)1.0e15; cw[c] = NB_IDX_MASK;   // never a hit
         if(gt < total) {
-          int r = 0;
           while(r + 1 < nr && rng_pref[r + 1] <= gt) r++;
           const int j = binned[rng_start[r] + (gt - rng_pref[r])];
           const real4 p = x[j];
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
         const real xix = xi.x, xiy = xi.y, xiz = xi.z;
         int n = cnt[a - ab];
         const size_t rowbase = ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63);
+        const size_t tilebase = ((size_t)(tile0 + ((a - a0) >> 6)) * maxneighs) * 64 + ((a - a0) & 63);
 #pragma unroll
         for(int c = 0; c < NB_CHUNKS; c++) {
           if(c < nchunks) {
@@ -261,7 +275,10 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
             const unsigned long long m = __ballot(keep);
             if(m) {
               const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-              if(keep && pos < maxneighs) neigh[rowbase + (size_t)pos * 64] = j;
+              if(keep && pos < maxneighs) {
+                neigh[rowbase + (size_t)pos * 64] = j;
+                if(tiles) nl16[tilebase + (size_t)pos * 64] = (unsigned short)(t0 + c * 64 + lane);
+              }
               n += __popcll(m);
             }
           }
@@ -280,6 +297,51 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
     if(lane == 0) atomicMax(&flags[0], wmax);
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tiles: blocks that hold at least one owned atom are cut into groups of <= 64 consecutive binned entries
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_tile_count(const int* __restrict__ binned, const int* __restrict__ bin_start, int nblocks, int nlocal,
+                             int* __restrict__ ntile_of_block)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= nblocks) return;
+  const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
+  bool owned = false;
+  for(int a = a0; a < a1 && !owned; a++) owned = binned[a] < nlocal;
+  ntile_of_block[b] = owned ? (a1 - a0 + 63) >> 6 : 0;
+}
+__global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, const int* __restrict__ tile_of_block,
+                            int* __restrict__ tile_block, int* __restrict__ tile_first)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= nblocks) return;
+  const int t0 = tile_of_block[b], t1 = tile_of_block[b + 1];
+  const int a0 = bin_start[b * 8];
+  for(int t = t0; t < t1; t++) { tile_block[t] = b; tile_first[t] = a0 + (t - t0) * 64; }
+}
+// pad the tile rows with the dummy candidate slot (= ncand of the block) up to the tile's longest row
+__global__ __launch_bounds__(256) void k_pad_tiles(int ntiles, int nlocal, int maxneighs, const int* __restrict__ tile_block,
+                                                   const int* __restrict__ tile_first, const int* __restrict__ bin_start,
+                                                   const int* __restrict__ binned, const int* __restrict__ numneigh,
+                                                   const int* __restrict__ blk_ncand, unsigned short* __restrict__ nl16,
+                                                   int* __restrict__ tile_max)
+{
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if(t >= ntiles) return;
+  const int b = tile_block[t];
+  const int a = tile_first[t] + lane, a1 = bin_start[b * 8 + 8];
+  int n = 0;
+  if(a < a1) { const int i = binned[a]; if(i < nlocal) n = numneigh[i]; }
+  int m = wave_max_i(n);
+  m = (m + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
+  if(m > maxneighs) m = maxneighs;
+  const unsigned short dummy = (unsigned short)blk_ncand[b];
+  const size_t base = ((size_t)t * maxneighs) * 64 + lane;
+  for(int k = n; k < m; k++) nl16[base + (size_t)k * 64] = dummy;
+  if(lane == 0) tile_max[t] = m;
 }
 
 // pad every row with the dummy atom up to its wavefront's longest row (rounded up to the unroll factor)
@@ -317,13 +379,31 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   MMD_TRY(h->numneigh.ensure((size_t)nlocal + 64, false, h->stream));
   MMD_TRY(h->wave_max.ensure((size_t)nwaves + 1, false, h->stream));
   const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
+  // tiles for the LDS force kernels (full lists, LJ uniform tables: see force_lj.hip)
+  h->tiles_ready = false;
+  const bool want_tiles = h->opt_tiles && !h->halfneigh && nlocal > 0;
+  if(want_tiles) {
+    MMD_TRY(h->tile_of_block.ensure((size_t)nblocks + 2, false, h->stream));
+    MMD_TRY(h->blk_ncand.ensure((size_t)nblocks + 2, false, h->stream));
+    hipLaunchKernelGGL(k_tile_count, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->binned.p, h->bin_start.p, nblocks, nlocal, h->tile_of_block.p);
+    int nt = 0;
+    MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nblocks, &nt));
+    h->ntiles = nt;
+    MMD_TRY(h->tile_block.ensure((size_t)nt + 2, false, h->stream));
+    MMD_TRY(h->tile_first.ensure((size_t)nt + 2, false, h->stream));
+    MMD_TRY(h->tile_max.ensure((size_t)nt + 2, false, h->stream));
+    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p);
+    HIP_TRY(hipGetLastError());
+  }
   for(int attempt = 0; attempt < 8; attempt++) {
     MMD_TRY(h->neigh.ensure((size_t)nwaves * h->maxneighs * 64 + 64, false, h->stream));
+    if(want_tiles) MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 64, false, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
     const int mode = !h->halfneigh ? 0 : (h->ghost_newton ? 2 : 1);
 #define LAUNCH_BUILD(M)                                                                                              \
   hipLaunchKernelGGL(k_build<M>, dim3(nblocks), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,        \
-                     h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags)
+                     h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags,       \
+                     h->tile_of_block.p, want_tiles ? h->nl16.p : (unsigned short*)nullptr, h->blk_ncand.p)
     if(nlocal) {
       if(mode == 0) LAUNCH_BUILD(0);
       else if(mode == 1) LAUNCH_BUILD(1);
@@ -346,6 +426,12 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     if(nwaves)
       hipLaunchKernelGGL(k_pad_rows, dim3(div_up(nwaves * 64, 256)), dim3(256), 0, h->stream, nlocal, nwaves, h->maxneighs, nall,
                          h->neigh.p, h->numneigh.p, h->wave_max.p, (unsigned long long*)h->d_result);
+    if(want_tiles && h->ntiles) {
+      hipLaunchKernelGGL(k_pad_tiles, dim3(div_up((long long)h->ntiles * 64, 256)), dim3(256), 0, h->stream, h->ntiles, nlocal, h->maxneighs,
+                         h->tile_block.p, h->tile_first.p, h->bin_start.p, h->binned.p, h->numneigh.p, h->blk_ncand.p, h->nl16.p, h->tile_max.p);
+      h->tile_tmax = h->h_flags[1];
+      h->tiles_ready = h->tile_tmax < 65535;
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -447,5 +533,6 @@ extern "C" int mmd_neighbor_upload(mmd_handle* h, const int* neighbors, int maxn
   tmp.release();
   h->neigh_nlocal = nlocal;
   h->max_row = maxn;
+  h->tiles_ready = false;         // an uploaded list has no block-local form
   return 0;
 }

@@ -76,6 +76,30 @@ def test_lj_force_full_matches_oracle(size, ntypes):
     h.close(); o.close()
 
 
+@pytest.mark.parametrize("args", [["-s", 4], ["-s", 7], ["-nx", 9, "-ny", 5, "-nz", 6], ["-s", 6, "-b", 9]])
+def test_lj_force_full_tile_path_matches_oracle(args):
+    """device-built list -> LDS tile kernel (the production LJ path) vs the oracle's forces on the same atoms;
+    and the tile kernel vs the generic global-gather kernel on the same device list"""
+    o = Oracle(args + ["-n", 20, "--half_neigh", 0])
+    o.initial(); o.run()
+    h = handle_from_oracle(o)
+    h.force_lj_setup(*o.lj_tables())
+    h.neighbor_build()
+    fo = o.f()
+    scale = np.abs(fo).max()
+    out = {}
+    for tiles in (1, 0):
+        h.set_option("tiles", tiles)
+        eng, vir = h.force_compute(1)
+        f = h.download()["f"]
+        assert np.abs(f - fo).max() <= 1e-12 * scale
+        assert abs(eng - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl())
+        assert abs(vir - o.virial()) <= 1e-11 * max(1.0, abs(o.virial()))
+        out[tiles] = f
+    assert np.abs(out[0] - out[1]).max() <= 1e-13 * scale
+    h.close(); o.close()
+
+
 def test_lj_force_nonuniform_type_tables():
     """per type-pair tables (the general path; miniMD itself always fills them uniformly)"""
     o = Oracle(["-s", 5, "-n", 20, "--half_neigh", 0, "--ntypes", 3])
