@@ -123,51 +123,42 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
 #define LJ_TILE_THREADS (64 * LJ_TILE_WAVES)
 #define LJ_STAGE 8            // candidates staged per thread and batch (independent load pairs in flight)
 
-// slices of binned[] that hold the candidates of block (bx,by,bz): lane r < nrows handles the x-row
-// (dy,dz) = r; lengths are prefix-summed with a wavefront scan. Must enumerate exactly like k_build.
-__device__ __forceinline__ int tile_ranges(const BinGeom& g, const int* __restrict__ bin_start, int bx, int by, int bz, int lane,
-                                           int* rng_start, int* rng_pref)
-{
-  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
-  const int nrows = ny * nz;                     // <= 64 guaranteed by the host
-  int len = 0, start = 0;
-  if(lane < nrows) {
-    const int z = bz + lane / ny - g.reach[2], y = by + lane % ny - g.reach[1];
-    if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
-      const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
-      const int row = (z * g.nblk[1] + y) * g.nblk[0];
-      start = bin_start[(row + x0) * 8];
-      len = bin_start[(row + x1) * 8 + 8] - start;
-    }
-  }
-  const int incl = wave_incl_scan(len);
-  if(lane < nrows) { rng_start[lane] = start; rng_pref[lane] = incl - len; }
-  if(lane == nrows - 1) rng_pref[nrows] = incl;
-  return nrows;
-}
-
 template <int EV, bool EXACT>
 __global__ __launch_bounds__(LJ_TILE_THREADS) void k_lj_full_tile(
-    const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ bin_start, BinGeom g,
-    const int* __restrict__ tile_block, const int* __restrict__ tile_first, const int* __restrict__ tile_max,
-    const unsigned short* __restrict__ nl16, int nlocal, int maxneighs, LJParams P, real* __restrict__ f,
+    const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
+    const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride,
+    const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, LJParams P, real* __restrict__ f,
     double* __restrict__ partials, int ablate)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
-  __shared__ int rng_start[64], rng_pref[66];
   __shared__ real s_f[3 * 64 * (LJ_TILE_WAVES - 1) + 3];
   __shared__ double s_red[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.x;
-  const int b = tile_block[tile];
-  const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
-  if(wv == 0) tile_ranges(g, bin_start, bx, by, bz, lane, rng_start, rng_pref);
-  // my atom and my slice of its neighbor row: issue these loads before the staging barrier
-  const int a = tile_first[tile] + lane;
-  const int a1 = bin_start[b * 8 + 8];
-  int i = a < a1 ? binned[a] : -1;
-  if(i >= nlocal) i = -1;
-  const real4 xi = x[i >= 0 ? i : 0];
+  const int ncand = tile_ncand[tile];
+  // ---- stage the positions of the tile's candidate union (+1 dummy slot) into LDS, SoA
+  real* sx = (real*)s_raw;                       // 8-byte (4-byte SP) gathers spread over all banks
+  real* sy = sx + (ncand + 1);
+  real* sz = sy + (ncand + 1);
+  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  for(int tb = tid; tb <= ncand && !(ablate & 1); tb += LJ_STAGE * LJ_TILE_THREADS) {
+    int jj[LJ_STAGE];
+#pragma unroll
+    for(int u = 0; u < LJ_STAGE; u++) {
+      const int t = tb + u * LJ_TILE_THREADS;
+      jj[u] = t < ncand ? cl[t] : nall;           // slot `ncand` (and beyond) = the far-away dummy atom
+    }
+    real4 pp[LJ_STAGE];
+#pragma unroll
+    for(int u = 0; u < LJ_STAGE; u++) pp[u] = x[jj[u]];
+#pragma unroll
+    for(int u = 0; u < LJ_STAGE; u++) {
+      const int t = tb + u * LJ_TILE_THREADS;
+      if(t <= ncand) { sx[t] = pp[u].x; sy[t] = pp[u].y; sz[t] = pp[u].z; }
+    }
+  }
+  // ---- my atom and my slice of its neighbor row (wave w takes k in [k0,k1))
+  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;     // a tile never straddles blocks
   const int kmax = (ablate & 2) ? 0 : tile_max[tile];
   const int per = ((kmax / MMD_UNROLL + LJ_TILE_WAVES - 1) / LJ_TILE_WAVES) * MMD_UNROLL;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
@@ -175,33 +166,8 @@ __global__ __launch_bounds__(LJ_TILE_THREADS) void k_lj_full_tile(
   int s_nxt[MMD_UNROLL];
 #pragma unroll
   for(int u = 0; u < MMD_UNROLL; u++) s_nxt[u] = k0 < k1 ? np[(size_t)(k0 + u) * 64] : 0;
-  __syncthreads();
-  const int nr = (2 * g.reach[1] + 1) * (2 * g.reach[2] + 1);
-  const int total = rng_pref[nr];
-  real* sx = (real*)s_raw;                       // SoA: 8-byte (4-byte SP) gathers spread over all banks
-  real* sy = sx + (total + 1);
-  real* sz = sy + (total + 1);
-  int rr = 0;                                   // candidate slots grow with u: the slice search never restarts
-  for(int tb = tid; tb <= total && !(ablate & 1); tb += LJ_STAGE * LJ_TILE_THREADS) {
-    int jj[LJ_STAGE];
-#pragma unroll
-    for(int u = 0; u < LJ_STAGE; u++) {
-      const int t = tb + u * LJ_TILE_THREADS;
-      jj[u] = -1;
-      if(t < total) {
-        while(rr + 1 < nr && rng_pref[rr + 1] <= t) rr++;
-        jj[u] = binned[rng_start[rr] + (t - rng_pref[rr])];
-      }
-    }
-    real4 pp[LJ_STAGE];
-#pragma unroll
-    for(int u = 0; u < LJ_STAGE; u++) pp[u] = jj[u] >= 0 ? x[jj[u]] : real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
-#pragma unroll
-    for(int u = 0; u < LJ_STAGE; u++) {
-      const int t = tb + u * LJ_TILE_THREADS;
-      if(t <= total) { sx[t] = pp[u].x; sy[t] = pp[u].y; sz[t] = pp[u].z; }     // slot `total` = padding dummy
-    }
-  }
+  if(i >= nlocal) i = -1;
+  const real4 xi = x[i >= 0 ? i : 0];
   __syncthreads();
 
   real fx = 0, fy = 0, fz = 0;
@@ -389,15 +355,14 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   const int ev = evflag ? 1 : 0, uni = h->lj_uniform ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
   int nsum = nblocks;
-  const size_t tile_lds = (size_t)3 * (h->tile_tmax + 1) * sizeof(real);
-  const bool rows_ok = (2 * h->bg.reach[1] + 1) * (2 * h->bg.reach[2] + 1) <= 64;
-  if(!h->halfneigh && h->tiles_ready && h->opt_tiles && uni && rows_ok && tile_lds <= 150 * 1024) {
+  const size_t tile_lds = (size_t)3 * (h->tile_cmax + 1) * sizeof(real);
+  if(!h->halfneigh && h->tiles_ready && h->opt_tiles && uni && tile_lds <= 60 * 1024) {
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
 #define TK(EVv, Xv) if(ev == EVv && ex == Xv)                                                                                \
     hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0)>), dim3(h->ntiles), dim3(LJ_TILE_THREADS), tile_lds, h->stream, h->x.p,  \
-                       h->binned.p, h->bin_start.p, h->bg, h->tile_block.p, h->tile_first.p, h->tile_max.p, h->nl16.p, nlocal,   \
-                       h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
+                       h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->nl16.p, \
+                       nlocal, nlocal + h->nghost, h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
     TK(0, 0); TK(0, 1); TK(1, 0); TK(1, 1);
 #undef TK
   } else if(!h->halfneigh) {

@@ -136,6 +136,8 @@ struct mmd_handle {
   bool tiles_ready = false;
   int ntiles = 0, tile_tmax = 0;          // tile_tmax: largest candidate count of any block (LDS sizing)
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max, blk_ncand;
+  DevArr<int> tile_used, tile_cand, tile_ncand, tile_cnt;   // per-tile union of referenced candidates (compact, global indices)
+  int tile_cstride = 0, tile_cmax = 0;
   DevArr<unsigned short> nl16;
   int opt_tiles = 1;
   int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)

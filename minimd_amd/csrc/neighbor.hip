@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
                                                  BinGeom g, int nlocal, real cutneighsq, int maxneighs,
                                                  int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags,
                                                  const int* __restrict__ tile_of_block, unsigned short* __restrict__ nl16,
-                                                 int* __restrict__ blk_ncand)
+                                                 int* __restrict__ blk_ncand, int* __restrict__ tile_used)
 {
   __shared__ int rng_start[128], rng_pref[130];
   __shared__ int cnt[NB_MAXA];
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
   if(lane == 0) rng_pref[nr] = carry;
   __syncthreads();
   const int total = rng_pref[nr];
-  const bool tiles = nl16 != nullptr && total < 65535;       // 16-bit candidate slots (slot `total` = dummy)
-  const int tile0 = tiles ? tile_of_block[b] : 0;
+  const int tile0 = nl16 != nullptr ? tile_of_block[b] : 0;
+  const bool tiles = nl16 != nullptr && tile_of_block[b + 1] > tile0 && total <= NB_CHUNKS * 64 && (a1 - a0) <= NB_MAXA;   // single-pass blocks with owned atoms
   if(lane == 0) {
     if(nl16 != nullptr) blk_ncand[b] = total;
     atomicMax(&flags[1], total);
@@ -247,9 +247,14 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
         }
       }
       const int nchunks = min(NB_CHUNKS, (total - t0 + 63) >> 6);
+      unsigned usedbits = 0;                     // bit c: my candidate of chunk c is a neighbor of some atom of the tile
 
       // ---- owned atoms of the block, one per iteration (wave-uniform)
       for(int a = ab; a < ae; a++) {
+        if(tiles && a > a0 && ((a - a0) & 63) == 0) {        // next tile of the same block: flush the usage bits
+          tile_used[(size_t)(tile0 + ((a - a0) >> 6) - 1) * 64 + lane] = usedbits;
+          usedbits = 0;
+        }
         const int i = __builtin_amdgcn_readfirstlane(binned[a]);
         if(i >= nlocal) continue;                            // ghosts get no row
         const real4 xi = x[i];                               // uniform address: scalar load
@@ -279,12 +284,14 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
                 neigh[rowbase + (size_t)pos * 64] = j;
                 if(tiles) nl16[tilebase + (size_t)pos * 64] = (unsigned short)(t0 + c * 64 + lane);
               }
+              if(keep) usedbits |= 1u << c;
               n += __popcll(m);
             }
           }
         }
         if(lane == 0) cnt[a - ab] = n;
       }
+      if(tiles && ae == a1 && t0 == 0) tile_used[(size_t)(tile0 + ((a1 - 1 - a0) >> 6)) * 64 + lane] = usedbits;
       __syncthreads();
     }
     // ---- row lengths
@@ -313,13 +320,17 @@ __global__ void k_tile_count(const int* __restrict__ binned, const int* __restri
   ntile_of_block[b] = owned ? (a1 - a0 + 63) >> 6 : 0;
 }
 __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, const int* __restrict__ tile_of_block,
-                            int* __restrict__ tile_block, int* __restrict__ tile_first)
+                            int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b >= nblocks) return;
   const int t0 = tile_of_block[b], t1 = tile_of_block[b + 1];
-  const int a0 = bin_start[b * 8];
-  for(int t = t0; t < t1; t++) { tile_block[t] = b; tile_first[t] = a0 + (t - t0) * 64; }
+  const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
+  for(int t = t0; t < t1; t++) {
+    tile_block[t] = b;
+    tile_first[t] = a0 + (t - t0) * 64;
+    tile_cnt[t] = min(64, a1 - tile_first[t]);
+  }
 }
 // pad the tile rows with the dummy candidate slot (= ncand of the block) up to the tile's longest row
 __global__ __launch_bounds__(256) void k_pad_tiles(int ntiles, int nlocal, int maxneighs, const int* __restrict__ tile_block,
@@ -342,6 +353,69 @@ __global__ __launch_bounds__(256) void k_pad_tiles(int ntiles, int nlocal, int m
   const size_t base = ((size_t)t * maxneighs) * 64 + lane;
   for(int k = n; k < m; k++) nl16[base + (size_t)k * 64] = dummy;
   if(lane == 0) tile_max[t] = m;
+}
+
+// compact the candidates a tile actually references (the union of its rows, ~40% of the block's candidate
+// sequence) into tile_cand[] (global atom indices, candidate order) and rewrite the tile's 16-bit slots to
+// index that compact list: the force kernel then stages only ~650 positions per tile and needs no bin tables.
+__global__ __launch_bounds__(64) void k_tile_remap(const int* __restrict__ binned, const int* __restrict__ bin_start, BinGeom g,
+                                                   int maxneighs, int cstride, const int* __restrict__ tile_block,
+                                                   const int* __restrict__ tile_max, const int* __restrict__ tile_used,
+                                                   const int* __restrict__ blk_ncand, int* __restrict__ tile_cand,
+                                                   int* __restrict__ tile_ncand, unsigned short* __restrict__ nl16,
+                                                   int* __restrict__ flags)
+{
+  __shared__ int rng_start[128], rng_pref[130];
+  __shared__ unsigned short remap[NB_CHUNKS * 64 + 64];
+  const int lane = threadIdx.x, tile = blockIdx.x;
+  const int b = tile_block[tile];
+  const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
+  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
+  const int nr = min(ny * nz, 128);
+  int carry = 0;
+  for(int r0 = 0; r0 < nr; r0 += 64) {
+    const int r = r0 + lane;
+    int len = 0, start = 0;
+    if(r < nr) {
+      const int z = bz + r / ny - g.reach[2], y = by + r % ny - g.reach[1];
+      if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
+        const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
+        const int row = (z * g.nblk[1] + y) * g.nblk[0];
+        start = bin_start[(row + x0) * 8];
+        len = bin_start[(row + x1) * 8 + 8] - start;
+      }
+    }
+    const int incl = wave_incl_scan(len);
+    if(r < nr) { rng_start[r] = start; rng_pref[r] = carry + incl - len; }
+    carry += __shfl(incl, 63, 64);
+  }
+  if(lane == 0) rng_pref[nr] = carry;
+  __syncthreads();
+  const int total = rng_pref[nr];                 // == blk_ncand[b]
+  const unsigned ub = (unsigned)tile_used[(size_t)tile * 64 + lane];
+  const int nch = (total + 63) >> 6;
+  int base = 0, rr = 0;
+  for(int c = 0; c < nch; c++) {
+    const bool bit = (ub >> c) & 1u;
+    const unsigned long long m = __ballot(bit);
+    const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    const int t = c * 64 + lane;
+    if(bit) {
+      while(rr + 1 < nr && rng_pref[rr + 1] <= t) rr++;
+      tile_cand[(size_t)tile * cstride + pos] = binned[rng_start[rr] + (t - rng_pref[rr])];
+      remap[t] = (unsigned short)pos;
+    }
+    base += __popcll(m);
+  }
+  if(lane == 0) { tile_ncand[tile] = base; atomicMax(&flags[2], base); }
+  __syncthreads();
+  const int kmax = tile_max[tile];
+  const unsigned short dummy_raw = (unsigned short)blk_ncand[b];
+  unsigned short* row = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  for(int k = 0; k < kmax; k++) {
+    const unsigned short v = row[(size_t)k * 64];
+    row[(size_t)k * 64] = v == dummy_raw ? (unsigned short)base : remap[v];
+  }
 }
 
 // pad every row with the dummy atom up to its wavefront's longest row (rounded up to the unroll factor)
@@ -392,7 +466,13 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     MMD_TRY(h->tile_block.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_first.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_max.ensure((size_t)nt + 2, false, h->stream));
-    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p);
+    MMD_TRY(h->tile_ncand.ensure((size_t)nt + 2, false, h->stream));
+    MMD_TRY(h->tile_cnt.ensure((size_t)nt + 2, false, h->stream));
+    MMD_TRY(h->tile_used.ensure((size_t)nt * 64 + 64, false, h->stream));
+    h->tile_cstride = NB_CHUNKS * 64;
+    MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
+    HIP_TRY(hipMemsetAsync(h->tile_used.p, 0, ((size_t)nt * 64 + 64) * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p);
     HIP_TRY(hipGetLastError());
   }
   for(int attempt = 0; attempt < 8; attempt++) {
@@ -403,7 +483,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #define LAUNCH_BUILD(M)                                                                                              \
   hipLaunchKernelGGL(k_build<M>, dim3(nblocks), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,        \
                      h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags,       \
-                     h->tile_of_block.p, want_tiles ? h->nl16.p : (unsigned short*)nullptr, h->blk_ncand.p)
+                     h->tile_of_block.p, want_tiles ? h->nl16.p : (unsigned short*)nullptr, h->blk_ncand.p, h->tile_used.p)
     if(nlocal) {
       if(mode == 0) LAUNCH_BUILD(0);
       else if(mode == 1) LAUNCH_BUILD(1);
@@ -430,7 +510,16 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       hipLaunchKernelGGL(k_pad_tiles, dim3(div_up((long long)h->ntiles * 64, 256)), dim3(256), 0, h->stream, h->ntiles, nlocal, h->maxneighs,
                          h->tile_block.p, h->tile_first.p, h->bin_start.p, h->binned.p, h->numneigh.p, h->blk_ncand.p, h->nl16.p, h->tile_max.p);
       h->tile_tmax = h->h_flags[1];
-      h->tiles_ready = h->tile_tmax < 65535;
+      // the tile form needs every owned block to be single-pass in k_build (<= NB_CHUNKS*64 candidates)
+      h->tiles_ready = h->tile_tmax <= NB_CHUNKS * 64 && (2 * g.reach[1] + 1) * (2 * g.reach[2] + 1) <= 128;
+      if(h->tiles_ready) {
+        hipLaunchKernelGGL(k_tile_remap, dim3(h->ntiles), dim3(64), 0, h->stream, h->binned.p, h->bin_start.p, g, h->maxneighs, h->tile_cstride,
+                           h->tile_block.p, h->tile_max.p, h->tile_used.p, h->blk_ncand.p, h->tile_cand.p, h->tile_ncand.p, h->nl16.p, h->d_flags);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->tile_cmax = h->h_flags[2];
+      }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
