@@ -92,6 +92,8 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "time_force_events")) h->time_force_events = value != 0;
   else if(!strcmp(name, "tiles")) h->opt_tiles = value;
   else if(!strcmp(name, "ablate")) h->opt_ablate = value;
+  else if(!strcmp(name, "tile_waves")) h->opt_tile_waves = value;
+  else if(!strcmp(name, "tile_unroll")) h->opt_tile_unroll = value;
   else if(!strcmp(name, "maxneighs")) h->maxneighs = (value + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
   else { mmd_set_error("mmd_set_option: unknown option '%s'", name); return -1; }
   return 0;

@@ -15,6 +15,7 @@
 #include "mmd_internal.hpp"
 
 #define EAM_MAX_KNOTS 1024
+#define EAM_UNR 4
 
 // ---- sweep 1 --------------------------------------------------------------------------------------
 template <int EV, int UNIFORM>
@@ -42,15 +43,15 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_density(const real4* __restri
   const int* __restrict__ np = neigh + ((size_t)w * maxneighs) * 64 + lane;
   const real cut0 = cutforcesq[0];
   real rhoi = 0;
-  for(int k = 0; k < kmax; k += MMD_UNROLL) {
-    int j[MMD_UNROLL];
-    real4 xj[MMD_UNROLL];
+  for(int k = 0; k < kmax; k += EAM_UNR) {
+    int j[EAM_UNR];
+    real4 xj[EAM_UNR];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) j[u] = np[(size_t)(k + u) * 64];
+    for(int u = 0; u < EAM_UNR; u++) j[u] = np[(size_t)(k + u) * 64];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) xj[u] = x[j[u]];
+    for(int u = 0; u < EAM_UNR; u++) xj[u] = x[j[u]];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) {
+    for(int u = 0; u < EAM_UNR; u++) {
       const real dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
       const real rsq = dx * dx + dy * dy + dz * dz;
       const int tij = UNIFORM ? 0 : ti * ntypes + (int)xj[u].w;
@@ -116,16 +117,16 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_force(const real4* __restrict
   const real cut0 = cutforcesq[0];
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
-  for(int k = 0; k < kmax; k += MMD_UNROLL) {
-    int j[MMD_UNROLL];
-    real4 xj[MMD_UNROLL];
-    real fpj[MMD_UNROLL];
+  for(int k = 0; k < kmax; k += EAM_UNR) {
+    int j[EAM_UNR];
+    real4 xj[EAM_UNR];
+    real fpj[EAM_UNR];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) j[u] = np[(size_t)(k + u) * 64];
+    for(int u = 0; u < EAM_UNR; u++) j[u] = np[(size_t)(k + u) * 64];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) { xj[u] = x[j[u]]; fpj[u] = fp[j[u]]; }
+    for(int u = 0; u < EAM_UNR; u++) { xj[u] = x[j[u]]; fpj[u] = fp[j[u]]; }
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) {
+    for(int u = 0; u < EAM_UNR; u++) {
       const real dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
       const real rsq = dx * dx + dy * dy + dz * dz;
       const int tij = UNIFORM ? 0 : ti * ntypes + (int)xj[u].w;

@@ -23,6 +23,21 @@ __device__ __forceinline__ double recip(double a)
   r = __builtin_fma(e, r, r);
   return r;
 }
+// one Newton step + the residual folded in:  r1 = r0 + r0*e, e = 1 - a*r0;  second-order term r0*e*e added
+// by a single extra fma => same accuracy class as two full steps with one multiply-add less
+__device__ __forceinline__ double recip_fast(double a)
+{
+  const double r = __builtin_amdgcn_rcp(a);
+  const double e = __builtin_fma(-a, r, 1.0);
+  const double t = __builtin_fma(e, e, e);       // e + e^2
+  return __builtin_fma(r, t, r);                 // r (1 + e + e^2)
+}
+__device__ __forceinline__ float recip_fast(float a)
+{
+  const float r = __builtin_amdgcn_rcpf(a);
+  const float e = __builtin_fmaf(-a, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
 template <bool EXACT>
 __device__ __forceinline__ float recip(float a)
 {
@@ -40,6 +55,7 @@ struct LJTables {       // general (non-uniform) case: per type-pair tables stag
 };
 
 #define LJ_MAX_TYPES2 64
+#define LJ_UNR 4                 // unroll of the global-gather kernels (rows are padded to MMD_UNROLL >= this)
 
 // ---- full neighbor list: compute_fullneigh<EVFLAG> (ref/force_lj.cpp:366-449) -------------------------
 template <int EV, int UNIFORM, bool EXACT>
@@ -68,14 +84,14 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
   double e_acc = 0, v_acc = 0;
   const real c48 = (real)48.0 * P.epsilon;
 
-  for(int k = 0; k < kmax; k += MMD_UNROLL) {
-    int j[MMD_UNROLL];
-    real4 xj[MMD_UNROLL];
+  for(int k = 0; k < kmax; k += LJ_UNR) {
+    int j[LJ_UNR];
+    real4 xj[LJ_UNR];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) j[u] = np[(size_t)(k + u) * 64];
+    for(int u = 0; u < LJ_UNR; u++) j[u] = np[(size_t)(k + u) * 64];
     if(ablate) {                               // profiling only (results invalid)
 #pragma unroll
-      for(int u = 0; u < MMD_UNROLL; u++) {
+      for(int u = 0; u < LJ_UNR; u++) {
         if(ablate & 4) j[u] = __builtin_amdgcn_readfirstlane(j[u]);                   // 1 line per gather
         if(ablate & 8) j[u] = __builtin_amdgcn_readfirstlane(j[u]) + (lane >> 2);     // 16 lines, 4 lanes each
         if(ablate & 16) j[u] = __builtin_amdgcn_readfirstlane(j[u]) + lane;           // 16 lines contiguous (2 KB)
@@ -83,9 +99,9 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
       }
     }
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) xj[u] = x[j[u]];
+    for(int u = 0; u < LJ_UNR; u++) xj[u] = x[j[u]];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) {
+    for(int u = 0; u < LJ_UNR; u++) {
       const real dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
       const real rsq = dx * dx + dy * dy + dz * dz;
       real cut, s6, c48e, eps;
@@ -119,12 +135,10 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
 // handles the neighbor-row slice k in [w*kmax/W, (w+1)*kmax/W) of the same 64 atoms, partial forces are
 // combined through LDS. The candidate sequence is rebuilt exactly like k_build's (same bin_start/binned
 // arrays, valid until the next re-neighboring) so the 16-bit slots of nl16 index straight into LDS.
-#define LJ_TILE_WAVES 4
-#define LJ_TILE_THREADS (64 * LJ_TILE_WAVES)
 #define LJ_STAGE 8            // candidates staged per thread and batch (independent load pairs in flight)
 
-template <int EV, bool EXACT>
-__global__ __launch_bounds__(LJ_TILE_THREADS) void k_lj_full_tile(
+template <int EV, bool EXACT, int LJ_TILE_WAVES, int UNR>
+__global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, LJParams P, real* __restrict__ f,
@@ -133,13 +147,13 @@ __global__ __launch_bounds__(LJ_TILE_THREADS) void k_lj_full_tile(
   extern __shared__ __align__(16) unsigned char s_raw[];
   __shared__ real s_f[3 * 64 * (LJ_TILE_WAVES - 1) + 3];
   __shared__ double s_red[16];
+  constexpr int LJ_TILE_THREADS = 64 * LJ_TILE_WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.x;
   const int ncand = tile_ncand[tile];
-  // ---- stage the positions of the tile's candidate union (+1 dummy slot) into LDS, SoA
-  real* sx = (real*)s_raw;                       // 8-byte (4-byte SP) gathers spread over all banks
-  real* sy = sx + (ncand + 1);
-  real* sz = sy + (ncand + 1);
+  // ---- stage the positions of the tile's candidate union (+1 dummy slot) into LDS: {x,y,z} records of
+  // 3 reals (stride 3 is coprime with the bank count: random slots spread over all banks, one address per pair)
+  real* sp = (real*)s_raw;
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
   for(int tb = tid; tb <= ncand && !(ablate & 1); tb += LJ_STAGE * LJ_TILE_THREADS) {
     int jj[LJ_STAGE];
@@ -154,53 +168,59 @@ __global__ __launch_bounds__(LJ_TILE_THREADS) void k_lj_full_tile(
 #pragma unroll
     for(int u = 0; u < LJ_STAGE; u++) {
       const int t = tb + u * LJ_TILE_THREADS;
-      if(t <= ncand) { sx[t] = pp[u].x; sy[t] = pp[u].y; sz[t] = pp[u].z; }
+      if(t <= ncand) { sp[3 * t] = pp[u].x; sp[3 * t + 1] = pp[u].y; sp[3 * t + 2] = pp[u].z; }
     }
   }
   // ---- my atom and my slice of its neighbor row (wave w takes k in [k0,k1))
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;     // a tile never straddles blocks
   const int kmax = (ablate & 2) ? 0 : tile_max[tile];
-  const int per = ((kmax / MMD_UNROLL + LJ_TILE_WAVES - 1) / LJ_TILE_WAVES) * MMD_UNROLL;
+  const int per = ((kmax / UNR + LJ_TILE_WAVES - 1) / LJ_TILE_WAVES) * UNR;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
-  int s_nxt[MMD_UNROLL];
+  int s_nxt[UNR];
 #pragma unroll
-  for(int u = 0; u < MMD_UNROLL; u++) s_nxt[u] = k0 < k1 ? np[(size_t)(k0 + u) * 64] : 0;
+  for(int u = 0; u < UNR; u++) s_nxt[u] = k0 < k1 ? np[(size_t)(k0 + u) * 64] : 0;
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   __syncthreads();
 
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
-  const real c48 = (real)48.0 * P.epsilon;
-  for(int k = k0; k < k1; k += MMD_UNROLL) {
-    int s[MMD_UNROLL];
+  // force = 48 eps sr6 (sr6 - 1/2) sr2 with sr6 = s6 A, A = sr2^3  ==  [48 eps s6] * (A sr2) * (s6 A - 1/2):
+  // the bracket is uniform and applied once after the loop
+  const real c_out = (real)48.0 * P.epsilon * P.sigma6;
+  for(int k = k0; k < k1; k += UNR) {
+    int s[UNR];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) s[u] = s_nxt[u];
-    if(k + MMD_UNROLL < k1) {                    // prefetch the next slots under this trip's arithmetic
+    for(int u = 0; u < UNR; u++) s[u] = s_nxt[u];
+    if(k + UNR < k1) {                    // prefetch the next slots under this trip's arithmetic
 #pragma unroll
-      for(int u = 0; u < MMD_UNROLL; u++) s_nxt[u] = np[(size_t)(k + MMD_UNROLL + u) * 64];
+      for(int u = 0; u < UNR; u++) s_nxt[u] = np[(size_t)(k + UNR + u) * 64];
     }
-    real xj[MMD_UNROLL], yj[MMD_UNROLL], zj[MMD_UNROLL];
+    real xj[UNR], yj[UNR], zj[UNR];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) { xj[u] = sx[s[u]]; yj[u] = sy[s[u]]; zj[u] = sz[s[u]]; }
+    for(int u = 0; u < UNR; u++) { const real* q = sp + 3 * s[u]; xj[u] = q[0]; yj[u] = q[1]; zj[u] = q[2]; }
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) {
+    for(int u = 0; u < UNR; u++) {
       const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
       const real rsq = dx * dx + dy * dy + dz * dz;
-      const real sr2 = recip<EXACT>(rsq);
-      const real sr6 = sr2 * sr2 * sr2 * P.sigma6;
-      real force = c48 * sr6 * (sr6 - (real)0.5) * sr2;
+      const real sr2 = EXACT ? recip<true>(rsq) : recip_fast(rsq);
+      const real A = sr2 * sr2 * sr2;
+      const real t = A * P.sigma6 - (real)0.5;
+      real fs = (A * sr2) * t;                     // force / c_out
       const bool in = rsq < P.cutforcesq;
-      force = in ? force : (real)0;
-      fx += dx * force; fy += dy * force; fz += dz * force;
+      fs = in ? fs : (real)0;
+      fx += dx * fs; fy += dy * fs; fz += dz * fs;
       if(EV) {
+        const real sr6 = A * P.sigma6;
         const real en = in ? sr6 * (sr6 - (real)1.0) * P.epsilon : (real)0;
         e_acc += (double)en;
-        v_acc += (double)(rsq * force);
+        v_acc += (double)(rsq * fs);
       }
     }
   }
+  fx *= c_out; fy *= c_out; fz *= c_out;
+  v_acc *= (double)c_out;
   // combine the wave slices
   if(wv > 0) { real* d = s_f + 3 * 64 * (wv - 1); d[lane] = fx; d[64 + lane] = fy; d[128 + lane] = fz; }
   __syncthreads();
@@ -243,15 +263,15 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_half(const real4* __restrict__
 
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
-  for(int k = 0; k < kmax; k += MMD_UNROLL) {
-    int j[MMD_UNROLL];
-    real4 xj[MMD_UNROLL];
+  for(int k = 0; k < kmax; k += LJ_UNR) {
+    int j[LJ_UNR];
+    real4 xj[LJ_UNR];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) j[u] = np[(size_t)(k + u) * 64];
+    for(int u = 0; u < LJ_UNR; u++) j[u] = np[(size_t)(k + u) * 64];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) xj[u] = x[j[u]];
+    for(int u = 0; u < LJ_UNR; u++) xj[u] = x[j[u]];
 #pragma unroll
-    for(int u = 0; u < MMD_UNROLL; u++) {
+    for(int u = 0; u < LJ_UNR; u++) {
       const real dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
       const real rsq = dx * dx + dy * dy + dz * dz;
       real cut, s6, eps;
@@ -355,15 +375,19 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   const int ev = evflag ? 1 : 0, uni = h->lj_uniform ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
   int nsum = nblocks;
-  const size_t tile_lds = (size_t)3 * (h->tile_cmax + 1) * sizeof(real);
+  const size_t tile_lds = (size_t)3 * (h->tile_cmax + 2) * sizeof(real);
   if(!h->halfneigh && h->tiles_ready && h->opt_tiles && uni && tile_lds <= 60 * 1024) {
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
-#define TK(EVv, Xv) if(ev == EVv && ex == Xv)                                                                                \
-    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0)>), dim3(h->ntiles), dim3(LJ_TILE_THREADS), tile_lds, h->stream, h->x.p,  \
-                       h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->nl16.p, \
-                       nlocal, nlocal + h->nghost, h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
-    TK(0, 0); TK(0, 1); TK(1, 0); TK(1, 1);
+#define TK(EVv, Xv, Wv, Uv) if(ev == EVv && ex == Xv && tw == Wv && tu == Uv)                                                    \
+    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv>), dim3(h->ntiles), dim3(64 * Wv), tile_lds, h->stream, h->x.p,        \
+                       h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
+                       h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
+    const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll;
+    TK(0, 0, 4, 4); TK(0, 1, 4, 4); TK(1, 0, 4, 4); TK(1, 1, 4, 4);
+    TK(0, 0, 2, 4); TK(1, 0, 2, 4); TK(0, 0, 1, 4); TK(1, 0, 1, 4);
+    TK(0, 0, 4, 8); TK(1, 0, 4, 8); TK(0, 0, 2, 8); TK(1, 0, 2, 8);
+    TK(0, 0, 4, 2); TK(1, 0, 4, 2);
 #undef TK
   } else if(!h->halfneigh) {
 #define F(EVv, Uv, Xv) if(ev == EVv && uni == Uv && ex == Xv) launch_full<EVv, Uv, (Xv != 0)>(h, nblocks, T)

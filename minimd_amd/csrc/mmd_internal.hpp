@@ -33,7 +33,7 @@ typedef double4 real4;
 #endif
 
 #define MMD_WAVE 64
-#define MMD_UNROLL 4            // neighbor rows are padded to a multiple of this
+#define MMD_UNROLL 8            // neighbor rows are padded to a multiple of this (>= every kernel's unroll factor)
 #define MMD_BLOCK 256
 
 void mmd_set_error(const char* fmt, ...);
@@ -140,6 +140,7 @@ struct mmd_handle {
   int tile_cstride = 0, tile_cmax = 0;
   DevArr<unsigned short> nl16;
   int opt_tiles = 1;
+  int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
   int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)
   // ---- Force
   int style = 0;             // 0 LJ, 1 EAM

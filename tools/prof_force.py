@@ -35,6 +35,13 @@ if a.ab:
         for v in (1, 0):
             h.set_option(a.ab, v)
             print("round %d  %s=%d  force %.4f ms" % (rnd, a.ab, v, h.profile_kernel(0, a.reps)))
+if os.environ.get("SHAPES"):
+    h.set_option("tiles", 1)
+    for rnd in range(2):
+        for w, u in ((4, 4), (2, 4), (1, 4), (4, 8), (2, 8), (4, 2)):
+            h.set_option("tile_waves", w); h.set_option("tile_unroll", u)
+            print("round %d waves=%d unroll=%d  tile force %.4f ms" % (rnd, w, u, h.profile_kernel(0, a.reps)))
+    h.set_option("tile_waves", 2); h.set_option("tile_unroll", 8)
 if os.environ.get("ABLATE"):
     h.set_option("tiles", 1)
     for ab in (0, 1, 2, 3):
