@@ -248,6 +248,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   if(h->halfneigh) { mmd_set_error("EAM with half neighbor lists is not implemented on the device yet (use --half_neigh 0)"); return -1; }
   const int nlocal = h->nlocal, nall = nlocal + h->nghost;
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
+  MMD_TRY(mmd_ensure_rows(h));
   const int nblocks = div_up(nlocal, MMD_BLOCK);
   MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
   MMD_TRY(h->partials.ensure((size_t)3 * nblocks + 8, false, h->stream));

@@ -390,10 +390,13 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     TK(0, 0, 4, 2); TK(1, 0, 4, 2);
 #undef TK
   } else if(!h->halfneigh) {
+    MMD_TRY(mmd_ensure_rows(h));
+    MMD_TRY(h->partials.ensure((size_t)2 * nblocks + 8, false, h->stream));
 #define F(EVv, Uv, Xv) if(ev == EVv && uni == Uv && ex == Xv) launch_full<EVv, Uv, (Xv != 0)>(h, nblocks, T)
     F(0, 0, 0); F(0, 0, 1); F(0, 1, 0); F(0, 1, 1); F(1, 0, 0); F(1, 0, 1); F(1, 1, 0); F(1, 1, 1);
 #undef F
   } else {
+    MMD_TRY(mmd_ensure_rows(h));
     MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));     // ref/force_lj.cpp:286-291
     const int gn = h->ghost_newton ? 1 : 0;
 #define H(EVv, Gv, Uv, Xv) if(ev == EVv && gn == Gv && uni == Uv && ex == Xv) launch_half<EVv, Gv, Uv, (Xv != 0)>(h, nblocks, T)

@@ -134,9 +134,10 @@ struct mmd_handle {
   // entries of binned[] inside one block; nl16[(tile*maxneighs + k)*64 + lane] = slot of the neighbor in
   // the block's candidate sequence (the order in which k_build walks the surrounding blocks)
   bool tiles_ready = false;
+  bool rows_ready = false;               // the wave-interleaved 32-bit rows (`neigh`, wave_max) are materialised
   int ntiles = 0, tile_tmax = 0;          // tile_tmax: largest candidate count of any block (LDS sizing)
-  DevArr<int> tile_of_block, tile_block, tile_first, tile_max, blk_ncand;
-  DevArr<int> tile_used, tile_cand, tile_ncand, tile_cnt;   // per-tile union of referenced candidates (compact, global indices)
+  DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
+  DevArr<int> tile_cand, tile_ncand, tile_cnt;   // per-tile union of referenced candidates (compact, global indices)
   int tile_cstride = 0, tile_cmax = 0;
   DevArr<unsigned short> nl16;
   int opt_tiles = 1;
@@ -193,6 +194,7 @@ int mmd_bin_atoms(mmd_handle* h, int count);
 int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_zero_forces(mmd_handle* h, int n);
+int mmd_ensure_rows(mmd_handle* h);       // materialise `neigh` from the tile form when a kernel needs it
 int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int dest, void* drecv, size_t nrecv, int src);
 int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv, int src);
 int mmd_transport_allreduce(mmd_handle* h, double* vals, int n);

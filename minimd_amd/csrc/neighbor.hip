@@ -170,9 +170,7 @@ template <int MODE>
 __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, const int* __restrict__ binned,
                                                  const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
                                                  BinGeom g, int nlocal, real cutneighsq, int maxneighs,
-                                                 int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags,
-                                                 const int* __restrict__ tile_of_block, unsigned short* __restrict__ nl16,
-                                                 int* __restrict__ blk_ncand, int* __restrict__ tile_used)
+                                                 int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags)
 {
   __shared__ int rng_start[128], rng_pref[130];
   __shared__ int cnt[NB_MAXA];
@@ -206,12 +204,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
   if(lane == 0) rng_pref[nr] = carry;
   __syncthreads();
   const int total = rng_pref[nr];
-  const int tile0 = nl16 != nullptr ? tile_of_block[b] : 0;
-  const bool tiles = nl16 != nullptr && tile_of_block[b + 1] > tile0 && total <= NB_CHUNKS * 64 && (a1 - a0) <= NB_MAXA;   // single-pass blocks with owned atoms
-  if(lane == 0) {
-    if(nl16 != nullptr) blk_ncand[b] = total;
-    atomicMax(&flags[1], total);
-  }
+  if(lane == 0) atomicMax(&flags[1], total);
 
   for(int ab = a0; ab < a1; ab += NB_MAXA) {                // (one pass unless a block holds > NB_MAXA atoms)
     const int ae = min(ab + NB_MAXA, a1);
@@ -247,21 +240,15 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
         }
       }
       const int nchunks = min(NB_CHUNKS, (total - t0 + 63) >> 6);
-      unsigned usedbits = 0;                     // bit c: my candidate of chunk c is a neighbor of some atom of the tile
 
       // ---- owned atoms of the block, one per iteration (wave-uniform)
       for(int a = ab; a < ae; a++) {
-        if(tiles && a > a0 && ((a - a0) & 63) == 0) {        // next tile of the same block: flush the usage bits
-          tile_used[(size_t)(tile0 + ((a - a0) >> 6) - 1) * 64 + lane] = usedbits;
-          usedbits = 0;
-        }
         const int i = __builtin_amdgcn_readfirstlane(binned[a]);
         if(i >= nlocal) continue;                            // ghosts get no row
         const real4 xi = x[i];                               // uniform address: scalar load
         const real xix = xi.x, xiy = xi.y, xiz = xi.z;
         int n = cnt[a - ab];
         const size_t rowbase = ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63);
-        const size_t tilebase = ((size_t)(tile0 + ((a - a0) >> 6)) * maxneighs) * 64 + ((a - a0) & 63);
 #pragma unroll
         for(int c = 0; c < NB_CHUNKS; c++) {
           if(c < nchunks) {
@@ -280,18 +267,13 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
             const unsigned long long m = __ballot(keep);
             if(m) {
               const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-              if(keep && pos < maxneighs) {
-                neigh[rowbase + (size_t)pos * 64] = j;
-                if(tiles) nl16[tilebase + (size_t)pos * 64] = (unsigned short)(t0 + c * 64 + lane);
-              }
-              if(keep) usedbits |= 1u << c;
+              if(keep && pos < maxneighs) neigh[rowbase + (size_t)pos * 64] = j;
               n += __popcll(m);
             }
           }
         }
         if(lane == 0) cnt[a - ab] = n;
       }
-      if(tiles && ae == a1 && t0 == 0) tile_used[(size_t)(tile0 + ((a1 - 1 - a0) >> 6)) * 64 + lane] = usedbits;
       __syncthreads();
     }
     // ---- row lengths
@@ -332,43 +314,33 @@ __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, cons
     tile_cnt[t] = min(64, a1 - tile_first[t]);
   }
 }
-// pad the tile rows with the dummy candidate slot (= ncand of the block) up to the tile's longest row
-__global__ __launch_bounds__(256) void k_pad_tiles(int ntiles, int nlocal, int maxneighs, const int* __restrict__ tile_block,
-                                                   const int* __restrict__ tile_first, const int* __restrict__ bin_start,
-                                                   const int* __restrict__ binned, const int* __restrict__ numneigh,
-                                                   const int* __restrict__ blk_ncand, unsigned short* __restrict__ nl16,
-                                                   int* __restrict__ tile_max)
+// ---------------------------------------------------------------------------------------------------
+// Fused tile build (full lists): same register-transposed test as k_build, but
+//   * hits go to an LDS row buffer rows[k][lane-of-atom] as raw candidate slots (ds_write_b16, no global
+//     scatter: the scattered 4-byte stores of k_build were TA-bound, ~2 store instructions per 64 tests);
+//   * at the end of a tile the union of referenced candidates is compacted (ballot/mbcnt), written to
+//     tile_cand[] as global atom indices, and the rows are rewritten through an LDS remap table;
+//   * rows leave the CU as coalesced 128-byte lines, already padded with the dummy slot (= ncand).
+// The 32-bit reference-style rows are NOT produced here; mmd_ensure_rows() derives them on demand.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__ x, const int* __restrict__ binned,
+                                                       const int* __restrict__ bin_start, BinGeom g, int nlocal, real cutneighsq,
+                                                       int maxneighs, int cstride, const int* __restrict__ tile_of_block,
+                                                       int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
+                                                       int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
+                                                       int* __restrict__ tile_max, int* __restrict__ flags,
+                                                       unsigned long long* __restrict__ total_out)
 {
-  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if(t >= ntiles) return;
-  const int b = tile_block[t];
-  const int a = tile_first[t] + lane, a1 = bin_start[b * 8 + 8];
-  int n = 0;
-  if(a < a1) { const int i = binned[a]; if(i < nlocal) n = numneigh[i]; }
-  int m = wave_max_i(n);
-  m = (m + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
-  if(m > maxneighs) m = maxneighs;
-  const unsigned short dummy = (unsigned short)blk_ncand[b];
-  const size_t base = ((size_t)t * maxneighs) * 64 + lane;
-  for(int k = n; k < m; k++) nl16[base + (size_t)k * 64] = dummy;
-  if(lane == 0) tile_max[t] = m;
-}
-
-// compact the candidates a tile actually references (the union of its rows, ~40% of the block's candidate
-// sequence) into tile_cand[] (global atom indices, candidate order) and rewrite the tile's 16-bit slots to
-// index that compact list: the force kernel then stages only ~650 positions per tile and needs no bin tables.
-__global__ __launch_bounds__(64) void k_tile_remap(const int* __restrict__ binned, const int* __restrict__ bin_start, BinGeom g,
-                                                   int maxneighs, int cstride, const int* __restrict__ tile_block,
-                                                   const int* __restrict__ tile_max, const int* __restrict__ tile_used,
-                                                   const int* __restrict__ blk_ncand, int* __restrict__ tile_cand,
-                                                   int* __restrict__ tile_ncand, unsigned short* __restrict__ nl16,
-                                                   int* __restrict__ flags)
-{
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  unsigned short* rows = (unsigned short*)s_dyn;              // [maxneighs][64]
   __shared__ int rng_start[128], rng_pref[130];
-  __shared__ unsigned short remap[NB_CHUNKS * 64 + 64];
-  const int lane = threadIdx.x, tile = blockIdx.x;
-  const int b = tile_block[tile];
+  __shared__ unsigned short remap[NB_CHUNKS * 64];
+  __shared__ int cnt[64];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int tile0 = tile_of_block[b], ntile_b = tile_of_block[b + 1] - tile0;
+  if(ntile_b == 0) return;                                    // no owned atom in this block (uniform exit)
+  const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
   const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
   const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
   const int nr = min(ny * nz, 128);
@@ -391,31 +363,113 @@ __global__ __launch_bounds__(64) void k_tile_remap(const int* __restrict__ binne
   }
   if(lane == 0) rng_pref[nr] = carry;
   __syncthreads();
-  const int total = rng_pref[nr];                 // == blk_ncand[b]
-  const unsigned ub = (unsigned)tile_used[(size_t)tile * 64 + lane];
-  const int nch = (total + 63) >> 6;
-  int base = 0, rr = 0;
-  for(int c = 0; c < nch; c++) {
-    const bool bit = (ub >> c) & 1u;
-    const unsigned long long m = __ballot(bit);
-    const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-    const int t = c * 64 + lane;
-    if(bit) {
-      while(rr + 1 < nr && rng_pref[rr + 1] <= t) rr++;
-      tile_cand[(size_t)tile * cstride + pos] = binned[rng_start[rr] + (t - rng_pref[rr])];
-      remap[t] = (unsigned short)pos;
+  const int total = rng_pref[nr];
+  if(total > NB_CHUNKS * 64) {                                // cannot hold the candidates in one register pass
+    if(lane == 0) atomicMax(&flags[3], 1);                    // host falls back to k_build + global rows
+    return;
+  }
+  // ---- transpose-load the candidates into registers
+  real cx[NB_CHUNKS], cy[NB_CHUNKS], cz[NB_CHUNKS];
+  int cj[NB_CHUNKS];
+  {
+    int r = 0;
+#pragma unroll
+    for(int c = 0; c < NB_CHUNKS; c++) {
+      const int gt = c * 64 + lane;
+      cx[c] = (real)1.0e15; cy[c] = (real)1.0e15; cz[c] = (real)1.0e15; cj[c] = -1;
+      if(gt < total) {
+        while(r + 1 < nr && rng_pref[r + 1] <= gt) r++;
+        const int j = binned[rng_start[r] + (gt - rng_pref[r])];
+        const real4 p = x[j];
+        cx[c] = p.x; cy[c] = p.y; cz[c] = p.z; cj[c] = j;
+      }
     }
-    base += __popcll(m);
   }
-  if(lane == 0) { tile_ncand[tile] = base; atomicMax(&flags[2], base); }
-  __syncthreads();
-  const int kmax = tile_max[tile];
-  const unsigned short dummy_raw = (unsigned short)blk_ncand[b];
-  unsigned short* row = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
-  for(int k = 0; k < kmax; k++) {
-    const unsigned short v = row[(size_t)k * 64];
-    row[(size_t)k * 64] = v == dummy_raw ? (unsigned short)base : remap[v];
+  const int nchunks = (total + 63) >> 6;
+
+  for(int tl = 0; tl < ntile_b; tl++) {
+    const int tile = tile0 + tl;
+    const int ta = a0 + tl * 64, te = min(ta + 64, a1);
+    unsigned usedbits = 0;
+    if(lane < 64) cnt[lane] = 0;
+    __syncthreads();
+    for(int a = ta; a < te; a++) {
+      const int i = __builtin_amdgcn_readfirstlane(binned[a]);
+      if(i >= nlocal) continue;                               // ghosts get no row
+      const real4 xi = x[i];                                  // uniform address: scalar load
+      const real xix = xi.x, xiy = xi.y, xiz = xi.z;
+      const int al = a - ta;
+      int n = 0;
+#pragma unroll
+      for(int c = 0; c < NB_CHUNKS; c++) {
+        if(c < nchunks) {
+          const real dx = xix - cx[c], dy = xiy - cy[c], dz = xiz - cz[c];
+          const real rsq = dx * dx + dy * dy + dz * dz;
+          const bool keep = rsq <= cutneighsq && cj[c] != i;
+          const unsigned long long m = __ballot(keep);
+          if(m) {
+            const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if(keep) {
+              if(pos < maxneighs) rows[pos * 64 + al] = (unsigned short)(c * 64 + lane);
+              usedbits |= 1u << c;
+            }
+            n += __popcll(m);
+          }
+        }
+      }
+      if(lane == 0) { cnt[al] = n; numneigh[i] = n; }
+    }
+    __syncthreads();
+    // ---- union of the candidates referenced by this tile -> compact list + remap table
+    int base = 0;
+#pragma unroll
+    for(int c = 0; c < NB_CHUNKS; c++) {
+      if(c < nchunks) {
+        const bool bit = (usedbits >> c) & 1u;
+        const unsigned long long m = __ballot(bit);
+        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if(bit) {
+          tile_cand[(size_t)tile * cstride + pos] = cj[c];
+          remap[c * 64 + lane] = (unsigned short)pos;
+        }
+        base += __popcll(m);
+      }
+    }
+    __syncthreads();
+    // ---- coalesced write-out of the padded, remapped rows
+    const int myn = cnt[lane];
+    const int maxn = wave_max_i(myn);
+    int kmax = (maxn + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
+    if(kmax > maxneighs) kmax = maxneighs;
+    const int lim = min(myn, maxneighs);
+    unsigned short* out = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+    for(int k = 0; k < kmax; k++) out[(size_t)k * 64] = k < lim ? remap[rows[k * 64 + lane]] : (unsigned short)base;
+    const long long tsum = wave_sum((long long)myn);
+    if(lane == 0) {
+      tile_max[tile] = kmax;
+      tile_ncand[tile] = base;
+      atomicMax(&flags[0], maxn);
+      atomicMax(&flags[2], base);
+      atomicAdd(total_out, (unsigned long long)tsum);
+    }
+    __syncthreads();
   }
+}
+
+// reference-style rows from the tile form: neigh[((i>>6)*maxneighs + k)*64 + (i&63)] = tile_cand[slot]
+__global__ __launch_bounds__(64) void k_tiles_to_rows(int nlocal, int maxneighs, int cstride, const int* __restrict__ binned,
+                                                      const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
+                                                      const int* __restrict__ tile_cand, const unsigned short* __restrict__ nl16,
+                                                      const int* __restrict__ numneigh, int* __restrict__ neigh)
+{
+  const int tile = blockIdx.x, lane = threadIdx.x;
+  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
+  if(i >= nlocal) i = -1;
+  const int n = i >= 0 ? min(numneigh[i], maxneighs) : 0;
+  const unsigned short* in = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  const int* cl = tile_cand + (size_t)tile * cstride;
+  const size_t rowbase = i >= 0 ? ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63) : 0;
+  for(int k = 0; k < n; k++) neigh[rowbase + (size_t)k * 64] = cl[in[(size_t)k * 64]];
 }
 
 // pad every row with the dummy atom up to its wavefront's longest row (rounded up to the unroll factor)
@@ -438,6 +492,40 @@ __global__ __launch_bounds__(256) void k_pad_rows(int nlocal, int nwaves, int ma
   if((i & 63) == 0 && s) atomicAdd(total, (unsigned long long)s);
 }
 
+// pad + wave_max + statistics for the 32-bit rows
+static int finish_rows(mmd_handle* h, bool count_total)
+{
+  const int nlocal = h->nlocal, nall = h->nlocal + h->nghost, nwaves = div_up(nlocal, 64);
+  if(count_total) HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
+  if(nwaves)
+    hipLaunchKernelGGL(k_pad_rows, dim3(div_up(nwaves * 64, 256)), dim3(256), 0, h->stream, nlocal, nwaves, h->maxneighs, nall,
+                       h->neigh.p, h->numneigh.p, h->wave_max.p, (unsigned long long*)(count_total ? h->d_result : h->d_result + 16));
+  HIP_TRY(hipGetLastError());
+  if(count_total) {
+    HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    unsigned long long tot;
+    memcpy(&tot, h->h_result, sizeof(tot));
+    h->total_neigh = (long long)tot;
+  }
+  h->rows_ready = true;
+  return 0;
+}
+
+int mmd_ensure_rows(mmd_handle* h)
+{
+  if(h->rows_ready) return 0;
+  if(!h->tiles_ready) { mmd_set_error("no neighbor list has been built"); return -1; }
+  const int nwaves = div_up(h->nlocal, 64);
+  MMD_TRY(h->neigh.ensure((size_t)nwaves * h->maxneighs * 64 + 64, false, h->stream));
+  MMD_TRY(h->wave_max.ensure((size_t)nwaves + 1, false, h->stream));
+  if(h->ntiles)
+    hipLaunchKernelGGL(k_tiles_to_rows, dim3(h->ntiles), dim3(64), 0, h->stream, h->nlocal, h->maxneighs, h->tile_cstride, h->binned.p,
+                       h->tile_first.p, h->tile_cnt.p, h->tile_cand.p, h->nl16.p, h->numneigh.p, h->neigh.p);
+  HIP_TRY(hipGetLastError());
+  return finish_rows(h, false);
+}
+
 extern "C" int mmd_neighbor_build(mmd_handle* h)
 {
   if(!h || !h->neigh_ready) { mmd_set_error("mmd_neighbor_build: call mmd_neighbor_setup first"); return -1; }
@@ -451,14 +539,14 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   }
   MMD_TRY(mmd_bin_atoms(h, -1));
   MMD_TRY(h->numneigh.ensure((size_t)nlocal + 64, false, h->stream));
-  MMD_TRY(h->wave_max.ensure((size_t)nwaves + 1, false, h->stream));
   const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
-  // tiles for the LDS force kernels (full lists, LJ uniform tables: see force_lj.hip)
   h->tiles_ready = false;
-  const bool want_tiles = h->opt_tiles && !h->halfneigh && nlocal > 0;
+  h->rows_ready = false;
+  h->neigh_nlocal = 0;
+  // ---- tile form (full lists): block-local 16-bit rows + per-tile candidate union, see k_build_tiles
+  bool want_tiles = h->opt_tiles && !h->halfneigh && nlocal > 0;
   if(want_tiles) {
     MMD_TRY(h->tile_of_block.ensure((size_t)nblocks + 2, false, h->stream));
-    MMD_TRY(h->blk_ncand.ensure((size_t)nblocks + 2, false, h->stream));
     hipLaunchKernelGGL(k_tile_count, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->binned.p, h->bin_start.p, nblocks, nlocal, h->tile_of_block.p);
     int nt = 0;
     MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nblocks, &nt));
@@ -468,22 +556,49 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     MMD_TRY(h->tile_max.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_ncand.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_cnt.ensure((size_t)nt + 2, false, h->stream));
-    MMD_TRY(h->tile_used.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64;
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
-    HIP_TRY(hipMemsetAsync(h->tile_used.p, 0, ((size_t)nt * 64 + 64) * sizeof(int), h->stream));
     hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p);
     HIP_TRY(hipGetLastError());
+    for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
+      MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 64, false, h->stream));
+      HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
+      HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
+      const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
+      hipLaunchKernelGGL(k_build_tiles, dim3(nblocks), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p, g, nlocal, h->cutneighsq,
+                         h->maxneighs, h->tile_cstride, h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,
+                         h->tile_max.p, h->d_flags, (unsigned long long*)h->d_result);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if(h->h_flags[3]) { want_tiles = false; break; }           // a block has too many candidates: global-row build below
+      const int maxn = h->h_flags[0];
+      h->max_row = maxn;
+      if(maxn >= h->maxneighs) {                                   // ref/neighbor.cpp:186-208
+        int m = (int)(maxn * 1.2);
+        h->maxneighs = (m + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
+        continue;
+      }
+      unsigned long long tot;
+      memcpy(&tot, h->h_result, sizeof(tot));
+      h->total_neigh = (long long)tot;
+      h->tile_cmax = h->h_flags[2];
+      h->tiles_ready = true;
+      h->neigh_nlocal = nlocal;
+      return 0;
+    }
+    if(want_tiles) { mmd_set_error("mmd_neighbor_build: neighbor rows keep overflowing (maxneighs=%d)", h->maxneighs); return -1; }
   }
+  // ---- global 32-bit rows (half lists, or blocks with too many candidates for the tile form)
+  MMD_TRY(h->wave_max.ensure((size_t)nwaves + 1, false, h->stream));
   for(int attempt = 0; attempt < 8; attempt++) {
     MMD_TRY(h->neigh.ensure((size_t)nwaves * h->maxneighs * 64 + 64, false, h->stream));
-    if(want_tiles) MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 64, false, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
     const int mode = !h->halfneigh ? 0 : (h->ghost_newton ? 2 : 1);
 #define LAUNCH_BUILD(M)                                                                                              \
   hipLaunchKernelGGL(k_build<M>, dim3(nblocks), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,        \
-                     h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags,       \
-                     h->tile_of_block.p, want_tiles ? h->nl16.p : (unsigned short*)nullptr, h->blk_ncand.p, h->tile_used.p)
+                     h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags)
     if(nlocal) {
       if(mode == 0) LAUNCH_BUILD(0);
       else if(mode == 1) LAUNCH_BUILD(1);
@@ -501,33 +616,9 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       h->maxneighs = m;
       continue;
     }
-    // pad + statistics
-    HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
-    if(nwaves)
-      hipLaunchKernelGGL(k_pad_rows, dim3(div_up(nwaves * 64, 256)), dim3(256), 0, h->stream, nlocal, nwaves, h->maxneighs, nall,
-                         h->neigh.p, h->numneigh.p, h->wave_max.p, (unsigned long long*)h->d_result);
-    if(want_tiles && h->ntiles) {
-      hipLaunchKernelGGL(k_pad_tiles, dim3(div_up((long long)h->ntiles * 64, 256)), dim3(256), 0, h->stream, h->ntiles, nlocal, h->maxneighs,
-                         h->tile_block.p, h->tile_first.p, h->bin_start.p, h->binned.p, h->numneigh.p, h->blk_ncand.p, h->nl16.p, h->tile_max.p);
-      h->tile_tmax = h->h_flags[1];
-      // the tile form needs every owned block to be single-pass in k_build (<= NB_CHUNKS*64 candidates)
-      h->tiles_ready = h->tile_tmax <= NB_CHUNKS * 64 && (2 * g.reach[1] + 1) * (2 * g.reach[2] + 1) <= 128;
-      if(h->tiles_ready) {
-        hipLaunchKernelGGL(k_tile_remap, dim3(h->ntiles), dim3(64), 0, h->stream, h->binned.p, h->bin_start.p, g, h->maxneighs, h->tile_cstride,
-                           h->tile_block.p, h->tile_max.p, h->tile_used.p, h->blk_ncand.p, h->tile_cand.p, h->tile_ncand.p, h->nl16.p, h->d_flags);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        h->tile_cmax = h->h_flags[2];
-      }
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    unsigned long long tot;
-    memcpy(&tot, h->h_result, sizeof(tot));
-    h->total_neigh = (long long)tot;
+    MMD_TRY(finish_rows(h, true));
     h->neigh_nlocal = nlocal;
+    (void)nall;
     return 0;
   }
   mmd_set_error("mmd_neighbor_build: neighbor rows keep overflowing (maxneighs=%d)", h->maxneighs);
@@ -579,6 +670,7 @@ __global__ void k_rows_from_ref(const int* __restrict__ in, const int* __restric
 extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneighs, int* numneigh)
 {
   if(!h || h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_neighbor_download: no neighbor list for the current atoms"); return -1; }
+  MMD_TRY(mmd_ensure_rows(h));
   const int n = h->nlocal;
   if(numneigh) HIP_TRY(hipMemcpyAsync(numneigh, h->numneigh.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if(neighbors && n) {
@@ -623,5 +715,6 @@ extern "C" int mmd_neighbor_upload(mmd_handle* h, const int* neighbors, int maxn
   h->neigh_nlocal = nlocal;
   h->max_row = maxn;
   h->tiles_ready = false;         // an uploaded list has no block-local form
+  h->rows_ready = true;
   return 0;
 }
