@@ -19,6 +19,31 @@ __device__ __forceinline__ int wave_max_i(int v)
   }
   return v;
 }
+// wavefront min / max of a float through DPP row shifts + row broadcasts (6 VALU ops, no LDS crossbar):
+// the classic GCN/CDNA reduction — the result is valid in lane 63 and returned wave-uniform.
+#define MMD_DPP_STEP(OP, ctrl, rmask)                                                                              \
+  v = OP(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
+                                                                   ctrl, rmask, 0xf, false)))
+__device__ __forceinline__ float wave_min_f(float v)
+{
+  MMD_DPP_STEP(fminf, 0x111, 0xf);   // row_shr:1
+  MMD_DPP_STEP(fminf, 0x112, 0xf);   // row_shr:2
+  MMD_DPP_STEP(fminf, 0x114, 0xf);   // row_shr:4
+  MMD_DPP_STEP(fminf, 0x118, 0xf);   // row_shr:8
+  MMD_DPP_STEP(fminf, 0x142, 0xa);   // row_bcast:15 -> rows 1,3
+  MMD_DPP_STEP(fminf, 0x143, 0xc);   // row_bcast:31 -> rows 2,3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+  MMD_DPP_STEP(fmaxf, 0x111, 0xf);
+  MMD_DPP_STEP(fmaxf, 0x112, 0xf);
+  MMD_DPP_STEP(fmaxf, 0x114, 0xf);
+  MMD_DPP_STEP(fmaxf, 0x118, 0xf);
+  MMD_DPP_STEP(fmaxf, 0x142, 0xa);
+  MMD_DPP_STEP(fmaxf, 0x143, 0xc);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 // inclusive prefix sum over a wavefront
 __device__ __forceinline__ int wave_incl_scan(int v)
 {

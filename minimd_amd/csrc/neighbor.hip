@@ -163,6 +163,7 @@ int mmd_bin_atoms(mmd_handle* h, int count)
 #else
 #define NB_CHUNKS 28
 #endif
+#define NB_FASTR 9             // slices handled by the branch-free slot addressing (3x3 rows of blocks)
 #define NB_MAXA 512            // owned atoms of one block handled per pass (counts live in LDS)
 #define NB_IDX_MASK 0x1FFFFFFF // candidate word = index | info << 29
 
@@ -329,13 +330,14 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
                                                        int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
                                                        int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
                                                        int* __restrict__ tile_max, int* __restrict__ flags,
-                                                       unsigned long long* __restrict__ total_out)
+                                                       unsigned long long* __restrict__ total_out, int ablate)
 {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   unsigned short* rows = (unsigned short*)s_dyn;              // [maxneighs][64]
   __shared__ int rng_start[128], rng_pref[130];
   __shared__ unsigned short remap[NB_CHUNKS * 64];
-  __shared__ int cnt[64];
+  __shared__ int cnt[64], at_i[64];
+  __shared__ real at_x[64], at_y[64], at_z[64];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   const int tile0 = tile_of_block[b], ntile_b = tile_of_block[b + 1] - tile0;
@@ -364,14 +366,41 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
   if(lane == 0) rng_pref[nr] = carry;
   __syncthreads();
   const int total = rng_pref[nr];
+  if(ablate & 16) return;
   if(total > NB_CHUNKS * 64) {                                // cannot hold the candidates in one register pass
     if(lane == 0) atomicMax(&flags[3], 1);                    // host falls back to k_build + global rows
     return;
   }
-  // ---- transpose-load the candidates into registers
+  // ---- transpose-load the candidates into registers. Slot t lives at binned[t + D(r)], r = slice of t:
+  // with few slices the offset is accumulated branch-free from wave-uniform (start, delta) pairs, so the 2x28
+  // dependent loads of a lane are all in flight together (a data-dependent search loop serialised them).
   real cx[NB_CHUNKS], cy[NB_CHUNKS], cz[NB_CHUNKS];
   int cj[NB_CHUNKS];
-  {
+  if(nr <= NB_FASTR) {
+    int pq[NB_FASTR], dq[NB_FASTR];
+#pragma unroll
+    for(int q = 0; q < NB_FASTR; q++) {
+      const int d_here = q < nr ? rng_start[q] - rng_pref[q] : 0;
+      const int d_prev = (q > 0 && q < nr) ? rng_start[q - 1] - rng_pref[q - 1] : 0;
+      pq[q] = q < nr ? rng_pref[q] : 0x7fffffff;
+      dq[q] = q < nr ? d_here - d_prev : 0;
+    }
+    int jj[NB_CHUNKS];
+#pragma unroll
+    for(int c = 0; c < NB_CHUNKS; c++) {
+      const int gt = c * 64 + lane;
+      int addr = gt;
+#pragma unroll
+      for(int q = 0; q < NB_FASTR; q++) addr += gt >= pq[q] ? dq[q] : 0;
+      jj[c] = gt < total ? binned[addr] : -1;
+    }
+#pragma unroll
+    for(int c = 0; c < NB_CHUNKS; c++) {
+      cj[c] = jj[c];
+      cx[c] = (real)1.0e15; cy[c] = (real)1.0e15; cz[c] = (real)1.0e15;
+      if(jj[c] >= 0) { const real4 p = x[jj[c]]; cx[c] = p.x; cy[c] = p.y; cz[c] = p.z; }
+    }
+  } else {
     int r = 0;
 #pragma unroll
     for(int c = 0; c < NB_CHUNKS; c++) {
@@ -386,23 +415,53 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     }
   }
   const int nchunks = (total + 63) >> 6;
+  // ---- conservative float bounding box of every chunk of 64 candidates; lane c keeps the box of chunk c.
+  // An owned atom farther than the cutoff (+0.1% margin for the float rounding) from a box skips that chunk
+  // with a scalar branch: ~60% of the (atom, chunk) passes disappear.
+  float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f, bz0 = 3.0e38f, bz1 = -3.0e38f;
+#pragma unroll
+  for(int c = 0; c < NB_CHUNKS; c++) {
+    if(c < nchunks && !(ablate & 4)) {
+      const bool valid = cj[c] >= 0;
+      const float fx = (float)cx[c], fy = (float)cy[c], fz = (float)cz[c];
+      const float mnx = wave_min_f(valid ? fx : 3.0e38f), mxx = wave_max_f(valid ? fx : -3.0e38f);
+      const float mny = wave_min_f(valid ? fy : 3.0e38f), mxy = wave_max_f(valid ? fy : -3.0e38f);
+      const float mnz = wave_min_f(valid ? fz : 3.0e38f), mxz = wave_max_f(valid ? fz : -3.0e38f);
+      if(lane == c) { bx0 = mnx; bx1 = mxx; by0 = mny; by1 = mxy; bz0 = mnz; bz1 = mxz; }
+    }
+  }
+  const float cull = (float)cutneighsq * 1.001f + 1.0e-4f;
 
   for(int tl = 0; tl < ntile_b; tl++) {
     const int tile = tile0 + tl;
     const int ta = a0 + tl * 64, te = min(ta + 64, a1);
     unsigned usedbits = 0;
-    if(lane < 64) cnt[lane] = 0;
+    // owned atoms of the tile: one coalesced load, then broadcast reads from LDS inside the atom loop
+    {
+      const int ii = ta + lane < te ? binned[ta + lane] : -1;
+      const real4 p = x[ii >= 0 ? ii : 0];
+      cnt[lane] = 0;
+      at_i[lane] = ii;
+      at_x[lane] = p.x; at_y[lane] = p.y; at_z[lane] = p.z;
+    }
     __syncthreads();
     for(int a = ta; a < te; a++) {
-      const int i = __builtin_amdgcn_readfirstlane(binned[a]);
-      if(i >= nlocal) continue;                               // ghosts get no row
-      const real4 xi = x[i];                                  // uniform address: scalar load
-      const real xix = xi.x, xiy = xi.y, xiz = xi.z;
       const int al = a - ta;
+      const int i = at_i[al];
+      if(i >= nlocal) continue;                               // ghosts get no row
+      const real xix = at_x[al], xiy = at_y[al], xiz = at_z[al];
+      // chunks whose box is within reach of this atom
+      const float fxi = (float)xix, fyi = (float)xiy, fzi = (float)xiz;
+      const float ddx = fmaxf(fmaxf(bx0 - fxi, fxi - bx1), 0.0f);
+      const float ddy = fmaxf(fmaxf(by0 - fyi, fyi - by1), 0.0f);
+      const float ddz = fmaxf(fmaxf(bz0 - fzi, fzi - bz1), 0.0f);
+      unsigned long long live = __ballot(lane < nchunks && ddx * ddx + ddy * ddy + ddz * ddz <= cull);
+      if(ablate & 2) live = ~0ull >> (64 - nchunks);      // profiling: no culling
+      if(ablate & 1) live = 0;                            // profiling: no tests at all
       int n = 0;
 #pragma unroll
       for(int c = 0; c < NB_CHUNKS; c++) {
-        if(c < nchunks) {
+        if((live >> c) & 1ull) {
           const real dx = xix - cx[c], dy = xiy - cy[c], dz = xiz - cz[c];
           const real rsq = dx * dx + dy * dy + dz * dz;
           const bool keep = rsq <= cutneighsq && cj[c] != i;
@@ -420,6 +479,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
       if(lane == 0) { cnt[al] = n; numneigh[i] = n; }
     }
     __syncthreads();
+    if(ablate & 8) continue;
     // ---- union of the candidates referenced by this tile -> compact list + remap table
     int base = 0;
 #pragma unroll
@@ -443,6 +503,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     if(kmax > maxneighs) kmax = maxneighs;
     const int lim = min(myn, maxneighs);
     unsigned short* out = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+#pragma unroll 8
     for(int k = 0; k < kmax; k++) out[(size_t)k * 64] = k < lim ? remap[rows[k * 64 + lane]] : (unsigned short)base;
     const long long tsum = wave_sum((long long)myn);
     if(lane == 0) {
@@ -567,7 +628,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
       hipLaunchKernelGGL(k_build_tiles, dim3(nblocks), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p, g, nlocal, h->cutneighsq,
                          h->maxneighs, h->tile_cstride, h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,
-                         h->tile_max.p, h->d_flags, (unsigned long long*)h->d_result);
+                         h->tile_max.p, h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -35,6 +35,15 @@ if a.ab:
         for v in (1, 0):
             h.set_option(a.ab, v)
             print("round %d  %s=%d  force %.4f ms" % (rnd, a.ab, v, h.profile_kernel(0, a.reps)))
+if os.environ.get("BUILDAB"):
+    for ab in (0, 1, 1+4, 1+4+8, 16):
+        h.set_option("ablate", ab)
+        try:
+            print("ablate=%d  neighbor build %.4f ms" % (ab, h.profile_kernel(1, 3)))
+        except Exception as e:
+            print("ablate=%d failed: %s" % (ab, e))
+    h.set_option("ablate", 0)
+    h.neighbor_build()
 if os.environ.get("SHAPES"):
     h.set_option("tiles", 1)
     for rnd in range(2):
