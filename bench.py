@@ -34,7 +34,9 @@ def cpu_baseline(size, nsteps):
     """rank 0, N=1 only: the UNMODIFIED reference (oracle/_ref/miniMD_ref_dp, built from /root/reference by
     oracle/Makefile) on this box's host cores, bounded sample of the same workload."""
     exe = os.path.join(REPO, "oracle", "_ref", "miniMD_ref_dp")
-    cores = os.cpu_count() or 1
+    # the reference's OpenMP loops stop scaling (and then collapse) far below the 256 hardware threads of the
+    # GPU box's host: use one thread per physical core of ONE socket unless told otherwise
+    cores = int(os.environ.get("MMD_CPU_THREADS", "0")) or max(1, min(32, (os.cpu_count() or 2) // 2))   # 32 measured best on the 2x64-core host (16: 57, 32: 61, 64: 40, 128: 33 Matom-steps/s)
     data = os.path.join(REPO, "data")
     if os.path.exists(exe):
         cmd = [exe, "-i", "in.lj.miniMD", "-s", str(size), "-n", str(nsteps), "--half_neigh", "0", "-t", str(cores)]
@@ -45,7 +47,8 @@ def cpu_baseline(size, nsteps):
         cmd = [exe, "-i", "in.lj.miniMD", "-s", str(size), "-n", str(max(nsteps // 2, 1)), "--half_neigh", "0"]
         kind, cores = "port", 1
     try:
-        r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=900)
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=900, env=env)
         line = [l for l in r.stdout.splitlines() if "PERF_SUMMARY" in l and not l.startswith("#")][0].split()
         return {"value": float(line[9]) / 1e6, "unit": "Matom-steps/s", "cores": cores, "kind": kind,
                 "sample": "%s, in.lj.miniMD -s %d --half_neigh 0 DP, %s steps, t_total %.2f s" % (
@@ -62,7 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=80, help="unit cells per GPU edge (BASELINE configs[1]: 80)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-steps", type=int, default=100)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
