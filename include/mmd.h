@@ -189,6 +189,8 @@ typedef struct mmd_sim mmd_sim;
  * Multi-GPU: one process per GPU, RANK/WORLD_SIZE/LOCAL_RANK from the environment; the RCCL id is
  * taken from mmd_sim_set_unique_id() if called before, else exchanged over MASTER_ADDR:MASTER_PORT. */
 int mmd_sim_set_unique_id(const unsigned char id[128]);
+/* use a host-staged transport (see mmd_comm_set_host_transport) for the sims created afterwards */
+int mmd_sim_set_host_transport(mmd_sendrecv_fn sr, mmd_allreduce_fn ar, void* ctx);
 int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out);
 int mmd_sim_initial(mmd_sim* s);                  /* ref/ljs.cpp:445-468 */
 int mmd_sim_run(mmd_sim* s);                      /* ref/ljs.cpp:470-483 */

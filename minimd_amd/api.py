@@ -78,7 +78,7 @@ def load_library(precision="dp"):
         "mmd_input_read": [P, C.c_char_p], "mmd_create_box": [I, I, I, D, rp],
         "mmd_create_atoms": [I, I, I, D, rp, rp, I, rp, rp, ip, ip, ip],
         "mmd_eam_tables_from_file": [C.c_char_p, I, ip, ip, ip, ip, rp, rp, rp, rp, rp, rp, rp],
-        "mmd_sim_set_unique_id": [C.c_char_p], "mmd_sim_create": [I, C.POINTER(C.c_char_p), I, C.POINTER(P)],
+        "mmd_sim_set_unique_id": [C.c_char_p], "mmd_sim_set_host_transport": [P, P, P], "mmd_sim_create": [I, C.POINTER(C.c_char_p), I, C.POINTER(P)],
         "mmd_sim_initial": [P], "mmd_sim_run": [P], "mmd_sim_run_steps": [P, I, dp], "mmd_sim_print_perf": [P],
         "mmd_sim_rows": [P, ip, ip, dp, dp, dp, I], "mmd_sim_natoms": [P], "mmd_sim_destroy": [P],
     }
@@ -397,6 +397,29 @@ def eam_tables_from_file(path, ntypes=4, precision="dp"):
     return {"nr": nr.value, "nrho": nrho.value, "nr_tot": nrt.value, "nrho_tot": nrhot.value, "rdr": rdr.value, "rdrho": rdrho.value,
             "cutmax": cut.value, "mass": mass.value, "rhor_spline": a, "frho_spline": b, "z2r_spline": c,
             "cutforcesq": np.full(n2, L._real(cut.value) * L._real(cut.value), L._real)}
+
+
+_SIM_TRANSPORT_KEEP = []
+
+
+def sim_set_host_transport(sendrecv, allreduce, precision="dp"):
+    """register a host-staged transport (e.g. minimd_amd.transport.GlooTransport) for subsequently created Sims"""
+    L = load_library(precision)
+
+    def _sr(ctx, sbuf, ns, dest, rbuf, nr, src):
+        data = C.string_at(sbuf, ns) if ns else b""
+        got = sendrecv(data, dest, nr, src)
+        if got:
+            C.memmove(rbuf, got, len(got))
+        return len(got)
+
+    def _ar(ctx, vals, n):
+        a = np.ctypeslib.as_array(vals, shape=(n,))
+        allreduce(a)
+        return 0
+    cb1, cb2 = SENDRECV_FN(_sr), ALLREDUCE_FN(_ar)
+    _SIM_TRANSPORT_KEEP.extend([cb1, cb2])
+    L.mmd_sim_set_host_transport(C.cast(cb1, C.c_void_p), C.cast(cb2, C.c_void_p), None)
 
 
 class Sim:

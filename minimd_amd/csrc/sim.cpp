@@ -41,6 +41,16 @@ struct mmd_sim {
 
 static bool g_have_id = false;
 static unsigned char g_id[128];
+static mmd_sendrecv_fn g_host_sr = nullptr;
+static mmd_allreduce_fn g_host_ar = nullptr;
+static void* g_host_ctx = nullptr;
+
+// host-staged transport for every sim created afterwards (tests: gloo; also an MPI bridge) instead of RCCL
+extern "C" int mmd_sim_set_host_transport(mmd_sendrecv_fn sr, mmd_allreduce_fn ar, void* ctx)
+{
+  g_host_sr = sr; g_host_ar = ar; g_host_ctx = ctx;
+  return 0;
+}
 
 extern "C" int mmd_sim_set_unique_id(const unsigned char id[128])
 {
@@ -217,7 +227,9 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
   mmd_create_box(s->in.nx, s->in.ny, s->in.nz, s->in.rho, s->prd);
   { const mmd_float zero[3] = {0, 0, 0}; SIM_TRY(mmd_atom_set_box(h, s->prd, zero, s->prd)); }
   SIM_TRY(mmd_comm_setup(h, s->in.neigh_cut, s->me, s->nprocs));
-  if(s->nprocs > 1) {
+  if(s->nprocs > 1 && g_host_sr) {
+    SIM_TRY(mmd_comm_set_host_transport(h, g_host_sr, g_host_ar, g_host_ctx));
+  } else if(s->nprocs > 1) {
     unsigned char id[128];
     if(g_have_id) memcpy(id, g_id, 128); else SIM_TRY(exchange_id_tcp(s->me, s->nprocs, id));
     SIM_TRY(mmd_comm_init_rccl(h, id, s->me, s->nprocs));

@@ -1,0 +1,207 @@
+"""`-m gpu` parity tests, part 2: EAM, single precision, half neighbor lists, two ranks on one GPU, and
+size-independent properties at the BASELINE.json sizes (-s 80 LJ, -s 64 EAM)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, fmt7, ref_pass_rule
+from test_gpu_parity import handle_from_oracle, mm, rows_close, sim_rows, REFRUNS, PUBLISHED
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- ForceEAM::compute_fullneigh (ref/force_eam.cpp:274-449) -----------------------------------------
+@pytest.mark.parametrize("size,ntypes", [(4, 4), (5, 1)])
+def test_eam_force_full_matches_oracle(size, ntypes):
+    o = Oracle(["-i", "in.eam.miniMD", "-s", size, "-n", 20, "--half_neigh", 0, "--ntypes", ntypes])
+    o.initial(); o.run()
+    h = handle_from_oracle(o)
+    h.comm_setup(o.param("cutneigh"), 0, 1)
+    h.exchange(); h.borders()                          # the fp halo needs the send lists (ghosts are rebuilt identically)
+    np.testing.assert_array_equal(h.download()["x"], o.x())
+    from minimd_amd import api
+    t = api.eam_tables_from_file(os.path.join(REPO, "data", "Cu_u6.eam"), ntypes)
+    h.force_eam_setup(ntypes, t)
+    h.neighbor_upload(o.neighbors(), o.numneigh())
+    eng, vir = h.force_compute(1)
+    f = h.download()["f"]
+    fo = o.f()
+    # tolerance: 1e-11 of the largest component (FMA contraction in the spline Horner forms)
+    assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+    nl = o.nlocal()
+    fp, fpo = h.eam_fp(), o.eam_fp()
+    assert np.abs(fp - fpo).max() <= 1e-12 * np.abs(fpo).max()      # owned AND ghost fp (halo)
+    assert abs(eng - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl())
+    assert abs(vir - o.virial()) <= 1e-10 * max(1.0, abs(o.virial()))
+    # device-built list gives the same physics
+    h.neighbor_build()
+    eng2, vir2 = h.force_compute(1)
+    assert abs(eng2 - eng) <= 1e-12 * abs(eng) and np.abs(h.download()["f"] - f).max() <= 1e-11 * np.abs(fo).max()
+    h.close(); o.close()
+
+
+@pytest.mark.parametrize("name", ["eam_s10_full_n1000", "eam_s16_full_n200"])
+def test_run_eam_rows_match_reference(name):
+    ent = REFRUNS[name]
+    rows = sim_rows([a for a in ent["args"]])
+    rows_close(rows, ent["rows"], 1.5e-5)
+    for a, b in zip(rows, ent["rows"]):
+        if a[0] <= 300:
+            for k in (1, 2, 3):
+                assert abs(a[k] - b[k]) <= 2e-6 * max(1.0, abs(b[k])), (a, b)
+    assert ref_pass_rule(ent["rows"], rows, ent["natoms"], 8, eam=True)[0]
+
+
+def test_eam_published_log_4k():
+    """tests/reference_output/4k.eam was produced with half lists; full lists give the same rows (README there)"""
+    ref = [r for r in PUBLISHED["4k.eam"]["rows"] if r[0] <= 500]
+    rows = sim_rows(["-i", "in.eam.miniMD", "-s", 10, "-n", 500, "--half_neigh", 0])
+    rows_close(rows, ref, 1.5e-5)
+
+
+# ---- half neighbor lists (ref/force_lj.cpp:271-357): device lists + atomics + reverse halo -----------------
+@pytest.mark.parametrize("name", ["lj_s10_half_gn1_n1000", "lj_s10_half_gn0_n1000", "lj_s32_half_n100"])
+def test_run_lj_half_rows_match_reference(name):
+    ent = REFRUNS[name]
+    args = [a for a in ent["args"] if a not in ("-t", "8")]
+    s = mm().Sim(args)
+    s.initial(); s.run()
+    rows = s.rows()
+    rows_close(rows, ent["rows"], 1.5e-5)
+    assert ref_pass_rule(ent["rows"], rows, ent["natoms"], 8)[0]
+    # every pair is stored exactly once (gn=1) / local-ghost pairs twice (gn=0): same totals as the reference
+    tot = s.handle.neighbor_info()["total"]
+    assert abs(tot - ent["neigh_total"]) <= 5e-6 * ent["neigh_total"]
+    s.close()
+
+
+def test_half_gn1_device_list_pairs_once():
+    """our ghost-newton rule (image vector) differs from the reference's bin rule but must store each pair once:
+    the half-list forces after reverse communication equal the full-list forces"""
+    o = Oracle(["-s", 6, "-n", 20, "--half_neigh", 0])
+    o.initial(); o.run()
+    fo = o.f()
+    m = mm()
+    h = m.Handle()
+    box = o.box()
+    h.set_box(box[0:3])
+    h.set_mass(1.0)
+    h.upload(o.x()[: o.nlocal()], o.v(), o.type()[: o.nlocal()], o.tag())
+    h.comm_setup(o.param("cutneigh"), 0, 1)
+    h.neighbor_setup(o.nbins(), o.param("cutneigh"), 1, 1, o.ntypes())
+    h.force_lj_setup(*o.lj_tables())
+    h.exchange(); h.borders(); h.neighbor_build()
+    assert h.neighbor_info()["total"] * 2 == int(o.numneigh().sum())
+    eng, vir = h.force_compute(1)
+    h.reverse_communicate()
+    f = h.download(halfneigh=True)["f"][: o.nlocal()]
+    assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+    # energy conventions: half lists report half of the full-list double sum (thermo doubles it back, thermo.cpp:123-125)
+    assert abs(2 * eng - o.eng_vdwl()) <= 1e-11 * abs(o.eng_vdwl())
+    assert abs(vir - o.virial()) <= 1e-10 * abs(o.virial())
+    h.close(); o.close()
+
+
+# ---- single precision build (PRECISION=1, ref/types.h:61-66) ---------------------------------------------
+def test_sp_force_matches_sp_oracle():
+    o = Oracle(["-s", 6, "-n", 20, "--half_neigh", 0], precision="sp")
+    o.initial(); o.run()
+    h = handle_from_oracle(o, precision="sp")
+    h.force_lj_setup(*o.lj_tables())
+    h.neighbor_upload(o.neighbors(), o.numneigh())
+    eng, vir = h.force_compute(1)
+    f = h.download()["f"]
+    fo = o.f()
+    # float arithmetic: 2e-6 of the largest component; energy accumulated in double on the device (the
+    # reference's float accumulation error is ~3e-3) -> compare against a double recomputation
+    assert np.abs(f - fo).max() <= 4e-6 * np.abs(fo).max()
+    od = Oracle(["-s", 6, "-n", 1, "--half_neigh", 0])
+    fd, ed, vd = od.lj_force_full(o.x().astype(np.float64), o.type(), o.nlocal(), o.neighbors(), o.numneigh(), *od.lj_tables(), 1)
+    assert abs(eng - ed) <= 2e-6 * abs(ed) and abs(vir - vd) <= 2e-5 * max(1.0, abs(vd))
+    h.neighbor_build()
+    nb, nn = h.neighbor_download()
+    np.testing.assert_array_equal(nn, o.numneigh())
+    h.close(); o.close(); od.close()
+
+
+def test_sp_run_passes_reference_rule_and_target_known_answer():
+    """SP -s 32: judged against the DP rows with the reference's SP tolerance (prec=4 in ref/run_one_test:124),
+    and against the known answer of target/run-offload-tests.sh:7-10 (T,U,P at step 100, the script's tol is 1e-1)"""
+    ref = REFRUNS["lj_s32_full_n100"]
+    rows = sim_rows(["-s", 32, "-n", 100, "--half_neigh", 0], precision="sp")
+    assert ref_pass_rule(ref["rows"], rows, ref["natoms"], 4)[0]
+    t, u, p = rows[-1][1:]
+    assert abs(t - 8.200912e-01) <= 1e-4 * 8.200912e-01
+    assert abs(u - (-5.852703e+00)) <= 1e-4 * 5.852703e+00
+    assert abs(p - (-1.873937e-01)) <= 5e-3 * 1.873937e-01
+    rows_h = sim_rows(["-s", 32, "-n", 100, "--half_neigh", 1], precision="sp")
+    assert ref_pass_rule(ref["rows"], rows_h, ref["natoms"], 4)[0]
+
+
+# ---- two ranks sharing this GPU, halo over the gloo host transport ----------------------------------------
+@pytest.mark.parametrize("half,port", [(0, 29631), (1, 29632)])
+def test_two_ranks_match_one_rank(half, port, tmp_path):
+    args = ["-s", "8", "-n", "100", "--half_neigh", str(half)]
+    base = sim_rows(args)
+    out = str(tmp_path / "mp.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "sim", out, "dp"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["natoms"] == 4 * 8 ** 3 and sum(c[0] for c in res["counts"]) == res["natoms"]
+    rows = [tuple(x) for x in res["rows"]]
+    assert [r_[0] for r_ in rows] == [b[0] for b in base]
+    for a, b in zip(rows, base):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)      # summation order only
+    # the oracle on 2 virtual ranks owns the same atoms per rank
+    o = Oracle(args, nprocs=2)
+    o.initial(); o.run()
+    assert [o.nlocal(0), o.nlocal(1)] == [c[0] for c in res["counts"]]
+    assert [o.nghost(0), o.nghost(1)] == [c[1] for c in res["counts"]]
+    o.close()
+
+
+# ---- BASELINE.json sizes: golden rows + size-independent properties -----------------------------------------
+def test_baseline_s80_full_and_half():
+    ent = REFRUNS["lj_s80_full_n100"]
+    s = mm().Sim(["-s", 80, "-n", 100, "--half_neigh", 0])
+    s.initial(); s.run()
+    rows = s.rows()
+    rows_close(rows, ent["rows"], 2e-6)
+    assert fmt7(rows[0][1]) == fmt7(ent["rows"][0][1]) and fmt7(rows[0][2]) == fmt7(ent["rows"][0][2])
+    nl, ng, _ = s.handle.counts()
+    assert nl == 2048000 and ng == int(ent["nghost"])
+    assert abs(s.handle.neighbor_info()["total"] - ent["neigh_total"]) <= 5e-6 * ent["neigh_total"]
+    d = s.handle.download()
+    # Newton's third law over the periodic system: total force vanishes; atoms stay inside the box after PBC
+    assert np.abs(d["f"].sum(axis=0)).max() <= 1e-7 * np.abs(d["f"]).max() * np.sqrt(nl)
+    assert len(np.unique(d["tag"])) == nl
+    s.close()
+    rows_h = sim_rows(["-s", 80, "-n", 100, "--half_neigh", 1])
+    rows_close(rows_h, ent["rows"], 2e-6)
+
+
+def test_baseline_eam_s64():
+    ent = REFRUNS["eam_s64_full_n100"]
+    s = mm().Sim(["-i", "in.eam.miniMD", "-s", 64, "-n", 100, "--half_neigh", 0])
+    s.initial(); s.run()
+    rows_close(s.rows(), ent["rows"], 2e-6)
+    nl, ng, _ = s.handle.counts()
+    assert nl == 1048576 and ng == int(ent["nghost"])
+    assert abs(s.handle.neighbor_info()["total"] - ent["neigh_total"]) <= 5e-6 * ent["neigh_total"]
+    s.close()
+
+
+def test_config_e_sp_half_scaled_down():
+    """BASELINE configs[4] (-s 160 SP half lists) at -s 48: runs, conserves atoms, passes the SP rule vs the DP run"""
+    ref = sim_rows(["-s", 48, "-n", 100, "--half_neigh", 0])
+    rows = sim_rows(["-s", 48, "-n", 100, "--half_neigh", 1], precision="sp")
+    assert ref_pass_rule(ref, rows, 4 * 48 ** 3, 4)[0]
