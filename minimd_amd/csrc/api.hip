@@ -93,6 +93,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   if(!strcmp(name, "exact_div")) h->opt_exact_div = value;
   else if(!strcmp(name, "time_force_events")) h->time_force_events = value != 0;
   else if(!strcmp(name, "tiles")) h->opt_tiles = value;
+  else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) h->opt_ablate = value;
   else if(!strcmp(name, "tile_waves")) h->opt_tile_waves = value;
   else if(!strcmp(name, "tile_unroll")) h->opt_tile_unroll = value;

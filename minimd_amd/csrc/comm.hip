@@ -329,7 +329,7 @@ extern "C" int mmd_comm_communicate(mmd_handle* h)
   if(!h) { mmd_set_error("null handle"); return -1; }
   for(auto& s : h->swaps) {
     const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
-    if(s.sendproc == h->me) {
+    if(s.sendproc == h->me && !h->opt_force_transport) {
       if(s.sendnum)
         hipLaunchKernelGGL(k_pack_comm, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->x.p, s.sendlist.p, s.sendnum,
                            sx, sy, sz, s.pbc_any, h->x.p + s.firstrecv);
@@ -366,7 +366,7 @@ extern "C" int mmd_comm_reverse_communicate(mmd_handle* h)
   for(int is = (int)h->swaps.size() - 1; is >= 0; is--) {
     Swap& s = h->swaps[is];
     const real* ghost_f = h->f.p + 3 * (size_t)s.firstrecv;     // Atom::pack_reverse is a contiguous slice
-    if(s.sendproc == h->me) {
+    if(s.sendproc == h->me && !h->opt_force_transport) {
       if(s.sendnum) hipLaunchKernelGGL(k_unpack_reverse, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->f.p, s.sendlist.p, s.sendnum, ghost_f);
     } else {
       MMD_TRY(h->buf_recv.ensure((size_t)3 * s.sendnum + 8, false, h->stream));
@@ -522,7 +522,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
       const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
       const int nall = h->nlocal + h->nghost;
       int nrecv = nsend;
-      if(s.sendproc == h->me) {
+      if(s.sendproc == h->me && !h->opt_force_transport) {
         MMD_TRY(mmd_ensure_atoms(h, nall + nrecv + 1, true));
         MMD_TRY(h->ghost_image.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
         if(nsend)

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_fp_pack(const real* __restrict__ fp, co
 static int eam_fp_halo(mmd_handle* h)
 {
   for(auto& s : h->swaps) {
-    if(s.sendproc == h->me) {
+    if(s.sendproc == h->me && !h->opt_force_transport) {
       if(s.sendnum) hipLaunchKernelGGL(k_fp_self, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->fp.p, s.sendlist.p, s.sendnum, s.firstrecv);
     } else {
       MMD_TRY(h->buf_send.ensure((size_t)s.sendnum + 8, false, h->stream));

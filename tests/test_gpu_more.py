@@ -169,6 +169,27 @@ def test_two_ranks_match_one_rank(half, port, tmp_path):
     o.close()
 
 
+def test_rccl_loopback_single_rank():
+    """exercise the production transport calls (ncclCommInitRank, grouped ncclSend/ncclRecv, ncclAllReduce) on ONE
+    GPU: every periodic self-swap of borders / communicate / reverse_communicate is forced through RCCL"""
+    o = Oracle(["-s", 6, "-n", 40, "--half_neigh", 1, "-gn", 1])
+    o.initial(); o.run()
+    ref = o.rows()
+    m = mm()
+    s = m.Sim(["-s", 6, "-n", 40, "--half_neigh", 1, "-gn", 1])
+    h = s.handle
+    h.init_rccl(h.unique_id(), 0, 1)
+    h.set_option("force_transport", 1)
+    s.initial(); s.run()
+    rows = s.rows()
+    for a, b in zip(rows, ref):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+    nl, ng, _ = h.counts()
+    assert (nl, ng) == (o.nlocal(), o.nghost())
+    s.close(); o.close()
+
+
 # ---- BASELINE.json sizes: golden rows + size-independent properties -----------------------------------------
 def test_baseline_s80_full_and_half():
     ent = REFRUNS["lj_s80_full_n100"]
