@@ -29,8 +29,12 @@ __device__ __forceinline__ double recip_fast(double a)
 {
   const double r = __builtin_amdgcn_rcp(a);
   const double e = __builtin_fma(-a, r, 1.0);
+#ifdef MMD_RCP_ONE_STEP
+  return __builtin_fma(r, e, r);                 // r (1 + e)
+#else
   const double t = __builtin_fma(e, e, e);       // e + e^2
   return __builtin_fma(r, t, r);                 // r (1 + e + e^2)
+#endif
 }
 __device__ __forceinline__ float recip_fast(float a)
 {
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
 template <int EV, bool EXACT, int LJ_TILE_WAVES, int UNR>
 __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
-    const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride,
+    const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, LJParams P, real* __restrict__ f,
     double* __restrict__ partials, int ablate)
 {
@@ -149,7 +153,13 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   __shared__ double s_red[16];
   constexpr int LJ_TILE_THREADS = 64 * LJ_TILE_WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int tile = blockIdx.x;
+  // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), so give every
+  // XCD one contiguous eighth of the (spatially sorted) tiles: neighbouring tiles share most of their candidate
+  // atoms, which then stay in that XCD's 4 MiB L2 instead of being streamed by all eight.
+  const int nt = ntiles;
+  const int per_xcd = gridDim.x >> 3;
+  int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if(tile >= nt) return;                         // (grid is padded to a multiple of 8)
   const int ncand = tile_ncand[tile];
   // ---- stage the positions of the tile's candidate union (+1 dummy slot) into LDS: {x,y,z} records of
   // 3 reals (stride 3 is coprime with the bank count: random slots spread over all banks, one address per pair)
@@ -199,7 +209,10 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     }
     real xj[UNR], yj[UNR], zj[UNR];
 #pragma unroll
-    for(int u = 0; u < UNR; u++) { const real* q = sp + 3 * s[u]; xj[u] = q[0]; yj[u] = q[1]; zj[u] = q[2]; }
+    for(int u = 0; u < UNR; u++) {               // s[u] is already the byte offset of the record: no address arithmetic
+      const real* q = (const real*)(s_raw + s[u]);
+      xj[u] = q[0]; yj[u] = q[1]; zj[u] = q[2];
+    }
 #pragma unroll
     for(int u = 0; u < UNR; u++) {
       const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     if(i < 0) { e_acc = 0; v_acc = 0; }
     const double es = block_sum(e_acc, s_red);
     const double vs = block_sum(v_acc, s_red);
-    if(tid == 0) { partials[2 * (size_t)blockIdx.x] = es; partials[2 * (size_t)blockIdx.x + 1] = vs; }
+    if(tid == 0) { partials[2 * (size_t)tile] = es; partials[2 * (size_t)tile + 1] = vs; }
   }
 }
 
@@ -380,8 +393,8 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
 #define TK(EVv, Xv, Wv, Uv) if(ev == EVv && ex == Xv && tw == Wv && tu == Uv)                                                    \
-    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv>), dim3(h->ntiles), dim3(64 * Wv), tile_lds, h->stream, h->x.p,        \
-                       h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
+    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv>), dim3(((h->ntiles + 7) / 8) * 8), dim3(64 * Wv), tile_lds, h->stream, h->x.p,        \
+                       h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->ntiles, \
                        h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
     const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll;
     TK(0, 0, 4, 4); TK(0, 1, 4, 4); TK(1, 0, 4, 4); TK(1, 1, 4, 4);

@@ -163,6 +163,7 @@ int mmd_bin_atoms(mmd_handle* h, int count)
 #else
 #define NB_CHUNKS 28
 #endif
+#define NB_SLOT_BYTES (3 * (int)sizeof(real))   // nl16 holds slot * NB_SLOT_BYTES (<= 43008 DP / 24576 SP)
 #define NB_FASTR 9             // slices handled by the branch-free slot addressing (3x3 rows of blocks)
 #define NB_MAXA 512            // owned atoms of one block handled per pass (counts live in LDS)
 #define NB_IDX_MASK 0x1FFFFFFF // candidate word = index | info << 29
@@ -504,7 +505,8 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     const int lim = min(myn, maxneighs);
     unsigned short* out = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
 #pragma unroll 8
-    for(int k = 0; k < kmax; k++) out[(size_t)k * 64] = k < lim ? remap[rows[k * 64 + lane]] : (unsigned short)base;
+    for(int k = 0; k < kmax; k++)                 // stored as the LDS byte offset of the {x,y,z} record (slot * 3 reals)
+      out[(size_t)k * 64] = (unsigned short)((k < lim ? remap[rows[k * 64 + lane]] : (unsigned short)base) * NB_SLOT_BYTES);
     const long long tsum = wave_sum((long long)myn);
     if(lane == 0) {
       tile_max[tile] = kmax;
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(64) void k_tiles_to_rows(int nlocal, int maxneighs,
   const unsigned short* in = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
   const int* cl = tile_cand + (size_t)tile * cstride;
   const size_t rowbase = i >= 0 ? ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63) : 0;
-  for(int k = 0; k < n; k++) neigh[rowbase + (size_t)k * 64] = cl[in[(size_t)k * 64]];
+  for(int k = 0; k < n; k++) neigh[rowbase + (size_t)k * 64] = cl[in[(size_t)k * 64] / NB_SLOT_BYTES];
 }
 
 // pad every row with the dummy atom up to its wavefront's longest row (rounded up to the unroll factor)
