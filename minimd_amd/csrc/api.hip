@@ -59,7 +59,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->tile_cand.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
   for(auto& s : h->swaps) s.sendlist.release();
-  h->buf_send.release(); h->buf_recv.release(); h->flag_tmp.release(); h->partials.release();
+  h->buf_send.release(); h->buf_recv.release(); h->flag_tmp.release(); h->bnd_list.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if(h->h_result) (void)hipHostFree(h->h_result);
   if(h->d_result) (void)hipFree(h->d_result);

@@ -161,10 +161,13 @@ extern "C" int mmd_atom_sort(mmd_handle* h)
   const int n = h->nlocal;
   if(n == 0) return 0;
   MMD_TRY(mmd_bin_atoms(h, n));               // Neighbor::binatoms(atom, nlocal)
-  MMD_TRY(h->x_alt.ensure(h->x.cap, false, h->stream));
-  MMD_TRY(h->v_alt.ensure(h->v.cap, false, h->stream));
-  MMD_TRY(h->type_alt.ensure(h->type.cap, false, h->stream));
-  MMD_TRY(h->tag_alt.ensure(h->tag.cap, false, h->stream));
+  // the copies only need to hold the current atoms (+ dummy slot); sizing them by the live arrays' capacity
+  // made the two buffers leap-frog each other and re-allocate on every sort
+  const size_t need = (size_t)h->nmax + 1;
+  MMD_TRY(h->x_alt.ensure(need, false, h->stream));
+  MMD_TRY(h->v_alt.ensure(3 * need, false, h->stream));
+  MMD_TRY(h->type_alt.ensure(need, false, h->stream));
+  MMD_TRY(h->tag_alt.ensure(need, false, h->stream));
   hipLaunchKernelGGL(k_sort_permute, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->binned.p, n, h->x.p, h->v.p, h->type.p,
                      h->tag.p, h->x_alt.p, h->v_alt.p, h->type_alt.p, h->tag_alt.p);
   HIP_TRY(hipGetLastError());

@@ -91,3 +91,16 @@ __device__ __forceinline__ int block_incl_scan(int v, int* lds /* >= 17 ints */,
   __syncthreads();
   return s;
 }
+
+// XCD-aware work order. Workgroup b of a launch is observed to run on XCD b % 8 (MI355X_MICROARCH.md, "for speed
+// only"); mapping b -> (b % 8) * ceil(n/8) + b / 8 hands every XCD one CONTIGUOUS eighth of a spatially sorted
+// work list, so the atoms its workgroups gather stay in that XCD's private 4 MiB L2 instead of being streamed by
+// all eight. Launch ceil(n/8)*8 workgroups; the function returns -1 for the padding ones. Results never depend on
+// the placement.
+__device__ __forceinline__ int xcd_work_item(int n)
+{
+  const int per = gridDim.x >> 3;
+  const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  return w < n ? w : -1;
+}
+static inline int xcd_grid(int n) { return ((n + 7) / 8) * 8; }

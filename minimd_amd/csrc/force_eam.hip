@@ -33,7 +33,9 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_density(const real4* __restri
     for(int t = threadIdx.x; t < (nr + 1) * 4; t += blockDim.x) s_tab[t] = rhor_spline[(t >> 2) * 7 + 3 + (t & 3)];
     __syncthreads();
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wg = xcd_work_item((nlocal + MMD_BLOCK - 1) / MMD_BLOCK);
+  if(wg < 0) return;
+  const int i = wg * MMD_BLOCK + threadIdx.x;
   const int w = i >> 6, lane = threadIdx.x & 63;
   const bool owned = i < nlocal;
   const real4 xi = x[owned ? i : nlocal - 1];
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_density(const real4* __restri
   }
   if(EV) {
     const double es = block_sum(e_acc, s_red);
-    if(threadIdx.x == 0) partials[3 * (size_t)blockIdx.x] = es;
+    if(threadIdx.x == 0) partials[3 * (size_t)wg] = es;
   }
 }
 
@@ -105,7 +107,9 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_force(const real4* __restrict
     }
     __syncthreads();
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wg = xcd_work_item((nlocal + MMD_BLOCK - 1) / MMD_BLOCK);
+  if(wg < 0) return;
+  const int i = wg * MMD_BLOCK + threadIdx.x;
   const int w = i >> 6, lane = threadIdx.x & 63;
   const bool owned = i < nlocal;
   const real4 xi = x[owned ? i : nlocal - 1];
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_force(const real4* __restrict
   if(EV) {
     const double es = block_sum(e_acc, s_red);
     const double vs = block_sum(v_acc, s_red);
-    if(threadIdx.x == 0) { partials[3 * (size_t)blockIdx.x + 1] = es; partials[3 * (size_t)blockIdx.x + 2] = vs; }
+    if(threadIdx.x == 0) { partials[3 * (size_t)wg + 1] = es; partials[3 * (size_t)wg + 2] = vs; }
   }
 }
 
@@ -255,11 +259,11 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   const size_t lds1 = h->eam_uniform ? (size_t)(h->nr + 1) * 4 * sizeof(real) : 0;
   const size_t lds2 = h->eam_uniform ? (size_t)(h->nr + 1) * 12 * sizeof(real) : 0;
 #define D(EVv, Uv)                                                                                                        \
-  hipLaunchKernelGGL((k_eam_density<EVv, Uv>), dim3(nblocks), dim3(MMD_BLOCK), lds1, h->stream, h->x.p, h->neigh.p,       \
+  hipLaunchKernelGGL((k_eam_density<EVv, Uv>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), lds1, h->stream, h->x.p, h->neigh.p,       \
                      h->wave_max.p, nlocal, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->lj_tables.p, h->ntypes,  \
                      h->nr, h->nrho, h->nr_tot, h->nrho_tot, h->rdr, h->rdrho, h->fp.p, h->partials.p)
 #define FK(EVv, Uv)                                                                                                       \
-  hipLaunchKernelGGL((k_eam_force<EVv, Uv>), dim3(nblocks), dim3(MMD_BLOCK), lds2, h->stream, h->x.p, h->neigh.p,         \
+  hipLaunchKernelGGL((k_eam_force<EVv, Uv>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), lds2, h->stream, h->x.p, h->neigh.p,         \
                      h->wave_max.p, nlocal, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->lj_tables.p, h->ntypes,   \
                      h->nr, h->nr_tot, h->rdr, h->fp.p, h->f.p, h->partials.p)
   const bool ev = evflag != 0, uni = h->eam_uniform;

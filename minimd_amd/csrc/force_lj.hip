@@ -74,7 +74,9 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
     for(int t = threadIdx.x; t < T.ntypes * T.ntypes; t += blockDim.x) { s_cut[t] = T.cutforcesq[t]; s_s6[t] = T.sigma6[t]; s_eps[t] = T.epsilon[t]; }
     __syncthreads();
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wg = xcd_work_item((nlocal + MMD_BLOCK - 1) / MMD_BLOCK);
+  if(wg < 0) return;
+  const int i = wg * MMD_BLOCK + threadIdx.x;
   const int w = i >> 6;
   const int lane = threadIdx.x & 63;
   const bool owned = i < nlocal;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
   if(EV) {
     const double es = block_sum(e_acc, s_red);
     const double vs = block_sum(v_acc, s_red);
-    if(threadIdx.x == 0) { partials[2 * (size_t)blockIdx.x] = es; partials[2 * (size_t)blockIdx.x + 1] = vs; }
+    if(threadIdx.x == 0) { partials[2 * (size_t)wg] = es; partials[2 * (size_t)wg + 1] = vs; }
   }
 }
 
@@ -153,13 +155,9 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   __shared__ double s_red[16];
   constexpr int LJ_TILE_THREADS = 64 * LJ_TILE_WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), so give every
-  // XCD one contiguous eighth of the (spatially sorted) tiles: neighbouring tiles share most of their candidate
-  // atoms, which then stay in that XCD's 4 MiB L2 instead of being streamed by all eight.
-  const int nt = ntiles;
-  const int per_xcd = gridDim.x >> 3;
-  int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if(tile >= nt) return;                         // (grid is padded to a multiple of 8)
+  // XCD-aware order (device_utils.hpp): neighbouring tiles share most of their candidate atoms
+  const int tile = xcd_work_item(ntiles);
+  if(tile < 0) return;                           // (grid is padded to a multiple of 8)
   const int ncand = tile_ncand[tile];
   // ---- stage the positions of the tile's candidate union (+1 dummy slot) into LDS: {x,y,z} records of
   // 3 reals (stride 3 is coprime with the bank count: random slots spread over all banks, one address per pair)
@@ -264,7 +262,9 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_half(const real4* __restrict__
     for(int t = threadIdx.x; t < T.ntypes * T.ntypes; t += blockDim.x) { s_cut[t] = T.cutforcesq[t]; s_s6[t] = T.sigma6[t]; s_eps[t] = T.epsilon[t]; }
     __syncthreads();
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wg = xcd_work_item((nlocal + MMD_BLOCK - 1) / MMD_BLOCK);
+  if(wg < 0) return;
+  const int i = wg * MMD_BLOCK + threadIdx.x;
   const int w = i >> 6;
   const int lane = threadIdx.x & 63;
   const bool owned = i < nlocal;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_half(const real4* __restrict__
   if(EV) {
     const double es = block_sum(e_acc, s_red);
     const double vs = block_sum(v_acc, s_red);
-    if(threadIdx.x == 0) { partials[2 * (size_t)blockIdx.x] = es; partials[2 * (size_t)blockIdx.x + 1] = vs; }
+    if(threadIdx.x == 0) { partials[2 * (size_t)wg] = es; partials[2 * (size_t)wg + 1] = vs; }
   }
 }
 
@@ -365,13 +365,13 @@ extern "C" int mmd_force_lj_setup(mmd_handle* h, int ntypes, const mmd_float* cu
 template <int EV, int UNIFORM, bool EXACT>
 static void launch_full(mmd_handle* h, int nblocks, const LJTables& T)
 {
-  hipLaunchKernelGGL((k_lj_full<EV, UNIFORM, EXACT>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
+  hipLaunchKernelGGL((k_lj_full<EV, UNIFORM, EXACT>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
                      h->wave_max.p, h->nlocal, h->maxneighs, h->lj, T, h->f.p, h->partials.p, h->opt_ablate);
 }
 template <int EV, int GN, int UNIFORM, bool EXACT>
 static void launch_half(mmd_handle* h, int nblocks, const LJTables& T)
 {
-  hipLaunchKernelGGL((k_lj_half<EV, GN, UNIFORM, EXACT>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
+  hipLaunchKernelGGL((k_lj_half<EV, GN, UNIFORM, EXACT>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
                      h->wave_max.p, h->nlocal, h->maxneighs, h->lj, T, h->f.p, h->partials.p);
 }
 
@@ -393,7 +393,7 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
 #define TK(EVv, Xv, Wv, Uv) if(ev == EVv && ex == Xv && tw == Wv && tu == Uv)                                                    \
-    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv>), dim3(((h->ntiles + 7) / 8) * 8), dim3(64 * Wv), tile_lds, h->stream, h->x.p,        \
+    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv>), dim3(xcd_grid(h->ntiles)), dim3(64 * Wv), tile_lds, h->stream, h->x.p,        \
                        h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->ntiles, \
                        h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
     const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll;

@@ -165,7 +165,7 @@ struct mmd_handle {
   mmd_allreduce_fn host_ar = nullptr;
   void* host_ctx = nullptr;
   std::vector<char> stage_send, stage_recv;
-  DevArr<int> flag_tmp;
+  DevArr<int> flag_tmp, bnd_list;
   // ---- Integrate
   real dt = 0, dtforce = 0;
   int neigh_every = 20, sort_every = 20;

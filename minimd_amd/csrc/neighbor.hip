@@ -177,7 +177,8 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
   __shared__ int rng_start[128], rng_pref[130];
   __shared__ int cnt[NB_MAXA];
   const int lane = threadIdx.x;
-  const int b = blockIdx.x;
+  const int b = xcd_work_item(g.nblk[0] * g.nblk[1] * g.nblk[2]);
+  if(b < 0) return;
   const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
   if(a0 == a1) return;                                      // empty block (uniform exit)
   const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
@@ -326,8 +327,8 @@ __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, cons
 // The 32-bit reference-style rows are NOT produced here; mmd_ensure_rows() derives them on demand.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__ x, const int* __restrict__ binned,
-                                                       const int* __restrict__ bin_start, BinGeom g, int nlocal, real cutneighsq,
-                                                       int maxneighs, int cstride, const int* __restrict__ tile_of_block,
+                                                       const int* __restrict__ bin_start, BinGeom g, int nblocks, int nlocal,
+                                                       real cutneighsq, int maxneighs, int cstride, const int* __restrict__ tile_of_block,
                                                        int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
                                                        int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
                                                        int* __restrict__ tile_max, int* __restrict__ flags,
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
   __shared__ int cnt[64], at_i[64];
   __shared__ real at_x[64], at_y[64], at_z[64];
   const int lane = threadIdx.x;
-  const int b = blockIdx.x;
+  const int b = xcd_work_item(nblocks);
+  if(b < 0) return;
   const int tile0 = tile_of_block[b], ntile_b = tile_of_block[b + 1] - tile0;
   if(ntile_b == 0) return;                                    // no owned atom in this block (uniform exit)
   const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
@@ -628,7 +630,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
       HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
       const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
-      hipLaunchKernelGGL(k_build_tiles, dim3(nblocks), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p, g, nlocal, h->cutneighsq,
+      hipLaunchKernelGGL(k_build_tiles, dim3(xcd_grid(nblocks)), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p, g, nblocks, nlocal, h->cutneighsq,
                          h->maxneighs, h->tile_cstride, h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,
                          h->tile_max.p, h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate);
       HIP_TRY(hipGetLastError());
@@ -660,7 +662,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
     const int mode = !h->halfneigh ? 0 : (h->ghost_newton ? 2 : 1);
 #define LAUNCH_BUILD(M)                                                                                              \
-  hipLaunchKernelGGL(k_build<M>, dim3(nblocks), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,        \
+  hipLaunchKernelGGL(k_build<M>, dim3(xcd_grid(nblocks)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,        \
                      h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags)
     if(nlocal) {
       if(mode == 0) LAUNCH_BUILD(0);

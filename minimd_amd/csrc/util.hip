@@ -107,7 +107,7 @@ int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve)
   if(h->f.cap / 3 < c) c = h->f.cap / 3;
   if(h->type.cap < c) c = h->type.cap;
   if(h->tag.cap < c) c = h->tag.cap;
-  h->nmax = (int)c;
+  h->nmax = (int)c - 1;
   return 0;
 }
 
