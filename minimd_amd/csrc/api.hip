@@ -4,6 +4,7 @@
 #include "mmd_internal.hpp"
 
 int mmd_temperature_async(mmd_handle* h, int slot);
+int mmd_integrate_final_initial(mmd_handle* h);
 
 extern "C" int mmd_float_size(void) { return (int)sizeof(mmd_float); }
 extern "C" const char* mmd_variant_string(void) { return "miniMD-HIP 1.0 (MI355X gfx950, HIP+RCCL)"; }
@@ -54,7 +55,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->x.release(); h->x_alt.release(); h->v.release(); h->v_alt.release(); h->f.release();
   h->type.release(); h->type_alt.release(); h->tag.release(); h->tag_alt.release();
   h->bin_count.release(); h->bin_start.release(); h->binned.release(); h->scan_tmp.release(); h->atom_bin.release();
-  h->neigh.release(); h->numneigh.release(); h->wave_max.release(); h->ghost_image.release();
+  h->neigh.release(); h->numneigh.release(); h->wave_max.release(); h->ghost_image.release(); h->ghost_root.release();
   h->tile_of_block.release(); h->tile_block.release(); h->tile_first.release(); h->tile_max.release();
   h->tile_cand.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
@@ -95,6 +96,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "tiles")) h->opt_tiles = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) h->opt_ablate = value;
+  else if(!strcmp(name, "fuse")) h->opt_fuse = value;
   else if(!strcmp(name, "tile_waves")) h->opt_tile_waves = value;
   else if(!strcmp(name, "tile_unroll")) h->opt_tile_unroll = value;
   else if(!strcmp(name, "maxneighs")) h->maxneighs = (value + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
@@ -170,8 +172,10 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // with a stream sync on re-neighbor steps (where the host must read counts anyway) and on thermo steps.
   int next_sort = h->sort_every > 0 ? h->sort_every : ntimes + 1;
   const bool reverse = h->halfneigh && h->ghost_newton;
+  bool initial_done = false;        // initialIntegrate of this step already ran fused with the previous finalIntegrate
   for(int n = 0; n < ntimes; n++) {
-    MMD_TRY(mmd_integrate_initial(h));
+    if(!initial_done) MMD_TRY(mmd_integrate_initial(h));
+    initial_done = false;
     if((n + 1) % h->neigh_every) {
       MMD_TRY(mmd_comm_communicate(h));
     } else {
@@ -193,7 +197,10 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     const int evflag = thermo_nstat > 0 && (step % thermo_nstat == 0);
     MMD_TRY(force_compute_async(h, evflag, nullptr, nullptr, true));
     if(reverse) MMD_TRY(mmd_comm_reverse_communicate(h));
-    MMD_TRY(mmd_integrate_final(h));
+    if(h->opt_fuse && !evflag && n + 1 < ntimes) {
+      MMD_TRY(mmd_integrate_final_initial(h));
+      initial_done = true;
+    } else MMD_TRY(mmd_integrate_final(h));
     if(evflag) {
       MMD_TRY(mmd_temperature_async(h, 2));
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));

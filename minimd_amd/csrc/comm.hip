@@ -346,9 +346,19 @@ __global__ __launch_bounds__(256) void k_pack_comm(const real4* __restrict__ x, 
   dst[i] = p;
 }
 
+__global__ void k_ghost_update(real4* __restrict__ x, int nlocal, int nghost, const int* __restrict__ root,
+                               const int* __restrict__ image, real xprd, real yprd, real zprd);
+
 extern "C" int mmd_comm_communicate(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
+  if(h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport) {
+    if(h->nghost)
+      hipLaunchKernelGGL(k_ghost_update, dim3(div_up(h->nghost, 256)), dim3(256), 0, h->stream, h->x.p, h->nlocal, h->nghost,
+                         h->ghost_root.p, h->ghost_image.p, h->prd[0], h->prd[1], h->prd[2]);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   for(auto& s : h->swaps) {
     const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
     if(s.sendproc == h->me && !h->opt_force_transport) {
@@ -506,9 +516,11 @@ __device__ __forceinline__ int image_add(int code, int px, int py, int pz)
 #define IMAGE_NONE 62      // (0,0,0)
 
 // Atom::pack_border (ref/atom.cpp:197-214): {x+shift, type} -> dst (real4), image code -> dst_img
-__global__ __launch_bounds__(256) void k_pack_border(const real4* __restrict__ x, const int* __restrict__ ghost_image, int nlocal,
+__global__ __launch_bounds__(256) void k_pack_border(const real4* __restrict__ x, const int* __restrict__ ghost_image,
+                                                     const int* __restrict__ ghost_root, int nlocal,
                                                      const int* __restrict__ list, int n, real sx, real sy, real sz, int pbc_any,
-                                                     int px, int py, int pz, real4* __restrict__ dst, int* __restrict__ dst_img)
+                                                     int px, int py, int pz, real4* __restrict__ dst, int* __restrict__ dst_img,
+                                                     int* __restrict__ dst_root)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= n) return;
@@ -518,6 +530,24 @@ __global__ __launch_bounds__(256) void k_pack_border(const real4* __restrict__ x
   dst[k] = p;
   const int code = i < nlocal ? IMAGE_NONE : ghost_image[i - nlocal];
   dst_img[k] = image_add(code, px, py, pz);
+  if(dst_root) dst_root[k] = i < nlocal ? i : ghost_root[i - nlocal];
+}
+
+// One-rank fast path of Comm::communicate: every ghost is a periodic image of an owned atom; replay its chain of
+// shifts (at most `need` per dimension, applied one box length at a time so the rounding equals the swap-by-swap
+// result) in ONE kernel instead of 2*sum(need) dependent ones.
+__global__ __launch_bounds__(256) void k_ghost_update(real4* __restrict__ x, int nlocal, int nghost, const int* __restrict__ root,
+                                                      const int* __restrict__ image, real xprd, real yprd, real zprd)
+{
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= nghost) return;
+  real4 p = x[root[g]];
+  const int code = image[g];
+  const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
+  for(int q = 0; q < (sx < 0 ? -sx : sx); q++) p.x += sx < 0 ? -xprd : xprd;
+  for(int q = 0; q < (sy < 0 ? -sy : sy); q++) p.y += sy < 0 ? -yprd : yprd;
+  for(int q = 0; q < (sz < 0 ? -sz : sz); q++) p.z += sz < 0 ? -zprd : zprd;
+  x[nlocal + g] = p;
 }
 // Atom::unpack_border tail (ref/atom.cpp:216-226): integer type array of the new ghosts
 __global__ __launch_bounds__(256) void k_ghost_types(const real4* __restrict__ x, int first, int n, int* __restrict__ type)
@@ -534,6 +564,8 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   h->nghost = 0;
   int iswap = 0;
   MMD_TRY(h->ghost_image.ensure(1024, false, h->stream));
+  MMD_TRY(h->ghost_root.ensure(1024, false, h->stream));
+  h->ghost_chain_ok = true;                // stays true while every swap is a self swap
   // one pass over the owned atoms keeps only those inside some send slab (~12% at -s 80); the per-swap
   // selections then scan that short list + the ghosts instead of every owned atom six times
   int nb = -1;
@@ -559,18 +591,21 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
       if(s.sendproc == h->me && !h->opt_force_transport) {
         MMD_TRY(mmd_ensure_atoms(h, nall + nrecv + 1, true));
         MMD_TRY(h->ghost_image.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
+        MMD_TRY(h->ghost_root.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
         if(nsend)
-          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->nlocal,
-                             s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], h->x.p + nall,
-                             h->ghost_image.p + h->nghost);
+          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->ghost_root.p,
+                             h->nlocal, s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], h->x.p + nall,
+                             h->ghost_image.p + h->nghost, h->ghost_root.p + h->nghost);
       } else {
         // message = nsend real4 followed by nsend image codes
         const size_t bytes_s = (size_t)nsend * (sizeof(real4) + sizeof(int));
         MMD_TRY(h->buf_send.ensure(bytes_s / sizeof(real) + 8, false, h->stream));
         int* simg = (int*)((real4*)h->buf_send.p + nsend);
+        h->ghost_chain_ok = false;
         if(nsend)
-          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->nlocal,
-                             s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], (real4*)h->buf_send.p, simg);
+          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->ghost_root.p,
+                             h->nlocal, s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], (real4*)h->buf_send.p, simg,
+                             (int*)nullptr);
         MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, s.sendproc, &nrecv, s.recvproc));
         const size_t bytes_r = (size_t)nrecv * (sizeof(real4) + sizeof(int));
         MMD_TRY(h->buf_recv.ensure(bytes_r / sizeof(real) + 8, false, h->stream));

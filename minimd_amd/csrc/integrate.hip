@@ -26,6 +26,31 @@ __global__ __launch_bounds__(256) void k_final_integrate(real* __restrict__ v, c
   v[i] += dtforce * f[i];
 }
 
+// finalIntegrate of step n fused with initialIntegrate of step n+1 (same f, same operation order:
+// v += dtf*f ; v += dtf*f ; x += dt*v) — 136 instead of 208 bytes per atom; used when step n is not a thermo step
+__global__ __launch_bounds__(256) void k_final_initial_integrate(real4* __restrict__ x, real* __restrict__ v, const real* __restrict__ f,
+                                                                 int n, real dt, real dtforce)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) return;
+  real4 p = x[i];
+  real vx = v[3 * (size_t)i + 0], vy = v[3 * (size_t)i + 1], vz = v[3 * (size_t)i + 2];
+  const real fx = f[3 * (size_t)i + 0], fy = f[3 * (size_t)i + 1], fz = f[3 * (size_t)i + 2];
+  vx += dtforce * fx; vy += dtforce * fy; vz += dtforce * fz;
+  vx += dtforce * fx; vy += dtforce * fy; vz += dtforce * fz;
+  p.x += dt * vx; p.y += dt * vy; p.z += dt * vz;
+  v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
+  x[i] = p;
+}
+
+int mmd_integrate_final_initial(mmd_handle* h)
+{
+  if(h->nlocal)
+    hipLaunchKernelGGL(k_final_initial_integrate, dim3(div_up(h->nlocal, 256)), dim3(256), 0, h->stream, h->x.p, h->v.p, h->f.p, h->nlocal, h->dt, h->dtforce);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void k_temperature(const real* __restrict__ v, int n, real mass, double* __restrict__ partials)
 {
   __shared__ double s_red[16];

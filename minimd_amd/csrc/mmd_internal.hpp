@@ -130,6 +130,8 @@ struct mmd_handle {
   long long total_neigh = 0;
   int max_row = 0;
   DevArr<int> ghost_image;   // per ghost: packed periodic-image code (half lists with ghost newton)
+  bool ghost_chain_ok = false;
+  DevArr<int> ghost_root;    // per ghost: owned atom it is an image of (valid when every swap is a self swap)
   // block-local ("tile") neighbor list used by the LDS force kernels: a tile = up to 64 consecutive
   // entries of binned[] inside one block; nl16[(tile*maxneighs + k)*64 + lane] = slot of the neighbor in
   // the block's candidate sequence (the order in which k_build walks the surrounding blocks)
@@ -143,6 +145,7 @@ struct mmd_handle {
   int opt_tiles = 1;
   int opt_force_transport = 0;   // testing: route self-swaps through the transport too (RCCL loop-back on one GPU)
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
+  int opt_fuse = 1;          // fused final+initial integrate, single-kernel ghost update on one rank
   int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)
   // ---- Force
   int style = 0;             // 0 LJ, 1 EAM

@@ -341,8 +341,10 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
   __shared__ int cnt[64], at_i[64];
   __shared__ real at_x[64], at_y[64], at_z[64];
   const int lane = threadIdx.x;
-  const int b = xcd_work_item(nblocks);
-  if(b < 0) return;
+  // plain block order here: blocks without owned atoms (ghost shell) exit at once, and round-robin placement
+  // balances that better than contiguous eighths (measured: 2.6 ms vs 2.96 ms per build at -s 80)
+  const int b = blockIdx.x;
+  if(b >= nblocks) return;
   const int tile0 = tile_of_block[b], ntile_b = tile_of_block[b + 1] - tile0;
   if(ntile_b == 0) return;                                    // no owned atom in this block (uniform exit)
   const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
