@@ -104,3 +104,17 @@ __device__ __forceinline__ int xcd_work_item(int n)
   return w < n ? w : -1;
 }
 static inline int xcd_grid(int n) { return ((n + 7) / 8) * 8; }
+
+// broadcast lane `l` (wave-uniform index) of a value to the whole wavefront through v_readlane (SGPR result),
+// not through the LDS crossbar
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float readlane_d(float v, int l)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}

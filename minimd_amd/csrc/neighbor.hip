@@ -464,20 +464,28 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
       if(ablate & 2) live = ~0ull >> (64 - nchunks);      // profiling: no culling
       if(ablate & 1) live = 0;                            // profiling: no tests at all
       int n = 0;
+      // dead chunks come in runs (candidates are ordered by rows of blocks): test 4 chunks with one scalar branch
+      // before looking at the single bits — most of the taken skip-branches (an instruction-fetch redirect each)
+      // disappear
 #pragma unroll
-      for(int c = 0; c < NB_CHUNKS; c++) {
-        if((live >> c) & 1ull) {
-          const real dx = xix - cx[c], dy = xiy - cy[c], dz = xiz - cz[c];
-          const real rsq = dx * dx + dy * dy + dz * dz;
-          const bool keep = rsq <= cutneighsq && cj[c] != i;
-          const unsigned long long m = __ballot(keep);
-          if(m) {
-            const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if(keep) {
-              if(pos < maxneighs) rows[pos * 64 + al] = (unsigned short)(c * 64 + lane);
-              usedbits |= 1u << c;
+      for(int c4 = 0; c4 < NB_CHUNKS; c4 += 4) {
+        if((live >> c4) & 0xFull) {
+#pragma unroll
+          for(int c = c4; c < c4 + 4; c++) {
+            if((live >> c) & 1ull) {
+              const real dx = xix - cx[c], dy = xiy - cy[c], dz = xiz - cz[c];
+              const real rsq = dx * dx + dy * dy + dz * dz;
+              const bool keep = rsq <= cutneighsq && cj[c] != i;
+              const unsigned long long m = __ballot(keep);
+              if(m) {
+                const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                if(keep) {
+                  if(pos < maxneighs) rows[pos * 64 + al] = (unsigned short)(c * 64 + lane);
+                  usedbits |= 1u << c;
+                }
+                n += __popcll(m);
+              }
             }
-            n += __popcll(m);
           }
         }
       }
