@@ -359,19 +359,43 @@ extern "C" int mmd_comm_communicate(mmd_handle* h)
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  for(auto& s : h->swaps) {
+  // swap by swap (later dimensions forward ghosts received by earlier ones); the two swaps of one dimension are
+  // independent of each other, so with RCCL they share one ncclGroup: 3 instead of 6 p2p rounds per step
+  const size_t nsw = h->swaps.size();
+  for(size_t is = 0; is < nsw; is++) {
+    Swap& s = h->swaps[is];
     const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
-    if(s.sendproc == h->me && !h->opt_force_transport) {
+    const bool self = s.sendproc == h->me && !h->opt_force_transport;
+    if(self) {
       if(s.sendnum)
         hipLaunchKernelGGL(k_pack_comm, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->x.p, s.sendlist.p, s.sendnum,
                            sx, sy, sz, s.pbc_any, h->x.p + s.firstrecv);
+      continue;
+    }
+    // pair with the next swap when it belongs to the same dimension, is remote too, and RCCL is the transport
+    const bool pair = h->rccl && is + 1 < nsw && h->swaps[is + 1].dim == s.dim && h->need[s.dim] == 1 &&
+                      !(h->swaps[is + 1].sendproc == h->me && !h->opt_force_transport);
+    Swap* s2 = pair ? &h->swaps[is + 1] : nullptr;
+    const size_t n1 = (size_t)s.sendnum, n2 = pair ? (size_t)s2->sendnum : 0;
+    MMD_TRY(h->buf_send.ensure((size_t)4 * (n1 + n2) + 16, false, h->stream));
+    real4* b1 = (real4*)h->buf_send.p;
+    real4* b2 = b1 + n1;
+    if(n1) hipLaunchKernelGGL(k_pack_comm, dim3(div_up((long long)n1, 256)), dim3(256), 0, h->stream, h->x.p, s.sendlist.p, (int)n1, sx, sy, sz, s.pbc_any, b1);
+    if(n2) {
+      const real tx = s2->pbc[0] * h->prd[0], ty = s2->pbc[1] * h->prd[1], tz = s2->pbc[2] * h->prd[2];
+      hipLaunchKernelGGL(k_pack_comm, dim3(div_up((long long)n2, 256)), dim3(256), 0, h->stream, h->x.p, s2->sendlist.p, (int)n2, tx, ty, tz, s2->pbc_any, b2);
+    }
+    if(pair) {
+      ncclComm_t c = (ncclComm_t)h->rccl;
+      NCCL_TRY(ncclGroupStart());
+      if(n1) NCCL_TRY(ncclSend(b1, n1 * sizeof(real4), ncclChar, s.sendproc, c, h->stream));
+      if(s.recvnum) NCCL_TRY(ncclRecv(h->x.p + s.firstrecv, (size_t)s.recvnum * sizeof(real4), ncclChar, s.recvproc, c, h->stream));
+      if(n2) NCCL_TRY(ncclSend(b2, n2 * sizeof(real4), ncclChar, s2->sendproc, c, h->stream));
+      if(s2->recvnum) NCCL_TRY(ncclRecv(h->x.p + s2->firstrecv, (size_t)s2->recvnum * sizeof(real4), ncclChar, s2->recvproc, c, h->stream));
+      NCCL_TRY(ncclGroupEnd());
+      is++;
     } else {
-      MMD_TRY(h->buf_send.ensure((size_t)4 * s.sendnum + 8, false, h->stream));
-      if(s.sendnum)
-        hipLaunchKernelGGL(k_pack_comm, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->x.p, s.sendlist.p, s.sendnum,
-                           sx, sy, sz, s.pbc_any, (real4*)h->buf_send.p);
-      MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)s.sendnum * sizeof(real4), s.sendproc, h->x.p + s.firstrecv,
-                                     (size_t)s.recvnum * sizeof(real4), s.recvproc));
+      MMD_TRY(mmd_transport_sendrecv(h, b1, n1 * sizeof(real4), s.sendproc, h->x.p + s.firstrecv, (size_t)s.recvnum * sizeof(real4), s.recvproc));
     }
   }
   HIP_TRY(hipGetLastError());
