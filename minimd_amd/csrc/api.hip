@@ -62,6 +62,8 @@ extern "C" int mmd_destroy(mmd_handle* h)
   for(auto& s : h->swaps) s.sendlist.release();
   h->buf_send.release(); h->buf_recv.release(); h->flag_tmp.release(); h->bnd_list.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if(h->ev_x_ready) { (void)hipEventDestroy(h->ev_x_ready); (void)hipEventDestroy(h->ev_halo_done); }
+  h->tile_ghost.release(); h->tile_order.release();
   if(h->h_result) (void)hipHostFree(h->h_result);
   if(h->d_result) (void)hipFree(h->d_result);
   if(h->h_flags) (void)hipHostFree(h->h_flags);
@@ -97,6 +99,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) h->opt_ablate = value;
   else if(!strcmp(name, "fuse")) h->opt_fuse = value;
+  else if(!strcmp(name, "overlap")) h->opt_overlap = value;
   else if(!strcmp(name, "tile_waves")) h->opt_tile_waves = value;
   else if(!strcmp(name, "tile_unroll")) h->opt_tile_unroll = value;
   else if(!strcmp(name, "maxneighs")) h->maxneighs = (value + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
@@ -173,11 +176,36 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   int next_sort = h->sort_every > 0 ? h->sort_every : ntimes + 1;
   const bool reverse = h->halfneigh && h->ghost_newton;
   bool initial_done = false;        // initialIntegrate of this step already ran fused with the previous finalIntegrate
+  // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
+  const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport) && h->style == 0 && !h->halfneigh;
+  bool halo_pending = false;
+  int evflag_pending = 0;
+  if(overlap && !h->ev_x_ready) {
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_x_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
+  }
   for(int n = 0; n < ntimes; n++) {
     if(!initial_done) MMD_TRY(mmd_integrate_initial(h));
     initial_done = false;
     if((n + 1) % h->neigh_every) {
-      MMD_TRY(mmd_comm_communicate(h));
+      const int step_now = first_step + n + 1;
+      const int ev_now = thermo_nstat > 0 && (step_now % thermo_nstat == 0);
+      if(overlap && mmd_lj_tiles_available(h)) {
+        // halo of this step on the communication stream, interior tiles (no ghost among their candidates)
+        // concurrently on the compute stream
+        HIP_TRY(hipEventRecord(h->ev_x_ready, h->stream));
+        HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_x_ready, 0));
+        std::swap(h->stream, h->comm_stream);
+        const int rc = mmd_comm_communicate(h);
+        std::swap(h->stream, h->comm_stream);
+        MMD_TRY(rc);
+        HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
+        if(h->time_force_events) MMD_TRY(ev_begin(h));
+        MMD_TRY(mmd_lj_compute_tiles_split(h, ev_now, 0));
+        halo_pending = true;
+        evflag_pending = ev_now;
+      } else
+        MMD_TRY(mmd_comm_communicate(h));
     } else {
       HIP_TRY(hipStreamSynchronize(h->stream));
       t_prev = mmd_wall();
@@ -195,7 +223,14 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     }
     const int step = first_step + n + 1;
     const int evflag = thermo_nstat > 0 && (step % thermo_nstat == 0);
-    MMD_TRY(force_compute_async(h, evflag, nullptr, nullptr, true));
+    if(halo_pending) {
+      // overlapped step: interior tiles ran under the halo; now wait for the ghosts and finish the boundary tiles
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
+      MMD_TRY(mmd_lj_compute_tiles_split(h, evflag_pending, 1));
+      if(h->time_force_events) MMD_TRY(ev_end(h));
+      halo_pending = false;
+    } else
+      MMD_TRY(force_compute_async(h, evflag, nullptr, nullptr, true));
     if(reverse) MMD_TRY(mmd_comm_reverse_communicate(h));
     if(h->opt_fuse && !evflag && n + 1 < ntimes) {
       MMD_TRY(mmd_integrate_final_initial(h));

@@ -273,6 +273,11 @@ struct StayPred {
   __device__ bool operator()(int i) const { const real4 p = x[i]; const real c = dim == 0 ? p.x : (dim == 1 ? p.y : p.z); return !(c < lo || c >= hi); }
   __device__ int index(int i) const { return i; }
 };
+struct TileFlagPred {  // tiles whose candidate union does (want=1) / does not (want=0) contain a ghost atom
+  const int* flag; int want;
+  __device__ bool operator()(int t) const { return (flag[t] != 0) == (want != 0); }
+  __device__ int index(int t) const { return t; }
+};
 struct ExchRec {       // Atom::pack_exchange payload (ref/atom.cpp:228-239) + tag
   real x, y, z, w, vx, vy, vz;
   int tag, pad;
@@ -652,5 +657,25 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   MMD_TRY(mmd_set_dummy(h));
   h->neigh_nlocal = 0;                 // any existing neighbor list is stale now
   h->tiles_ready = false;
+  return 0;
+}
+
+// interior tiles (no ghost among their candidates) first, boundary tiles after: the former can run while the halo
+// of this step is still in flight on the communication stream
+int mmd_order_tiles(mmd_handle* h)
+{
+  if(h->ntiles_interior >= 0) return 0;
+  const int nt = h->ntiles;
+  MMD_TRY(h->tile_order.ensure((size_t)nt + 8, false, h->stream));
+  DevArr<int> part;
+  int n_int = 0, n_bnd = 0;
+  MMD_TRY(compact(h, TileFlagPred{h->tile_ghost.p, 0}, 0, nt, part, &n_int));
+  if(n_int) HIP_TRY(hipMemcpyAsync(h->tile_order.p, part.p, (size_t)n_int * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  MMD_TRY(compact(h, TileFlagPred{h->tile_ghost.p, 1}, 0, nt, part, &n_bnd));
+  if(n_bnd) HIP_TRY(hipMemcpyAsync(h->tile_order.p + n_int, part.p, (size_t)n_bnd * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  part.release();
+  if(n_int + n_bnd != nt) { mmd_set_error("mmd_order_tiles: lost tiles (%d + %d != %d)", n_int, n_bnd, nt); return -1; }
+  h->ntiles_interior = n_int;
   return 0;
 }

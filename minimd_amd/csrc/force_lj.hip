@@ -147,6 +147,7 @@ template <int EV, bool EXACT, int LJ_TILE_WAVES, int UNR>
 __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
+    const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, LJParams P, real* __restrict__ f,
     double* __restrict__ partials, int ablate)
 {
@@ -156,8 +157,9 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   constexpr int LJ_TILE_THREADS = 64 * LJ_TILE_WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // XCD-aware order (device_utils.hpp): neighbouring tiles share most of their candidate atoms
-  const int tile = xcd_work_item(ntiles);
-  if(tile < 0) return;                           // (grid is padded to a multiple of 8)
+  const int witem = xcd_work_item(ntiles);
+  if(witem < 0) return;                          // (grid is padded to a multiple of 8)
+  const int tile = tile_list ? tile_list[witem] : witem;
   const int ncand = tile_ncand[tile];
   // ---- stage the positions of the tile's candidate union (+1 dummy slot) into LDS: {x,y,z} records of
   // 3 reals (stride 3 is coprime with the bank count: random slots spread over all banks, one address per pair)
@@ -375,6 +377,48 @@ static void launch_half(mmd_handle* h, int nblocks, const LJTables& T)
                      h->wave_max.p, h->nlocal, h->maxneighs, h->lj, T, h->f.p, h->partials.p);
 }
 
+int mmd_lj_tiles_available(mmd_handle* h)
+{
+  const size_t tile_lds = (size_t)3 * (h->tile_cmax + 2) * sizeof(real);
+  return h->style == 0 && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && tile_lds <= 60 * 1024 && h->neigh_nlocal == h->nlocal;
+}
+
+// launch the tile kernel over `count` tiles: tile ids from `list` (device) or 0..count-1
+static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
+{
+  if(count <= 0) return 0;
+  const size_t tile_lds = (size_t)3 * (h->tile_cmax + 2) * sizeof(real);
+  const int nlocal = h->nlocal;
+  const int ev = evflag ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
+#define TK(EVv, Xv, Wv, Uv) if(ev == EVv && ex == Xv && tw == Wv && tu == Uv)                                                    \
+    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv>), dim3(xcd_grid(count)), dim3(64 * Wv), tile_lds, h->stream, h->x.p,  \
+                       h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
+                       count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
+  const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll;
+  TK(0, 0, 4, 4); TK(0, 1, 4, 4); TK(1, 0, 4, 4); TK(1, 1, 4, 4);
+  TK(0, 0, 2, 4); TK(1, 0, 2, 4); TK(0, 0, 1, 4); TK(1, 0, 1, 4);
+  TK(0, 0, 4, 8); TK(1, 0, 4, 8); TK(0, 0, 2, 8); TK(1, 0, 2, 8); TK(0, 1, 2, 8); TK(1, 1, 2, 8);
+  TK(0, 0, 4, 2); TK(1, 0, 4, 2);
+#undef TK
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// two-part launch for the halo overlap: part 0 = interior tiles (no ghost candidates), part 1 = boundary tiles and,
+// when evflag, the energy/virial sum over all tiles
+int mmd_lj_compute_tiles_split(mmd_handle* h, int evflag, int part)
+{
+  MMD_TRY(mmd_order_tiles(h));
+  MMD_TRY(h->partials.ensure((size_t)2 * h->ntiles + 8, false, h->stream));
+  if(part == 0) return launch_tiles(h, evflag, h->tile_order.p, h->ntiles_interior);
+  MMD_TRY(launch_tiles(h, evflag, h->tile_order.p + h->ntiles_interior, h->ntiles - h->ntiles_interior));
+  if(evflag) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->partials.p, h->ntiles, 2, h->d_result, 4.0, 0.5);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
 // ForceLJ::compute dispatch (ref/force_lj.cpp:72-113); eng_vdwl/virial (reference conventions) land in
 // h->d_result[0..1] when evflag
 int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
@@ -388,20 +432,10 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   const int ev = evflag ? 1 : 0, uni = h->lj_uniform ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
   int nsum = nblocks;
-  const size_t tile_lds = (size_t)3 * (h->tile_cmax + 2) * sizeof(real);
-  if(!h->halfneigh && h->tiles_ready && h->opt_tiles && uni && tile_lds <= 60 * 1024) {
+  if(mmd_lj_tiles_available(h)) {
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
-#define TK(EVv, Xv, Wv, Uv) if(ev == EVv && ex == Xv && tw == Wv && tu == Uv)                                                    \
-    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv>), dim3(xcd_grid(h->ntiles)), dim3(64 * Wv), tile_lds, h->stream, h->x.p,        \
-                       h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->ntiles, \
-                       h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
-    const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll;
-    TK(0, 0, 4, 4); TK(0, 1, 4, 4); TK(1, 0, 4, 4); TK(1, 1, 4, 4);
-    TK(0, 0, 2, 4); TK(1, 0, 2, 4); TK(0, 0, 1, 4); TK(1, 0, 1, 4);
-    TK(0, 0, 4, 8); TK(1, 0, 4, 8); TK(0, 0, 2, 8); TK(1, 0, 2, 8);
-    TK(0, 0, 4, 2); TK(1, 0, 4, 2);
-#undef TK
+    MMD_TRY(launch_tiles(h, evflag, nullptr, h->ntiles));
   } else if(!h->halfneigh) {
     MMD_TRY(mmd_ensure_rows(h));
     MMD_TRY(h->partials.ensure((size_t)2 * nblocks + 8, false, h->stream));

@@ -139,7 +139,11 @@ struct mmd_handle {
   bool rows_ready = false;               // the wave-interleaved 32-bit rows (`neigh`, wave_max) are materialised
   int ntiles = 0, tile_tmax = 0;          // tile_tmax: largest candidate count of any block (LDS sizing)
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
-  DevArr<int> tile_cand, tile_ncand, tile_cnt;   // per-tile union of referenced candidates (compact, global indices)
+  DevArr<int> tile_cand, tile_ncand, tile_cnt;
+  DevArr<int> tile_ghost, tile_order;     // per tile: references a ghost atom?; tiles ordered interior-first
+  int ntiles_interior = 0;
+  hipEvent_t ev_x_ready = nullptr, ev_halo_done = nullptr;
+  int opt_overlap = 1;   // per-tile union of referenced candidates (compact, global indices)
   int tile_cstride = 0, tile_cmax = 0;
   DevArr<unsigned short> nl16;
   int opt_tiles = 1;
@@ -198,6 +202,9 @@ int mmd_bin_atoms(mmd_handle* h, int count);
 int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_zero_forces(mmd_handle* h, int n);
+int mmd_lj_tiles_available(mmd_handle* h);
+int mmd_lj_compute_tiles_split(mmd_handle* h, int evflag, int part);   // part 0: interior tiles, 1: boundary tiles + energy sum
+int mmd_order_tiles(mmd_handle* h);
 int mmd_ensure_rows(mmd_handle* h);       // materialise `neigh` from the tile form when a kernel needs it
 int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int dest, void* drecv, size_t nrecv, int src);
 int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv, int src);

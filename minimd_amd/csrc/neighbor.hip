@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
                                                        real cutneighsq, int maxneighs, int cstride, const int* __restrict__ tile_of_block,
                                                        int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
                                                        int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
-                                                       int* __restrict__ tile_max, int* __restrict__ flags,
+                                                       int* __restrict__ tile_max, int* __restrict__ tile_ghost, int* __restrict__ flags,
                                                        unsigned long long* __restrict__ total_out, int ablate)
 {
   extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -495,10 +495,12 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     if(ablate & 8) continue;
     // ---- union of the candidates referenced by this tile -> compact list + remap table
     int base = 0;
+    bool refs_ghost = false;
 #pragma unroll
     for(int c = 0; c < NB_CHUNKS; c++) {
       if(c < nchunks) {
         const bool bit = (usedbits >> c) & 1u;
+        refs_ghost = refs_ghost || (bit && cj[c] >= nlocal);
         const unsigned long long m = __ballot(bit);
         const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if(bit) {
@@ -520,9 +522,11 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     for(int k = 0; k < kmax; k++)                 // stored as the LDS byte offset of the {x,y,z} record (slot * 3 reals)
       out[(size_t)k * 64] = (unsigned short)((k < lim ? remap[rows[k * 64 + lane]] : (unsigned short)base) * NB_SLOT_BYTES);
     const long long tsum = wave_sum((long long)myn);
+    const bool any_ghost = __ballot(refs_ghost) != 0ull;
     if(lane == 0) {
       tile_max[tile] = kmax;
       tile_ncand[tile] = base;
+      tile_ghost[tile] = any_ghost ? 1 : 0;
       atomicMax(&flags[0], maxn);
       atomicMax(&flags[2], base);
       atomicAdd(total_out, (unsigned long long)tsum);
@@ -631,6 +635,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     MMD_TRY(h->tile_max.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_ncand.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_cnt.ensure((size_t)nt + 2, false, h->stream));
+    MMD_TRY(h->tile_ghost.ensure((size_t)nt + 2, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64;
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
     hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p);
@@ -642,7 +647,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
       hipLaunchKernelGGL(k_build_tiles, dim3(xcd_grid(nblocks)), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p, g, nblocks, nlocal, h->cutneighsq,
                          h->maxneighs, h->tile_cstride, h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,
-                         h->tile_max.p, h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate);
+                         h->tile_max.p, h->tile_ghost.p, h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -661,6 +666,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       h->tile_cmax = h->h_flags[2];
       h->tiles_ready = true;
       h->neigh_nlocal = nlocal;
+      h->ntiles_interior = -1;              // interior/boundary order is derived on demand (multi-rank overlap)
       return 0;
     }
     if(want_tiles) { mmd_set_error("mmd_neighbor_build: neighbor rows keep overflowing (maxneighs=%d)", h->maxneighs); return -1; }

@@ -169,14 +169,16 @@ def test_two_ranks_match_one_rank(half, port, tmp_path):
     o.close()
 
 
-def test_rccl_loopback_single_rank():
+@pytest.mark.parametrize("lists", [["--half_neigh", 1, "-gn", 1], ["--half_neigh", 0]])
+def test_rccl_loopback_single_rank(lists):
     """exercise the production transport calls (ncclCommInitRank, grouped ncclSend/ncclRecv, ncclAllReduce) on ONE
-    GPU: every periodic self-swap of borders / communicate / reverse_communicate is forced through RCCL"""
-    o = Oracle(["-s", 6, "-n", 40, "--half_neigh", 1, "-gn", 1])
+    GPU: every periodic self-swap of borders / communicate / reverse_communicate is forced through RCCL; with full
+    lists this also runs the overlapped step (halo on the comm stream under the interior tiles)"""
+    o = Oracle(["-s", 8, "-n", 40] + lists)
     o.initial(); o.run()
     ref = o.rows()
     m = mm()
-    s = m.Sim(["-s", 6, "-n", 40, "--half_neigh", 1, "-gn", 1])
+    s = m.Sim(["-s", 8, "-n", 40] + lists)
     h = s.handle
     h.init_rccl(h.unique_id(), 0, 1)
     h.set_option("force_transport", 1)
@@ -188,6 +190,24 @@ def test_rccl_loopback_single_rank():
     nl, ng, _ = h.counts()
     assert (nl, ng) == (o.nlocal(), o.nghost())
     s.close(); o.close()
+
+
+def test_overlap_split_equals_single_launch():
+    """interior + boundary tile launches (the multi-GPU overlap path) give bit-identical forces to one launch"""
+    m = mm()
+    rows = {}
+    for ov in (1, 0):
+        s = m.Sim(["-s", 12, "-n", 60, "--half_neigh", 0])
+        h = s.handle
+        h.init_rccl(h.unique_id(), 0, 1)
+        h.set_option("force_transport", 1)
+        h.set_option("overlap", ov)
+        s.initial(); s.run()
+        rows[ov] = (s.rows(), h.download()["f"].copy(), h.download()["x"].copy())
+        s.close()
+    assert rows[0][0] == rows[1][0]
+    np.testing.assert_array_equal(rows[0][1], rows[1][1])
+    np.testing.assert_array_equal(rows[0][2], rows[1][2])
 
 
 # ---- BASELINE.json sizes: golden rows + size-independent properties -----------------------------------------
