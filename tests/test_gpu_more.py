@@ -246,3 +246,51 @@ def test_config_e_sp_half_scaled_down():
     ref = sim_rows(["-s", 48, "-n", 100, "--half_neigh", 0])
     rows = sim_rows(["-s", 48, "-n", 100, "--half_neigh", 1], precision="sp")
     assert ref_pass_rule(ref, rows, 4 * 48 ** 3, 4)[0]
+
+
+# ---- the drop-in executable: same CLI / stdout grammar as ref/ljs.cpp ---------------------------------------
+def parse_thermo(text):
+    rows, on = [], False
+    for line in text.splitlines():
+        if line.startswith("# Timestep"):
+            on = True
+            continue
+        if line.startswith("# Performance Summary"):
+            break
+        if on and len(line.split()) >= 4:
+            p = line.split()
+            rows.append((int(p[0]), float(p[1]), float(p[2]), float(p[3])))
+    return rows
+
+
+@pytest.mark.parametrize("exe,deck,extra", [("miniMD_dp", "in.lj.miniMD", ["--half_neigh", "0"]), ("miniMD_dp", "in.eam.miniMD", ["--half_neigh", "0"]),
+                                            ("miniMD_sp", "in.lj.miniMD", ["--half_neigh", "1"])])
+def test_executable_stdout_grammar_and_rows(exe, deck, extra):
+    """what ref/run_one_test greps: '# Atoms:' $3, 'System size' field 10, '# Size of float' $5, the thermo block
+    between '# Timestep T' and '# Performance Summary', and the PERF_SUMMARY row (unknown flags such as -dm ignored)"""
+    path = os.path.join(REPO, "minimd_amd", "bin", exe)
+    r = subprocess.run([path, "-t", "1", "-s", "10", "-n", "200", "--yaml_output", "0", "-dm", "-i", deck] + extra,
+                       cwd=os.path.join(REPO, "data"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    atoms = [l for l in out.splitlines() if "# Atoms:" in l][0].split()
+    assert atoms[2] == "4000"
+    size = [l for l in out.splitlines() if "System size" in l][0].split()
+    assert size[9] == "10"
+    assert [l for l in out.splitlines() if "Size of float" in l][0].split()[4] == ("8" if exe.endswith("dp") else "4")
+    rows = parse_thermo(out)
+    assert [r_[0] for r_ in rows] == [0, 100, 200]
+    perf = [l for l in out.splitlines() if "PERF_SUMMARY" in l and not l.startswith("#")][0].split()
+    assert perf[2] == "200" and perf[3] == "4000" and float(perf[9]) > 0
+    key = "4k.eam" if "eam" in deck else "4k.lj"
+    ref = [tuple(x) for x in PUBLISHED[key]["rows"] if x[0] <= 200]
+    ok, frac = ref_pass_rule(ref, rows, 4000, 8 if exe.endswith("dp") else 4, eam="eam" in deck)
+    assert ok, frac
+    if exe.endswith("dp"):
+        rows_close(rows, ref, 2e-6)
+
+
+def test_executable_reports_errors_like_the_reference():
+    path = os.path.join(REPO, "minimd_amd", "bin", "miniMD_dp")
+    r = subprocess.run([path, "-i", "does_not_exist.miniMD"], cwd=os.path.join(REPO, "data"), capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "Cannot open" in r.stdout          # ref/input.cpp:62-66 prints and exits 0
