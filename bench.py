@@ -85,17 +85,24 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        if os.environ.get("MMD_BENCH_TRANSPORT") == "gloo":
+            # debugging aid (e.g. two ranks sharing one GPU): host-staged halos over gloo instead of RCCL
+            from minimd_amd import api
+            from minimd_amd.transport import GlooTransport
+            _tr = GlooTransport()
+            api.sim_set_host_transport(_tr.sendrecv, _tr.allreduce, "dp")
         # data plane: the library's own RCCL communicator (ncclSend/ncclRecv halos over xGMI)
         L = minimd_amd.load_library("dp")
-        obj = [None]
-        if rank == 0:
-            import ctypes
-            buf = ctypes.create_string_buffer(128)
-            assert L.mmd_comm_unique_id(buf) == 0, L.mmd_last_error()
-            obj = [buf.raw]
-        dist.broadcast_object_list(obj, src=0)
-        L.mmd_sim_set_unique_id(obj[0])
+        if os.environ.get("MMD_BENCH_TRANSPORT") != "gloo":
+            obj = [None]
+            if rank == 0:
+                import ctypes
+                buf = ctypes.create_string_buffer(128)
+                assert L.mmd_comm_unique_id(buf) == 0, L.mmd_last_error()
+                obj = [buf.raw]
+            dist.broadcast_object_list(obj, src=0)
+            L.mmd_sim_set_unique_id(obj[0])
 
     # weak scaling: per-GPU sub-box stays size^3 unit cells; Comm::setup factorises the ranks 1/2/4/8 ->
     # 1x1x1 / 2x1x1 / 2x2x1 / 2x2x2 for these boxes (min surface, ref/comm.cpp:80-126)
