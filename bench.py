@@ -140,6 +140,12 @@ def main():
     bpa = algorithmic_bytes_per_atom(kbar, nghost / max(nlocal, 1))
     k_ms = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
     achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if world == 1 and args.size == 80 and os.path.exists(tpath):
+        # HBM bytes per launch of the same kernel on the same workload from the committed PMC passes
+        # (rocprofv3 cannot be run from inside the timed process); see profiles/README.md
+        traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
     out = {
         "metric": "Matom-steps/sec (LJ, full-neigh)", "value": natoms * args.steps / dt / 1e6, "unit": "Matom-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -147,8 +153,8 @@ def main():
         "config": {"workload": "in.lj.miniMD -s %d per GPU (global %dx%dx%d cells, %d atoms), full neighbor list, DP, "
                                "reneigh 20, thermo 100" % (args.size, nx, ny, nz, natoms),
                    "parallelism": "spatial %dx%dx%d, RCCL p2p halos" % dims},
-        "roofline": {"bound": "hbm", "kernel": "k_lj_full (ForceLJ::compute_fullneigh)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": "k_lj_full_tile (ForceLJ::compute_fullneigh)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "kernel_ms": k_ms, "launches": tm["force_launches"], "bytes_per_atom": bpa, "atoms_per_launch": nlocal,
                      "kbar": kbar, "ghost_ratio": nghost / max(nlocal, 1)},
         "phases_s": {k: tm[k] for k in ("total", "comm", "force", "neigh", "extra")},
