@@ -176,6 +176,208 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_force(const real4* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Tile forms of the two sweeps (same data structure as k_lj_full_tile, force_lj.hip): the tile's candidate
+// union is staged in LDS ({x,y,z} records, and fp for sweep 2) next to the re-packed spline knots; every pair
+// gathers from LDS only. EAM_TW wavefronts per tile split the k range of the same 64 atoms.
+// ---------------------------------------------------------------------------------------------------
+#define EAM_TW 4
+#define EAM_TU 4
+#define EAM_STAGE 4
+
+template <int EV>
+__global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
+    const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
+    const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
+    const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
+    const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, real rdr, real rdrho, real* __restrict__ fp,
+    double* __restrict__ partials)
+{
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  __shared__ real s_part[64 * (EAM_TW - 1) + 1];
+  __shared__ double s_red[16];
+  constexpr int NT = 64 * EAM_TW;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  real* s_tab = (real*)s_raw;                           // [knot][4]: coeffs 3..6 of rhor_spline
+  unsigned char* s_pos = s_raw + (size_t)(nr + 1) * 4 * sizeof(real);   // {x,y,z} records, byte offsets = nl16 values
+  for(int t = tid; t < (nr + 1) * 4; t += NT) s_tab[t] = rhor_spline[(t >> 2) * 7 + 3 + (t & 3)];
+  // persistent workgroups: the knots are staged once, then the workgroup walks its share of the tiles of "its" XCD
+  // (workgroup b runs on XCD b % 8; XCD e owns the contiguous tile range [e*per, (e+1)*per))
+  const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;
+  for(int tq = blockIdx.x >> 3; tq < per_xcd; tq += wg_per_xcd) {
+  const int tile = (blockIdx.x & 7) * per_xcd + tq;
+  if(tile >= ntiles) break;
+  __syncthreads();                                      // previous tile's readers are done with s_pos / s_part
+  const int ncand = tile_ncand[tile];
+  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  for(int tb = tid; tb <= ncand; tb += EAM_STAGE * NT) {
+    int jj[EAM_STAGE];
+#pragma unroll
+    for(int u = 0; u < EAM_STAGE; u++) { const int t = tb + u * NT; jj[u] = t < ncand ? cl[t] : nall; }
+    real4 pp[EAM_STAGE];
+#pragma unroll
+    for(int u = 0; u < EAM_STAGE; u++) pp[u] = x[jj[u]];
+#pragma unroll
+    for(int u = 0; u < EAM_STAGE; u++) {
+      const int t = tb + u * NT;
+      if(t <= ncand) { real* q = (real*)s_pos + 3 * t; q[0] = pp[u].x; q[1] = pp[u].y; q[2] = pp[u].z; }
+    }
+  }
+  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
+  if(i >= nlocal) i = -1;
+  const real4 xi = x[i >= 0 ? i : 0];
+  const int kmax = tile_max[tile];
+  const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
+  const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
+  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  __syncthreads();
+  real rhoi = 0;
+  for(int k = k0; k < k1; k += EAM_TU) {
+    int sl[EAM_TU];
+#pragma unroll
+    for(int u = 0; u < EAM_TU; u++) sl[u] = np[(size_t)(k + u) * 64];
+#pragma unroll
+    for(int u = 0; u < EAM_TU; u++) {
+      const real* q = (const real*)(s_pos + sl[u]);
+      const real dx = xi.x - q[0], dy = xi.y - q[1], dz = xi.z - q[2];
+      const real rsq = dx * dx + dy * dy + dz * dz;
+      if(rsq < cutforcesq) {
+        real p = sqrt(rsq) * rdr + (real)1.0;
+        int m = (int)p;
+        m = m < nr - 1 ? m : nr - 1;
+        p -= m;
+        p = p < (real)1.0 ? p : (real)1.0;
+        const real* c = &s_tab[m * 4];
+        rhoi += ((c[0] * p + c[1]) * p + c[2]) * p + c[3];
+      }
+    }
+  }
+  if(wv > 0) s_part[64 * (wv - 1) + lane] = rhoi;
+  __syncthreads();
+  double e_acc = 0;
+  if(wv == 0 && i >= 0) {
+#pragma unroll
+    for(int q = 0; q < EAM_TW - 1; q++) rhoi += s_part[64 * q + lane];
+    real p = (real)1.0 * rhoi * rdrho + (real)1.0;
+    int m = (int)p;
+    m = max(1, min(m, nrho - 1));
+    p -= m;
+    p = p < (real)1.0 ? p : (real)1.0;
+    const real* c = &frho_spline[m * 7];
+    fp[i] = (c[0] * p + c[1]) * p + c[2];
+    if(EV) e_acc = (double)(((c[3] * p + c[4]) * p + c[5]) * p + c[6]);
+  }
+  if(EV) {
+    const double es = block_sum(e_acc, s_red);
+    if(tid == 0) partials[3 * (size_t)tile] = es;
+  }
+  }   // tile loop
+}
+
+template <int EV>
+__global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
+    const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
+    const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
+    const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
+    const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
+    double* __restrict__ partials)
+{
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  __shared__ real s_f[3 * 64 * (EAM_TW - 1) + 3];
+  __shared__ double s_red[16];
+  constexpr int NT = 64 * EAM_TW;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  real* s_tab = (real*)s_raw;                           // [knot][10]: rhor 0..2, z2r 0..6
+  unsigned char* s_pos = s_raw + (size_t)(nr + 1) * 10 * sizeof(real);
+  for(int t = tid; t < (nr + 1) * 10; t += NT) {
+    const int m = t / 10, c = t % 10;
+    s_tab[t] = c < 3 ? rhor_spline[m * 7 + c] : z2r_spline[m * 7 + (c - 3)];
+  }
+  const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;     // persistent workgroups, see k_eam_density_tile
+  for(int tq = blockIdx.x >> 3; tq < per_xcd; tq += wg_per_xcd) {
+  const int tile = (blockIdx.x & 7) * per_xcd + tq;
+  if(tile >= ntiles) break;
+  __syncthreads();
+  const int ncand = tile_ncand[tile];
+  real* s_fp = (real*)(s_pos + (size_t)3 * (cmax + 2) * sizeof(real));        // fp of the candidates, indexed by slot
+  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  for(int tb = tid; tb <= ncand; tb += EAM_STAGE * NT) {
+    int jj[EAM_STAGE];
+#pragma unroll
+    for(int u = 0; u < EAM_STAGE; u++) { const int t = tb + u * NT; jj[u] = t < ncand ? cl[t] : nall; }
+    real4 pp[EAM_STAGE];
+    real ff[EAM_STAGE];
+#pragma unroll
+    for(int u = 0; u < EAM_STAGE; u++) { pp[u] = x[jj[u]]; ff[u] = fp[jj[u]]; }
+#pragma unroll
+    for(int u = 0; u < EAM_STAGE; u++) {
+      const int t = tb + u * NT;
+      if(t <= ncand) { real* q = (real*)s_pos + 3 * t; q[0] = pp[u].x; q[1] = pp[u].y; q[2] = pp[u].z; s_fp[t] = ff[u]; }
+    }
+  }
+  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
+  if(i >= nlocal) i = -1;
+  const real4 xi = x[i >= 0 ? i : 0];
+  const real fpi = fp[i >= 0 ? i : 0];
+  const int kmax = tile_max[tile];
+  const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
+  const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
+  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  __syncthreads();
+  real fx = 0, fy = 0, fz = 0;
+  double e_acc = 0, v_acc = 0;
+  for(int k = k0; k < k1; k += EAM_TU) {
+    int sl[EAM_TU];
+#pragma unroll
+    for(int u = 0; u < EAM_TU; u++) sl[u] = np[(size_t)(k + u) * 64];
+#pragma unroll
+    for(int u = 0; u < EAM_TU; u++) {
+      const real* q = (const real*)(s_pos + sl[u]);
+      const real dx = xi.x - q[0], dy = xi.y - q[1], dz = xi.z - q[2];
+      const real rsq = dx * dx + dy * dy + dz * dz;
+      if(rsq < cutforcesq) {
+        const real fpj = s_fp[sl[u] / (3 * (int)sizeof(real))];
+        const real r = sqrt(rsq);
+        real p = r * rdr + (real)1.0;
+        int m = (int)p;
+        m = m < nr - 1 ? m : nr - 1;
+        p -= m;
+        p = p < (real)1.0 ? p : (real)1.0;
+        const real* c = &s_tab[m * 10];
+        const real rhoip = (c[0] * p + c[1]) * p + c[2];
+        const real z2p = (c[3] * p + c[4]) * p + c[5];
+        const real z2 = ((c[6] * p + c[7]) * p + c[8]) * p + c[9];
+        const real recip = (real)1.0 / r;
+        const real phi = z2 * recip;
+        const real phip = z2p * recip - phi * recip;
+        const real psip = fpi * rhoip + fpj * rhoip + phip;
+        real fpair = -psip * recip;
+        fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
+        if(EV) {
+          fpair *= (real)0.5;
+          v_acc += (double)(dx * dx * fpair + dy * dy * fpair + dz * dz * fpair);
+          e_acc += (double)((real)0.5 * phi);
+        }
+      }
+    }
+  }
+  if(wv > 0) { real* d = s_f + 3 * 64 * (wv - 1); d[lane] = fx; d[64 + lane] = fy; d[128 + lane] = fz; }
+  __syncthreads();
+  if(wv == 0 && i >= 0) {
+#pragma unroll
+    for(int q = 0; q < EAM_TW - 1; q++) { const real* d = s_f + 3 * 64 * q; fx += d[lane]; fy += d[64 + lane]; fz += d[128 + lane]; }
+    f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz;
+  }
+  if(EV) {
+    if(i < 0) { e_acc = 0; v_acc = 0; }
+    const double es = block_sum(e_acc, s_red);
+    const double vs = block_sum(v_acc, s_red);
+    if(tid == 0) { partials[3 * (size_t)tile + 1] = es; partials[3 * (size_t)tile + 2] = vs; }
+  }
+  }   // tile loop
+}
+
 // eng_vdwl = 2*(E_embed + sum phi/2) (ref/force_eam.cpp:446), virial = sum
 __global__ __launch_bounds__(1024) void k_eam_sum(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
 {
@@ -252,9 +454,54 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   if(h->halfneigh) { mmd_set_error("EAM with half neighbor lists is not implemented on the device yet (use --half_neigh 0)"); return -1; }
   const int nlocal = h->nlocal, nall = nlocal + h->nghost;
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
+  MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
+  // ---- tile path: LDS-staged candidates + knots (uniform tables, device-built list)
+  const size_t tl1 = (size_t)(h->nr + 1) * 4 * sizeof(real) + (size_t)3 * (h->tile_cmax + 2) * sizeof(real);
+  const size_t tl2 = (size_t)(h->nr + 1) * 10 * sizeof(real) + (size_t)4 * (h->tile_cmax + 2) * sizeof(real);
+  if(h->tiles_ready && h->opt_tiles && h->eam_uniform && tl2 <= 144 * 1024) {
+    const int nt = h->ntiles;
+    MMD_TRY(h->partials.ensure((size_t)3 * nt + 8, false, h->stream));
+    // persistent grids: as many workgroups as fit the LDS budget of every CU (multiple of 8 for the XCD split)
+    const int cus = h->prop.multiProcessorCount;
+    const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl1 + 4096)))) / 8 * 8);
+    const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 8192)))) / 8 * 8);
+    static bool attr_set = false;
+    if(!attr_set) {            // > 64 KiB of dynamic LDS needs the opt-in
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      attr_set = true;
+    }
+#define DT(EVv) hipLaunchKernelGGL((k_eam_density_tile<EVv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
+                                   h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \
+                                   h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
+                                   h->nrho, h->rdr, h->rdrho, h->fp.p, h->partials.p)
+#define FT(EVv) hipLaunchKernelGGL((k_eam_force_tile<EVv>), dim3(pgrid2), dim3(64 * EAM_TW), tl2, h->stream, h->x.p, h->binned.p,       \
+                                   h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \
+                                   h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
+                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p)
+    if(evflag) DT(1); else DT(0);
+    HIP_TRY(hipGetLastError());
+    MMD_TRY(eam_fp_halo(h));
+    if(evflag) FT(1); else FT(0);
+#undef DT
+#undef FT
+    HIP_TRY(hipGetLastError());
+    if(evflag) {
+      hipLaunchKernelGGL(k_eam_sum, dim3(1), dim3(1024), 0, h->stream, h->partials.p, nt, h->d_result);
+      HIP_TRY(hipGetLastError());
+      if(eng || vir) {
+        HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if(eng) *eng = h->h_result[0];
+        if(vir) *vir = h->h_result[1];
+      }
+    }
+    return 0;
+  }
   MMD_TRY(mmd_ensure_rows(h));
   const int nblocks = div_up(nlocal, MMD_BLOCK);
-  MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
   MMD_TRY(h->partials.ensure((size_t)3 * nblocks + 8, false, h->stream));
   const size_t lds1 = h->eam_uniform ? (size_t)(h->nr + 1) * 4 * sizeof(real) : 0;
   const size_t lds2 = h->eam_uniform ? (size_t)(h->nr + 1) * 12 * sizeof(real) : 0;
