@@ -29,6 +29,7 @@ struct mmd_sim {
   int nbin[3] = {1, 1, 1};
   int natoms = 0;
   int sort_every = 0;
+  int dev_half = 0;          // neighbor-list style used on the device (may differ from the requested one for EAM)
   mmd_float prd[3], mass = 1, dt = 0, dtforce = 0;
   ThermoScales th;
   int steps_done = 0;        // steps integrated so far (bench slices)
@@ -146,6 +147,7 @@ static void thermo_row(void* ctx, int step, double sum_mv2, double eng_vdwl, dou
   const ThermoScales& th = s->th;
   const mmd_float t = (mmd_float)sum_mv2 * th.t_scale;
   mmd_float e_act = (mmd_float)eng_vdwl;
+  if(s->halfneigh && !s->dev_half) e_act *= 0.5;       // full-list kernels standing in for a half-list request (EAM)
   if(s->halfneigh) e_act *= 2.0;
   e_act *= th.e_scale;
   const mmd_float eng = e_act / s->natoms;
@@ -199,7 +201,9 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     // unknown flags are ignored, like the reference (run_one_test passes -dm)
   }
   if(s->in.has_datafile) { mmd_set_error("LAMMPS data files (-f) are not supported yet"); if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
-  if(s->halfneigh < 0) { mmd_set_error("--half_neigh -1 (original miniMD force) is not available in the HIP variant"); if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
+  // --half_neigh -1 ("original miniMD force", ref/force_lj.cpp:118-176) computes the same half-list physics with
+  // force on both partners and a reverse halo; on the device it is the half-list + ghost-newton path
+  if(s->halfneigh < 0) s->ghost_newton = s->in.forcetype == 1 ? 0 : 1;
   if(s->in.forcetype == 1 && s->ghost_newton == 1) {
     if(s->me == 0 && !quiet) printf("# EAM currently requires '--ghost_newton 0'; Changing setting now.\n");
     s->ghost_newton = 0;
@@ -234,7 +238,11 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     if(g_have_id) memcpy(id, g_id, 128); else SIM_TRY(exchange_id_tcp(s->me, s->nprocs, id));
     SIM_TRY(mmd_comm_init_rccl(h, id, s->me, s->nprocs));
   }
-  SIM_TRY(mmd_neighbor_setup(h, s->nbin, s->in.neigh_cut, s->halfneigh, s->ghost_newton, s->ntypes));
+  // Device list style. LJ: as requested. EAM with half lists (the reference's serial-only path,
+  // ref/force_eam.cpp:94-270) runs on the full-list kernels: forces are identical and eng_vdwl is converted to the
+  // half-list convention (full lists report 2x, ref/force_eam.cpp:446 vs :269), so thermo rows are unchanged.
+  s->dev_half = (s->in.forcetype == 1) ? 0 : (s->halfneigh != 0 ? 1 : 0);
+  SIM_TRY(mmd_neighbor_setup(h, s->nbin, s->in.neigh_cut, s->dev_half, s->ghost_newton, s->ntypes));
   s->dtforce = 0.5 * s->dt;                        // Integrate::setup (ref/integrate.cpp:41-44)
   const int nt2 = s->ntypes * s->ntypes;
   if(s->in.forcetype == 0) {
@@ -327,7 +335,7 @@ static int force_and_row(mmd_sim* s, int step)
   mmd_handle* h = s->h;
   double eng = 0, vir = 0, mv2 = 0;
   MMD_TRY(mmd_force_compute(h, 1, &eng, &vir));
-  if(s->halfneigh && s->ghost_newton) MMD_TRY(mmd_comm_reverse_communicate(h));
+  if(s->dev_half && s->ghost_newton) MMD_TRY(mmd_comm_reverse_communicate(h));
   MMD_TRY(mmd_thermo_temperature(h, &mv2));
   double vals[3] = {mv2, eng, vir};
   MMD_TRY(mmd_transport_allreduce(h, vals, 3));
@@ -361,7 +369,7 @@ extern "C" int mmd_sim_run(mmd_sim* s)
   s->steps_done += s->in.ntimes;
   // ref/ljs.cpp:477-483 + Thermo::compute(-1) gating (ref/thermo.cpp:80)
   if(!(nstat > 0 && s->in.ntimes % nstat == 0)) MMD_TRY(force_and_row(s, s->in.ntimes));
-  else { MMD_TRY(mmd_force_compute(h, 1, nullptr, nullptr)); if(s->halfneigh && s->ghost_newton) MMD_TRY(mmd_comm_reverse_communicate(h)); }
+  else { MMD_TRY(mmd_force_compute(h, 1, nullptr, nullptr)); if(s->dev_half && s->ghost_newton) MMD_TRY(mmd_comm_reverse_communicate(h)); }
   return 0;
 }
 

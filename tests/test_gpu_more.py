@@ -347,3 +347,15 @@ def test_stale_list_and_bad_arguments_are_errors():
     with pytest.raises(m.MMDError):
         h.set_option("no_such_option", 1)
     h.close()
+
+
+def test_eam_half_request_and_original_force_alias():
+    """EAM with the reference's default --half_neigh 1 (serial-only path there) is served by the full-list kernels with
+    the energy converted to the half-list convention: rows equal the reference's half-list run; --half_neigh -1
+    (original miniMD force) is the half + ghost-newton path"""
+    ent = REFRUNS["eam_s10_half_n300"]
+    rows = sim_rows([a for a in ent["args"]])
+    rows_close(rows, ent["rows"], 2e-6)
+    ref = REFRUNS["lj_s10_half_gn1_n1000"]
+    rows = sim_rows(["-s", 10, "-n", 300, "--half_neigh", -1])
+    rows_close(rows, [r_ for r_ in ref["rows"] if r_[0] <= 300], 2e-6)
