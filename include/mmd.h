@@ -196,6 +196,9 @@ int mmd_sim_initial(mmd_sim* s);                  /* ref/ljs.cpp:445-468 */
 int mmd_sim_run(mmd_sim* s);                      /* ref/ljs.cpp:470-483 */
 int mmd_sim_run_steps(mmd_sim* s, int nsteps, double* seconds);   /* timed re-entrant slice for bench.py */
 int mmd_sim_print_perf(mmd_sim* s);               /* ref/ljs.cpp:485-495 */
+/* YAML report of -o / --yaml_output and --yaml_screen: output() + stats() (ref/output.cpp:48-547) */
+int mmd_sim_output(mmd_sim* s, int screen_yaml);
+int mmd_sim_wants_yaml(mmd_sim* s, int* screen_yaml);   /* returns the -o level parsed from the command line */
 int mmd_sim_rows(mmd_sim* s, int* nrows, int* steps, double* t, double* u, double* p, int maxrows);
 int mmd_sim_natoms(mmd_sim* s);
 mmd_handle* mmd_sim_handle(mmd_sim* s);

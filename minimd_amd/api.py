@@ -80,7 +80,7 @@ def load_library(precision="dp"):
         "mmd_eam_tables_from_file": [C.c_char_p, I, ip, ip, ip, ip, rp, rp, rp, rp, rp, rp, rp],
         "mmd_sim_set_unique_id": [C.c_char_p], "mmd_sim_set_host_transport": [P, P, P], "mmd_sim_create": [I, C.POINTER(C.c_char_p), I, C.POINTER(P)],
         "mmd_sim_initial": [P], "mmd_sim_run": [P], "mmd_sim_run_steps": [P, I, dp], "mmd_sim_print_perf": [P],
-        "mmd_sim_rows": [P, ip, ip, dp, dp, dp, I], "mmd_sim_natoms": [P], "mmd_sim_destroy": [P],
+        "mmd_sim_rows": [P, ip, ip, dp, dp, dp, I], "mmd_sim_output": [P, I], "mmd_sim_wants_yaml": [P, ip], "mmd_sim_natoms": [P], "mmd_sim_destroy": [P],
     }
     for name, args in sig.items():
         fn = getattr(L, name)          # AttributeError here = symbol declared in include/mmd.h is not exported

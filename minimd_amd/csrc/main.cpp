@@ -14,6 +14,8 @@ int main(int argc, char** argv)
     return 1;
   }
   mmd_sim_print_perf(sim);
+  int screen = 0;
+  if(mmd_sim_wants_yaml(sim, &screen)) mmd_sim_output(sim, screen);          // ref/ljs.cpp:497-498
   mmd_sim_destroy(sim);
   return 0;
 }

@@ -7,8 +7,11 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -25,7 +28,7 @@ struct mmd_sim {
   mmd_input in;
   std::string input_file = "in.lj.miniMD";
   int me = 0, nprocs = 1, quiet = 0;
-  int num_threads = 1, ntypes = 4, halfneigh = 1, ghost_newton = 1, sort = -1, yaml_output = 0;
+  int num_threads = 1, ntypes = 4, halfneigh = 1, ghost_newton = 1, sort = -1, yaml_output = 0, yaml_screen = 0;
   int nbin[3] = {1, 1, 1};
   int natoms = 0;
   int sort_every = 0;
@@ -193,6 +196,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     else if(is_flag(a, "-sse") && has) ++i;
     else if(is_flag(a, "--sort") && has) s->sort = atoi(argv[++i]);
     else if(is_flag(a, "-o", "--yaml_output") && has) s->yaml_output = atoi(argv[++i]);
+    else if(is_flag(a, "--yaml_screen")) s->yaml_screen = 1;
     else if(is_flag(a, "-f", "--data_file") && has) { s->in.has_datafile = 1; strncpy(s->in.datafile, argv[++i], sizeof(s->in.datafile) - 1); }
     else if(is_flag(a, "-u", "--units") && has) s->in.units = strcmp(argv[++i], "metal") == 0 ? 1 : 0;
     else if(is_flag(a, "-p", "--force") && has) s->in.forcetype = strcmp(argv[++i], "eam") == 0 ? 1 : 0;
@@ -402,6 +406,158 @@ extern "C" int mmd_sim_print_perf(mmd_sim* s)
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// YAML report of `-o 1` / `--yaml_screen` — counterpart of output() + stats() (ref/output.cpp:48-547): same keys,
+// same sections (run_configuration, thermodynamic_output incl. the energy-conservation ratio, time, per-rank
+// histograms of timings and of Nlocal / Nghost / Nswaps / Neighs, total neighbor count).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Emit {                       // every line goes to the file and, when asked, to stdout as well
+  FILE* fp; bool screen;
+  void operator()(const char* fmt, ...) const
+  {
+    va_list ap;
+    if(fp) { va_start(ap, fmt); vfprintf(fp, fmt, ap); va_end(ap); }
+    if(screen) { va_start(ap, fmt); vfprintf(stdout, fmt, ap); va_end(ap); }
+  }
+};
+// all ranks' values of one scalar on every rank (sum-allreduce of a one-hot vector, 16 ranks per call)
+int gather_all(mmd_sim* s, double mine, std::vector<double>& all)
+{
+  all.assign(s->nprocs, 0.0);
+  for(int base = 0; base < s->nprocs; base += 16) {
+    double buf[16] = {0};
+    const int n = std::min(16, s->nprocs - base);
+    if(s->me >= base && s->me < base + n) buf[s->me - base] = mine;
+    MMD_TRY(mmd_transport_allreduce(s->h, buf, n));
+    for(int i = 0; i < n; i++) all[base + i] = buf[i];
+  }
+  return 0;
+}
+// ave / max / min + 10-bin histogram over ranks (stats(), ref/output.cpp:496-547)
+void histogram(const std::vector<double>& v, double* ave, double* mx, double* mn, int histo[10])
+{
+  *mn = 1.0e20; *mx = -1.0e20; *ave = 0.0;
+  for(double d : v) { *ave += d; if(d < *mn) *mn = d; if(d > *mx) *mx = d; }
+  *ave /= (double)v.size();
+  for(int i = 0; i < 10; i++) histo[i] = 0;
+  const double del = *mx - *mn;
+  for(double d : v) {
+    int m = del == 0.0 ? 0 : static_cast<int>((d - *mn) / del * 10);
+    if(m > 9) m = 9;
+    histo[m]++;
+  }
+}
+}  // namespace
+
+extern "C" int mmd_sim_output(mmd_sim* s, int screen_yaml)
+{
+  if(!s) { mmd_set_error("null sim"); return -1; }
+  mmd_handle* h = s->h;
+  // enforce PBC, then check for lost atoms (ref/output.cpp:60-85)
+  MMD_TRY(mmd_atom_pbc(h));
+  int nlocal = 0, nghost = 0;
+  MMD_TRY(mmd_atom_counts(h, &nlocal, &nghost, nullptr));
+  std::vector<mmd_float> x((size_t)3 * (nlocal + nghost) + 3);
+  MMD_TRY(mmd_atom_download(h, x.data(), nullptr, nullptr, nullptr, nullptr));
+  double counts[2] = {(double)nlocal, 0.0};
+  for(int i = 0; i < nlocal; i++)
+    for(int d = 0; d < 3; d++)
+      if(x[3 * (size_t)i + d] < 0.0 || x[3 * (size_t)i + d] >= s->prd[d]) { counts[1] += 1; break; }
+  MMD_TRY(mmd_transport_allreduce(h, counts, 2));
+  if((long long)counts[0] != s->natoms || counts[1] > 0) {
+    if(s->me == 0) { printf("Atom counts = %d %d %d\n", (int)counts[1], (int)counts[0], s->natoms); printf("ERROR: Incorrect number of atoms\n"); }
+    return 0;
+  }
+  FILE* fp = nullptr;
+  if(s->me == 0) {
+    time_t now = time(NULL);
+    struct tm lt = *localtime(&now);
+    char name[256];
+    snprintf(name, sizeof(name), "miniMD-%4d-%02d-%02d-%02d-%02d-%02d.yaml", lt.tm_year + 1900, lt.tm_mon + 1, lt.tm_mday, lt.tm_hour, lt.tm_min, lt.tm_sec);
+    fp = fopen(name, "w");
+  }
+  Emit out{fp, s->me == 0 && screen_yaml != 0};
+  out("run_configuration: \n");
+  out("  variant: %s\n", mmd_variant_string());
+  out("  mpi_processes: %i\n", s->nprocs);
+  out("  thread_teams: %i\n", 1);
+  out("  threads: %i\n", s->num_threads);
+  out("  datafile: %s\n", "None");
+  out("  units: %s\n", s->in.units == 0 ? "LJ" : "METAL");
+  out("  atoms: %i\n", s->natoms);
+  out("  atom_types: %i\n", s->ntypes);
+  out("  system_size: %2.2lf %2.2lf %2.2lf\n", (double)s->prd[0], (double)s->prd[1], (double)s->prd[2]);
+  out("  unit_cells: %i %i %i\n", s->in.nx, s->in.ny, s->in.nz);
+  out("  density: %lf\n", (double)s->in.rho);
+  out("  force_type: %s\n", s->in.forcetype == 0 ? "LJ" : "EAM");
+  out("  force_cutoff: %lf\n", (double)s->in.force_cut);
+  out("  force_params: %2.2lf %2.2lf\n", (double)s->in.epsilon, (double)s->in.sigma);
+  out("  neighbor_cutoff: %lf\n", (double)s->in.neigh_cut);
+  out("  neighbor_type: %i\n", s->halfneigh);
+  out("  neighbor_bins: %i %i %i\n", s->nbin[0], s->nbin[1], s->nbin[2]);
+  out("  neighbor_frequency: %i\n", s->in.neigh_every);
+  out("  sort_frequency: %i\n", s->sort_every);
+  out("  timestep_size: %lf\n", (double)s->dt);
+  out("  thermo_frequency: %i\n", s->in.thermo_nstat);
+  out("  ghost_newton: %i\n", s->ghost_newton);
+  out("  use_intrinsics: %i\n", 0);
+  out("  safe_exchange: %i\n", 0);
+  out("  float_size: %i\n\n", (int)sizeof(mmd_float));
+  out("\n\nthermodynamic_output:\n");
+  for(size_t i = 0; i < s->row_step.size(); i++) {
+    const double conserve = (1.5 * s->row_t[i] + s->row_u[i]) / (1.5 * s->row_t[0] + s->row_u[0]);
+    out("  timestep: %d \n", s->row_step[i]);
+    out("      T*:           %15.10g \n", s->row_t[i]);
+    out("      U*:           %15.10g \n", s->row_u[i]);
+    out("      P*:           %15.10g \n", s->row_p[i]);
+    out("      Conservation: %15.10g \n", conserve);
+  }
+  if(s->me == 0) { fprintf(stdout, "\n\n"); if(fp) fprintf(fp, "\n\n"); }
+  // timings averaged over ranks
+  const double* t = s->last_timers;
+  double tv[4] = {t[0], t[2], t[3], t[1]};                 // total, force, neigh, comm
+  MMD_TRY(mmd_transport_allreduce(h, tv, 4));
+  for(double& v : tv) v /= s->nprocs;
+  double time_total = tv[0];
+  out("time:\n  total:\n");
+  out("    time: %g \n", time_total);
+  out("    performance: %10.5e \n", (double)s->natoms * s->in.ntimes / time_total);
+  out("    performance_proc: %10.5e \n", (double)s->natoms * s->in.ntimes / time_total / s->nprocs / s->num_threads);
+  if(time_total == 0.0) time_total = 1.0;
+  out("  force: %g\n", tv[1]);
+  out("  neigh: %g\n", tv[2]);
+  out("  comm:  %g\n", tv[3]);
+  out("  other: %g\n", tv[0] - (tv[1] + tv[2] + tv[3]));
+  out("\n");
+  // per-rank histograms
+  long long nswaps = 0, neighs = 0;
+  { int ns = 0; MMD_TRY(mmd_comm_info(h, nullptr, nullptr, nullptr, nullptr, &ns));
+    for(int i = 0; i < ns; i++) { int c[3]; MMD_TRY(mmd_comm_swap_info(h, i, nullptr, nullptr, nullptr, c)); nswaps += c[0]; } }
+  MMD_TRY(mmd_neighbor_info(h, nullptr, nullptr, &neighs, nullptr));
+  const struct { const char* label; double v; } items[] = {
+    {"# Force time:", t[2]}, {"# Neigh time:", t[3]}, {"# Comm  time:", t[1]}, {"# Other time:", t[0] - (t[2] + t[3] + t[1])},
+    {"# Nlocal:    ", (double)nlocal}, {"# Nghost:    ", (double)nghost}, {"# Nswaps:    ", (double)nswaps}, {"# Neighs:    ", (double)neighs}};
+  double total_neigh = 0;
+  for(int k = 0; k < 8; k++) {
+    std::vector<double> all;
+    MMD_TRY(gather_all(s, items[k].v, all));
+    double ave, mx, mn; int histo[10];
+    histogram(all, &ave, &mx, &mn, histo);
+    if(k == 0) out("# Timing histograms \n");
+    if(k == 4 && s->me == 0) { fprintf(stdout, "\n"); if(fp) fprintf(fp, "\n"); }
+    out("%s %g ave %g max %g min\n", items[k].label, ave, mx, mn);
+    out("# Histogram:");
+    for(int i = 0; i < 10; i++) out(" %d", histo[i]);
+    out("\n");
+    if(k == 7) for(double d : all) total_neigh += d;
+  }
+  out("# Total # of neighbors = %g\n", total_neigh);
+  out("\n");
+  if(fp) fclose(fp);
+  return 0;
+}
+
 extern "C" int mmd_sim_rows(mmd_sim* s, int* nrows, int* steps, double* t, double* u, double* p, int maxrows)
 {
   if(!s || !nrows) { mmd_set_error("mmd_sim_rows: bad arguments"); return -1; }
@@ -416,6 +572,7 @@ extern "C" int mmd_sim_rows(mmd_sim* s, int* nrows, int* steps, double* t, doubl
 }
 
 extern "C" int mmd_sim_natoms(mmd_sim* s) { return s ? s->natoms : -1; }
+extern "C" int mmd_sim_wants_yaml(mmd_sim* s, int* screen) { if(!s) return 0; if(screen) *screen = s->yaml_screen; return s->yaml_output; }
 extern "C" mmd_handle* mmd_sim_handle(mmd_sim* s) { return s ? s->h : nullptr; }
 
 extern "C" int mmd_sim_destroy(mmd_sim* s)

@@ -359,3 +359,26 @@ def test_eam_half_request_and_original_force_alias():
     ref = REFRUNS["lj_s10_half_gn1_n1000"]
     rows = sim_rows(["-s", 10, "-n", 300, "--half_neigh", -1])
     rows_close(rows, [r_ for r_ in ref["rows"] if r_[0] <= 300], 2e-6)
+
+
+def test_yaml_report_matches_reference_counts(tmp_path):
+    """`-o 1 --yaml_screen` (ref/output.cpp): same keys; the structural counts equal the reference's own report"""
+    ent = REFRUNS["lj_s16_full_n300"]
+    path = os.path.join(REPO, "minimd_amd", "bin", "miniMD_dp")
+    for f in ("in.lj.miniMD",):
+        os.symlink(os.path.join(REPO, "data", f), str(tmp_path / f))
+    r = subprocess.run([path, "-i", "in.lj.miniMD", "-s", "16", "-n", "300", "--half_neigh", "0", "-o", "1", "--yaml_screen"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    out = r.stdout
+    for key in ("run_configuration:", "  variant:", "  atoms: 16384", "  unit_cells: 16 16 16", "  neighbor_type: 0", "thermodynamic_output:",
+                "      Conservation:", "time:", "    performance:", "  force:", "  neigh:", "  comm:", "  other:", "# Timing histograms",
+                "# Nlocal:", "# Nghost:", "# Nswaps:", "# Neighs:", "# Total # of neighbors ="):
+        assert key in out, key
+    import re
+    assert float(re.search(r"# Nghost:\s+([-+.\deE]+) ave", out).group(1)) == ent["nghost"]
+    assert float(re.search(r"# Total # of neighbors = ([-+.\deE]+)", out).group(1)) == ent["neigh_total"]
+    cons = [float(m) for m in re.findall(r"Conservation:\s+([-+.\deE]+)", out)]
+    assert cons[0] == 1.0 and all(abs(c - 1.0) < 5e-3 for c in cons)
+    yamls = [f for f in os.listdir(str(tmp_path)) if f.startswith("miniMD-") and f.endswith(".yaml")]
+    assert len(yamls) == 1 and "thermodynamic_output:" in open(str(tmp_path / yamls[0])).read()
