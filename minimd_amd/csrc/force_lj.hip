@@ -143,19 +143,46 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
 // arrays, valid until the next re-neighboring) so the 16-bit slots of nl16 index straight into LDS.
 #define LJ_STAGE 8            // candidates staged per thread and batch (independent load pairs in flight)
 
-template <int EV, bool EXACT, int LJ_TILE_WAVES, int UNR>
+// keep `v` when `in`, otherwise clear its high word only: the result is then a denormal whose square underflows
+// to exactly 0, so every product built from it (A = sr2^3, the force, the energy term) is an exact zero —
+// one v_cndmask instead of the two a 64-bit select costs
+__device__ __forceinline__ double keep_if(bool in, double v)
+{
+  const long long b = __double_as_longlong(v);
+  return __hiloint2double(in ? (int)(b >> 32) : 0, (int)b);
+}
+__device__ __forceinline__ float keep_if(bool in, float v) { return in ? v : 0.0f; }
+
+// read one {x,y,z} record at LDS byte address `a`. The dynamic LDS segment starts at address 0 (the tile kernels
+// declare no static __shared__), so slot offsets are used as addresses as they are — no per-pair base add.
+// RD=1 keeps the three 8-byte reads separate (volatile: not fused into ds_read2_b64).
+typedef __attribute__((address_space(3))) const real lds_creal;
+typedef __attribute__((address_space(3))) const volatile real lds_cvreal;
+template <int RD>
+__device__ __forceinline__ void lds_read3(unsigned a, real& qx, real& qy, real& qz)
+{
+  if(RD == 1) { lds_cvreal* q = (lds_cvreal*)a; qx = q[0]; qy = q[1]; qz = q[2]; }
+  else        { lds_creal* q = (lds_creal*)a; qx = q[0]; qy = q[1]; qz = q[2]; }
+}
+
+// dynamic LDS of the tile kernel: [positions: pos_bytes][wave-slice forces: 3*64*(W-1) reals][16 doubles].
+// Nothing static precedes it, so the 16-bit values of nl16 ARE the ds_read addresses of the records.
+__host__ __device__ constexpr int lj_tile_sf_bytes(int waves) { return 3 * 64 * (waves - 1) * (int)sizeof(real); }
+
+template <int EV, bool EXACT, int LJ_TILE_WAVES, int UNR, int RD>
 __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
-    const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, LJParams P, real* __restrict__ f,
+    const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, int pos_bytes, LJParams P, real* __restrict__ f,
     double* __restrict__ partials, int ablate)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
-  __shared__ real s_f[3 * 64 * (LJ_TILE_WAVES - 1) + 3];
-  __shared__ double s_red[16];
+  real* s_f = (real*)(s_raw + pos_bytes);
+  double* s_red = (double*)(s_raw + pos_bytes + lj_tile_sf_bytes(LJ_TILE_WAVES));
   constexpr int LJ_TILE_THREADS = 64 * LJ_TILE_WAVES;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform => the k loop runs on the scalar unit
   // XCD-aware order (device_utils.hpp): neighbouring tiles share most of their candidate atoms
   const int witem = xcd_work_item(ntiles);
   if(witem < 0) return;                          // (grid is padded to a multiple of 8)
@@ -186,10 +213,10 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   const int kmax = (ablate & 2) ? 0 : tile_max[tile];
   const int per = ((kmax / UNR + LJ_TILE_WAVES - 1) / LJ_TILE_WAVES) * UNR;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
-  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
-  int s_nxt[UNR];
+  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
+  int s[UNR];
 #pragma unroll
-  for(int u = 0; u < UNR; u++) s_nxt[u] = k0 < k1 ? np[(size_t)(k0 + u) * 64] : 0;
+  for(int u = 0; u < UNR; u++) s[u] = k0 < k1 ? np[u * 64] : 0;
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   __syncthreads();
@@ -200,34 +227,27 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   // the bracket is uniform and applied once after the loop
   const real c_out = (real)48.0 * P.epsilon * P.sigma6;
   for(int k = k0; k < k1; k += UNR) {
-    int s[UNR];
-#pragma unroll
-    for(int u = 0; u < UNR; u++) s[u] = s_nxt[u];
-    if(k + UNR < k1) {                    // prefetch the next slots under this trip's arithmetic
-#pragma unroll
-      for(int u = 0; u < UNR; u++) s_nxt[u] = np[(size_t)(k + UNR + u) * 64];
-    }
     real xj[UNR], yj[UNR], zj[UNR];
 #pragma unroll
-    for(int u = 0; u < UNR; u++) {               // s[u] is already the byte offset of the record: no address arithmetic
-      const real* q = (const real*)(s_raw + s[u]);
-      xj[u] = q[0]; yj[u] = q[1]; zj[u] = q[2];
+    for(int u = 0; u < UNR; u++) lds_read3<RD>((unsigned)s[u], xj[u], yj[u], zj[u]);   // s[u] IS the record's LDS address
+    np += UNR * 64;
+    if(k + UNR < k1) {                    // the next trip's slots travel under this trip's arithmetic
+#pragma unroll
+      for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
     }
 #pragma unroll
     for(int u = 0; u < UNR; u++) {
       const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
       const real rsq = dx * dx + dy * dy + dz * dz;
-      const real sr2 = EXACT ? recip<true>(rsq) : recip_fast(rsq);
-      const real A = sr2 * sr2 * sr2;
-      const real t = A * P.sigma6 - (real)0.5;
-      real fs = (A * sr2) * t;                     // force / c_out
       const bool in = rsq < P.cutforcesq;
-      fs = in ? fs : (real)0;
+      const real sr2 = keep_if(in, EXACT ? recip<true>(rsq) : recip_fast(rsq));   // out of range => everything below is 0
+      const real A = (sr2 * sr2) * sr2;
+      const real t = A * P.sigma6 - (real)0.5;
+      const real fs = (A * sr2) * t;               // force / c_out
       fx += dx * fs; fy += dy * fs; fz += dz * fs;
       if(EV) {
         const real sr6 = A * P.sigma6;
-        const real en = in ? sr6 * (sr6 - (real)1.0) * P.epsilon : (real)0;
-        e_acc += (double)en;
+        e_acc += (double)(sr6 * (sr6 - (real)1.0) * P.epsilon);
         v_acc += (double)(rsq * fs);
       }
     }
@@ -377,29 +397,37 @@ static void launch_half(mmd_handle* h, int nblocks, const LJTables& T)
                      h->wave_max.p, h->nlocal, h->maxneighs, h->lj, T, h->f.p, h->partials.p);
 }
 
+// bytes of the position records in the tile kernel's LDS (rounded to 16)
+static size_t lj_tile_pos_bytes(const mmd_handle* h) { return (((size_t)3 * (h->tile_cmax + 2) * sizeof(real)) + 15) & ~(size_t)15; }
+
 int mmd_lj_tiles_available(mmd_handle* h)
 {
-  const size_t tile_lds = (size_t)3 * (h->tile_cmax + 2) * sizeof(real);
-  return h->style == 0 && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && tile_lds <= 60 * 1024 && h->neigh_nlocal == h->nlocal;
+  return h->style == 0 && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && lj_tile_pos_bytes(h) <= 60 * 1024 && h->neigh_nlocal == h->nlocal;
 }
 
 // launch the tile kernel over `count` tiles: tile ids from `list` (device) or 0..count-1
 static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
 {
   if(count <= 0) return 0;
-  const size_t tile_lds = (size_t)3 * (h->tile_cmax + 2) * sizeof(real);
+  const size_t pos_bytes = lj_tile_pos_bytes(h);
   const int nlocal = h->nlocal;
   const int ev = evflag ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
-#define TK(EVv, Xv, Wv, Uv) if(ev == EVv && ex == Xv && tw == Wv && tu == Uv)                                                    \
-    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv>), dim3(xcd_grid(count)), dim3(64 * Wv), tile_lds, h->stream, h->x.p,  \
+  bool launched = false;
+#define TK(EVv, Xv, Wv, Uv, Rv) if(!launched && ev == EVv && ex == Xv && tw == Wv && tu == Uv && rd == Rv) { launched = true;        \
+    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv, Rv>), dim3(xcd_grid(count)), dim3(64 * Wv),                           \
+                       pos_bytes + lj_tile_sf_bytes(Wv) + 16 * sizeof(double), h->stream, h->x.p,                                    \
                        h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
-                       count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, h->lj, h->f.p, h->partials.p, h->opt_ablate)
-  const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll;
-  TK(0, 0, 4, 4); TK(0, 1, 4, 4); TK(1, 0, 4, 4); TK(1, 1, 4, 4);
-  TK(0, 0, 2, 4); TK(1, 0, 2, 4); TK(0, 0, 1, 4); TK(1, 0, 1, 4);
-  TK(0, 0, 4, 8); TK(1, 0, 4, 8); TK(0, 0, 2, 8); TK(1, 0, 2, 8); TK(0, 1, 2, 8); TK(1, 1, 2, 8);
-  TK(0, 0, 4, 2); TK(1, 0, 4, 2);
+                       count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,              \
+                       h->partials.p, h->opt_ablate); }
+  const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = h->opt_tile_read;
+  TK(0, 0, 2, 8, 0); TK(1, 0, 2, 8, 0); TK(0, 1, 2, 8, 0); TK(1, 1, 2, 8, 0);      // production shape (+ exact-division check)
+  TK(0, 0, 2, 8, 1); TK(1, 0, 2, 8, 1); TK(0, 1, 2, 8, 1); TK(1, 1, 2, 8, 1);
+  TK(0, 0, 4, 8, 0); TK(1, 0, 4, 8, 0); TK(0, 0, 4, 8, 1); TK(1, 0, 4, 8, 1);      // tuning shapes
+  TK(0, 0, 1, 8, 0); TK(1, 0, 1, 8, 0); TK(0, 0, 1, 8, 1); TK(1, 0, 1, 8, 1);
+  TK(0, 0, 2, 4, 0); TK(1, 0, 2, 4, 0); TK(0, 0, 2, 4, 1); TK(1, 0, 2, 4, 1);
+  TK(0, 0, 4, 4, 0); TK(1, 0, 4, 4, 0); TK(0, 0, 4, 4, 1); TK(1, 0, 4, 4, 1);
 #undef TK
+  if(!launched) { mmd_set_error("tile force kernel: unsupported tile_waves/tile_unroll/tile_read combination"); return -1; }
   HIP_TRY(hipGetLastError());
   return 0;
 }

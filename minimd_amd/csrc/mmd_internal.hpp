@@ -149,6 +149,7 @@ struct mmd_handle {
   int opt_tiles = 1;
   int opt_force_transport = 0;   // testing: route self-swaps through the transport too (RCCL loop-back on one GPU)
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
+  int opt_tile_read = 0;                          // 1: three separate 8-byte LDS reads per pair (A/B knob)
   int opt_fuse = 1;          // fused final+initial integrate, single-kernel ghost update on one rank
   int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)
   // ---- Force

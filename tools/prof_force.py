@@ -47,7 +47,7 @@ if os.environ.get("BUILDAB"):
 if os.environ.get("SHAPES"):
     h.set_option("tiles", 1)
     for rnd in range(2):
-        for w, u in ((4, 4), (2, 4), (1, 4), (4, 8), (2, 8), (4, 2)):
+        for w, u in ((4, 4), (2, 4), (1, 8), (4, 8), (2, 8)):
             h.set_option("tile_waves", w); h.set_option("tile_unroll", u)
             print("round %d waves=%d unroll=%d  tile force %.4f ms" % (rnd, w, u, h.profile_kernel(0, a.reps)))
     h.set_option("tile_waves", 2); h.set_option("tile_unroll", 8)
