@@ -61,7 +61,7 @@ def load_library(precision="dp"):
         "mmd_atom_upload_f": [P, rp, I], "mmd_atom_counts": [P, ip, ip, ip], "mmd_atom_pbc": [P], "mmd_atom_sort": [P],
         "mmd_neighbor_setup": [P, ip, creal, I, I, I], "mmd_neighbor_build": [P],
         "mmd_neighbor_geometry": [P, ip, ip, ip, ip],
-        "mmd_neighbor_info": [P, ip, ip, C.POINTER(C.c_longlong), ip], "mmd_neighbor_download": [P, ip, I, ip],
+        "mmd_neighbor_info": [P, ip, ip, C.POINTER(C.c_longlong), ip], "mmd_neighbor_tile_stats": [P, C.POINTER(C.c_longlong)], "mmd_neighbor_download": [P, ip, I, ip],
         "mmd_neighbor_upload": [P, ip, I, ip, I],
         "mmd_force_lj_setup": [P, I, rp, rp, rp],
         "mmd_force_eam_setup": [P, I, I, I, I, I, creal, creal, rp, rp, rp, rp],
@@ -209,6 +209,12 @@ class Handle:
         t = C.c_longlong()
         self._chk(self.L.mmd_neighbor_info(self.h, C.byref(m), C.byref(b), C.byref(t), C.byref(mr)))
         return {"maxneighs": m.value, "mbins": b.value, "total": t.value, "max_row": mr.value}
+
+    def neighbor_tile_stats(self):
+        out = (C.c_longlong * 6)()
+        self._chk(self.L.mmd_neighbor_tile_stats(self.h, out))
+        keys = ("tiles", "max_candidates", "sum_candidates", "sum_padded_rows", "sum_atoms", "max_padded_row")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def neighbor_download(self):
         nl = self.counts()[0]

@@ -141,7 +141,6 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
 // handles the neighbor-row slice k in [w*kmax/W, (w+1)*kmax/W) of the same 64 atoms, partial forces are
 // combined through LDS. The candidate sequence is rebuilt exactly like k_build's (same bin_start/binned
 // arrays, valid until the next re-neighboring) so the 16-bit slots of nl16 index straight into LDS.
-#define LJ_STAGE 8            // candidates staged per thread and batch (independent load pairs in flight)
 
 // keep `v` when `in`, otherwise clear its high word only: the result is then a denormal whose square underflows
 // to exactly 0, so every product built from it (A = sr2^3, the force, the energy term) is an exact zero —
@@ -192,21 +191,18 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   // 3 reals (stride 3 is coprime with the bank count: random slots spread over all banks, one address per pair)
   real* sp = (real*)s_raw;
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int tb = tid; tb <= ncand && !(ablate & 1); tb += LJ_STAGE * LJ_TILE_THREADS) {
-    int jj[LJ_STAGE];
+  // Branch-free: the build stores the dummy atom's index at cl[ncand], lanes past the end clamp to that entry
+  // and (re)write the same dummy record, so one pass of 512 records covers almost every tile (unions hold ~450 atoms at LJ liquid density).
+  constexpr int STG = 512 / LJ_TILE_THREADS;
+  for(int t0 = 0; t0 <= ncand && !(ablate & 1); t0 += 512) {
+    int tt[STG], jj[STG];
 #pragma unroll
-    for(int u = 0; u < LJ_STAGE; u++) {
-      const int t = tb + u * LJ_TILE_THREADS;
-      jj[u] = t < ncand ? cl[t] : nall;           // slot `ncand` (and beyond) = the far-away dummy atom
-    }
-    real4 pp[LJ_STAGE];
+    for(int u = 0; u < STG; u++) { tt[u] = min(t0 + u * LJ_TILE_THREADS + tid, ncand); jj[u] = cl[tt[u]]; }
+    real4 pp[STG];
 #pragma unroll
-    for(int u = 0; u < LJ_STAGE; u++) pp[u] = x[jj[u]];
+    for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
 #pragma unroll
-    for(int u = 0; u < LJ_STAGE; u++) {
-      const int t = tb + u * LJ_TILE_THREADS;
-      if(t <= ncand) { sp[3 * t] = pp[u].x; sp[3 * t + 1] = pp[u].y; sp[3 * t + 2] = pp[u].z; }
-    }
+    for(int u = 0; u < STG; u++) { sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z; }
   }
   // ---- my atom and my slice of its neighbor row (wave w takes k in [k0,k1))
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;     // a tile never straddles blocks

@@ -18,6 +18,7 @@
 //    guarded; the host reads the maximum, grows maxneighs to 1.2*max and relaunches.
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"
+#include <vector>
 
 #define NB_SMALL 1.0e-6
 
@@ -328,7 +329,7 @@ __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, cons
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__ x, const int* __restrict__ binned,
                                                        const int* __restrict__ bin_start, BinGeom g, int nblocks, int nlocal,
-                                                       real cutneighsq, int maxneighs, int cstride, const int* __restrict__ tile_of_block,
+                                                       int nall, real cutneighsq, int maxneighs, int cstride, const int* __restrict__ tile_of_block,
                                                        int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
                                                        int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
                                                        int* __restrict__ tile_max, int* __restrict__ tile_ghost, int* __restrict__ flags,
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     if(lane == 0) {
       tile_max[tile] = kmax;
       tile_ncand[tile] = base;
+      tile_cand[(size_t)tile * cstride + base] = nall;       // the dummy atom closes the list (cstride > NB_CHUNKS*64)
       tile_ghost[tile] = any_ghost ? 1 : 0;
       atomicMax(&flags[0], maxn);
       atomicMax(&flags[2], base);
@@ -636,7 +638,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     MMD_TRY(h->tile_ncand.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_cnt.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_ghost.ensure((size_t)nt + 2, false, h->stream));
-    h->tile_cstride = NB_CHUNKS * 64;
+    h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
     hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p);
     HIP_TRY(hipGetLastError());
@@ -645,7 +647,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
       HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
       const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
-      hipLaunchKernelGGL(k_build_tiles, dim3(xcd_grid(nblocks)), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p, g, nblocks, nlocal, h->cutneighsq,
+      hipLaunchKernelGGL(k_build_tiles, dim3(xcd_grid(nblocks)), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p, g, nblocks, nlocal, nlocal + h->nghost, h->cutneighsq,
                          h->maxneighs, h->tile_cstride, h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,
                          h->tile_max.p, h->tile_ghost.p, h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate);
       HIP_TRY(hipGetLastError());
@@ -725,6 +727,27 @@ extern "C" int mmd_neighbor_info(mmd_handle* h, int* maxneighs, int* mbins, long
   if(mbins) *mbins = h->bg.mbins;
   if(total_neigh) *total_neigh = h->total_neigh;
   if(max_row) *max_row = h->max_row;
+  return 0;
+}
+
+// diagnostics of the tile form: {ntiles, max candidates, sum candidates, sum padded rows, sum atoms, longest padded row}
+extern "C" int mmd_neighbor_tile_stats(mmd_handle* h, long long out[6])
+{
+  if(!h || !out) { mmd_set_error("mmd_neighbor_tile_stats: bad arguments"); return -1; }
+  for(int q = 0; q < 6; q++) out[q] = 0;
+  if(!h->tiles_ready || h->ntiles <= 0) return 0;
+  HIP_TRY(hipSetDevice(h->device));
+  std::vector<int> nc(h->ntiles), mx(h->ntiles), ct(h->ntiles);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(nc.data(), h->tile_ncand.p, sizeof(int) * h->ntiles, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(mx.data(), h->tile_max.p, sizeof(int) * h->ntiles, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ct.data(), h->tile_cnt.p, sizeof(int) * h->ntiles, hipMemcpyDeviceToHost));
+  out[0] = h->ntiles;
+  for(int t = 0; t < h->ntiles; t++) {
+    if(nc[t] > out[1]) out[1] = nc[t];
+    out[2] += nc[t]; out[3] += mx[t]; out[4] += ct[t];
+    if(mx[t] > out[5]) out[5] = mx[t];
+  }
   return 0;
 }
 

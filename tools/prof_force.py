@@ -26,6 +26,7 @@ h = sim.handle
 nl, ng, _ = h.counts()
 info = h.neighbor_info()
 print("atoms", nl, "ghosts", ng, "kbar %.2f" % (info["total"] / nl), "maxneighs", info["maxneighs"], "max_row", info["max_row"])
+print("tile stats", h.neighbor_tile_stats())
 names = {0: "force", 1: "neighbor_build(+binning)", 2: "initial_integrate", 3: "final_integrate", 4: "communicate"}
 for k in [int(q) for q in a.kernels.split(",")]:
     ms = h.profile_kernel(k, a.reps if k != 1 else 3)
