@@ -373,7 +373,10 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
   __syncthreads();
   const int total = rng_pref[nr];
   if(ablate & 16) return;
-  if(total > NB_CHUNKS * 64) {                                // cannot hold the candidates in one register pass
+  // slot of this block's first atom in the candidate sequence (its own (y,z) row is slice rc)
+  const int rc = g.reach[2] * ny + g.reach[1];
+  const int self0 = rc < nr ? rng_pref[rc] + (a0 - rng_start[rc]) : 0;
+  if(total > NB_CHUNKS * 64 || rc >= nr) {                                // cannot hold the candidates in one register pass
     if(lane == 0) atomicMax(&flags[3], 1);                    // host falls back to k_build + global rows
     return;
   }
@@ -441,7 +444,6 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
   for(int tl = 0; tl < ntile_b; tl++) {
     const int tile = tile0 + tl;
     const int ta = a0 + tl * 64, te = min(ta + 64, a1);
-    unsigned usedbits = 0;
     // owned atoms of the tile: one coalesced load, then broadcast reads from LDS inside the atom loop
     {
       const int ii = ta + lane < te ? binned[ta + lane] : -1;
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
       const float ddx = fmaxf(fmaxf(bx0 - fxi, fxi - bx1), 0.0f);
       const float ddy = fmaxf(fmaxf(by0 - fyi, fyi - by1), 0.0f);
       const float ddz = fmaxf(fmaxf(bz0 - fzi, fzi - bz1), 0.0f);
-      unsigned long long live = __ballot(lane < nchunks && ddx * ddx + ddy * ddy + ddz * ddz <= cull);
+      unsigned long long live = __builtin_amdgcn_ballot_w64(lane < nchunks && ddx * ddx + ddy * ddy + ddz * ddz <= cull);
       if(ablate & 2) live = ~0ull >> (64 - nchunks);      // profiling: no culling
       if(ablate & 1) live = 0;                            // profiling: no tests at all
       int n = 0;
@@ -476,33 +478,44 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
             if((live >> c) & 1ull) {
               const real dx = xix - cx[c], dy = xiy - cy[c], dz = xiz - cz[c];
               const real rsq = dx * dx + dy * dy + dz * dz;
-              const bool keep = rsq <= cutneighsq && cj[c] != i;
-              const unsigned long long m = __ballot(keep);
+              // the atom itself (rsq = 0) is kept here and dropped at write-out: no index compare per pass, and
+              // the v_cmp result IS the hit mask
+              const unsigned long long m = __builtin_amdgcn_fcmp(rsq, cutneighsq, 5 /* ordered <= */);
               if(m) {
-                const int pos = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                if(keep) {
-                  if(pos < maxneighs) rows[pos * 64 + al] = (unsigned short)(c * 64 + lane);
-                  usedbits |= 1u << c;
-                }
+                // ordered append: rank of this lane among the hits, on top of the n found so far; a row that
+                // overflows keeps overwriting its last slot (the host grows maxneighs and rebuilds, ref :184-208)
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, n));
+                if(rsq <= cutneighsq) rows[min(pos, maxneighs - 1) * 64 + al] = (unsigned short)(c * 64 + lane);
                 n += __popcll(m);
               }
             }
           }
         }
       }
-      if(lane == 0) { cnt[al] = n; numneigh[i] = n; }
+      if(lane == 0) { cnt[al] = n; numneigh[i] = max(n - 1, 0); }      // n counts the atom itself
     }
     __syncthreads();
     if(ablate & 8) continue;
-    // ---- union of the candidates referenced by this tile -> compact list + remap table
+    // ---- union of the candidates referenced by this tile -> compact list + remap table. Every lane marks the
+    // slots of its own raw row (the atom itself included: it is a neighbor of its tile mates anyway)
+#pragma unroll
+    for(int c = 0; c < NB_CHUNKS; c++) if(c < nchunks) remap[c * 64 + lane] = 0;
+    __syncthreads();
+    const int myraw = min(cnt[lane], maxneighs);
+    for(int k = 0; k < myraw; k++) remap[rows[k * 64 + lane]] = 1;
+    __syncthreads();
     int base = 0;
     bool refs_ghost = false;
+    unsigned usedbits = 0;
+#pragma unroll
+    for(int c = 0; c < NB_CHUNKS; c++) if(c < nchunks) usedbits |= (unsigned)(remap[c * 64 + lane] != 0) << c;
+    __syncthreads();
 #pragma unroll
     for(int c = 0; c < NB_CHUNKS; c++) {
       if(c < nchunks) {
         const bool bit = (usedbits >> c) & 1u;
         refs_ghost = refs_ghost || (bit && cj[c] >= nlocal);
-        const unsigned long long m = __ballot(bit);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
         const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if(bit) {
           tile_cand[(size_t)tile * cstride + pos] = cj[c];
@@ -512,18 +525,21 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
       }
     }
     __syncthreads();
-    // ---- coalesced write-out of the padded, remapped rows
-    const int myn = cnt[lane];
+    // ---- coalesced write-out of the padded, remapped rows; the atom's own slot is skipped on the way
+    const int myn = max(cnt[lane] - 1, 0);
     const int maxn = wave_max_i(myn);
     int kmax = (maxn + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
     if(kmax > maxneighs) kmax = maxneighs;
-    const int lim = min(myn, maxneighs);
+    const int selfslot = self0 + tl * 64 + lane;
     unsigned short* out = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
-#pragma unroll 8
-    for(int k = 0; k < kmax; k++)                 // stored as the LDS byte offset of the {x,y,z} record (slot * 3 reals)
-      out[(size_t)k * 64] = (unsigned short)((k < lim ? remap[rows[k * 64 + lane]] : (unsigned short)base) * NB_SLOT_BYTES);
+    int ko = 0;                                   // output row of this lane (lags k by one after its own slot)
+    for(int k = 0; k <= kmax; k++) {              // stored as the LDS byte offset of the {x,y,z} record (slot * 3 reals)
+      const int raw = k < myraw ? rows[k * 64 + lane] : -1;
+      const unsigned short v = (unsigned short)((raw >= 0 ? remap[raw] : (unsigned short)base) * NB_SLOT_BYTES);
+      if(raw != selfslot && ko < kmax) { out[(size_t)ko * 64] = v; ko++; }
+    }
     const long long tsum = wave_sum((long long)myn);
-    const bool any_ghost = __ballot(refs_ghost) != 0ull;
+    const bool any_ghost = __builtin_amdgcn_ballot_w64(refs_ghost) != 0ull;
     if(lane == 0) {
       tile_max[tile] = kmax;
       tile_ncand[tile] = base;

@@ -37,7 +37,7 @@ if a.ab:
             h.set_option(a.ab, v)
             print("round %d  %s=%d  force %.4f ms" % (rnd, a.ab, v, h.profile_kernel(0, a.reps)))
 if os.environ.get("BUILDAB"):
-    for ab in (0, 1, 2, 16):
+    for ab in (0, 1, 8, 9, 13, 16):
         h.set_option("ablate", ab)
         try:
             print("ablate=%d  neighbor build %.4f ms" % (ab, h.profile_kernel(1, 3)))
