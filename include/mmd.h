@@ -178,6 +178,14 @@ int mmd_create_box(int nx, int ny, int nz, double rho, mmd_float prd[3]);
  * x=v=type=tag=NULL to get the count. Types follow rand()%ntypes after srand(5413) (ref/atom.cpp:97). */
 int mmd_create_atoms(int nx, int ny, int nz, double rho, const mmd_float lo[3], const mmd_float hi[3], int ntypes,
                      mmd_float* x, mmd_float* v, int* type, int* tag, int* nlocal);
+/* read_lammps_data (ref/setup.cpp:55-301), parsing part: header ("<n> atoms", "xlo xhi" ...; the box starts at 0 like the
+ * reference assumes) and the Atoms / Velocities / Masses sections. Two-call protocol: with x = v = NULL only natoms,
+ * prd and mass (-1 when the file has no Masses section) are returned; then x, v (3*natoms each) indexed by file id-1. */
+int mmd_lammps_data_read(const char* file, int* natoms, mmd_float prd[3], mmd_float* mass, mmd_float* x, mmd_float* v);
+/* the atoms of sub-box [lo,hi) in file order with rand()%ntypes types (ref/setup.cpp:281-286, ref/atom.cpp:86-100);
+ * two-call protocol like mmd_create_atoms; tag = file id */
+int mmd_lammps_data_select(int natoms, const mmd_float* x_all, const mmd_float* v_all, const mmd_float lo[3], const mmd_float hi[3],
+                           int ntypes, mmd_float* x, mmd_float* v, int* type, int* tag, int* nlocal);
 /* EAM funcfl file -> spline tables (ref/force_eam.cpp:505-793). Two-call protocol: with the three
  * spline pointers NULL only the sizes/scalars are returned. */
 int mmd_eam_tables_from_file(const char* filename, int ntypes, int* nr, int* nrho, int* nr_tot, int* nrho_tot,

@@ -77,6 +77,8 @@ def load_library(precision="dp"):
         "mmd_sync": [P],
         "mmd_input_read": [P, C.c_char_p], "mmd_create_box": [I, I, I, D, rp],
         "mmd_create_atoms": [I, I, I, D, rp, rp, I, rp, rp, ip, ip, ip],
+        "mmd_lammps_data_read": [C.c_char_p, ip, rp, rp, rp, rp],
+        "mmd_lammps_data_select": [I, rp, rp, rp, rp, I, rp, rp, ip, ip, ip],
         "mmd_eam_tables_from_file": [C.c_char_p, I, ip, ip, ip, ip, rp, rp, rp, rp, rp, rp, rp],
         "mmd_sim_set_unique_id": [C.c_char_p], "mmd_sim_set_host_transport": [P, P, P], "mmd_sim_create": [I, C.POINTER(C.c_char_p), I, C.POINTER(P)],
         "mmd_sim_initial": [P], "mmd_sim_run": [P], "mmd_sim_run_steps": [P, I, dp], "mmd_sim_print_perf": [P],
@@ -384,6 +386,37 @@ def create_atoms(nx, ny, nz, rho, lo, hi, ntypes=4, precision="dp"):
     ipt = C.POINTER(C.c_int)
     L.mmd_create_atoms(nx, ny, nz, float(rho), lo.ctypes.data_as(rp), hi.ctypes.data_as(rp), ntypes, x.ctypes.data_as(rp),
                        v.ctypes.data_as(rp), t.ctypes.data_as(ipt), tag.ctypes.data_as(ipt), C.byref(n))
+    return x, v, t, tag
+
+
+def lammps_data_read(path, precision="dp"):
+    """read_lammps_data's parsing part (ref/setup.cpp:55-301): (natoms, prd[3], mass or None, x[natoms,3], v[natoms,3])"""
+    L = load_library(precision)
+    rp = C.POINTER(L._creal)
+    n, mass = C.c_int(), L._creal()
+    prd = np.zeros(3, L._real)
+    if L.mmd_lammps_data_read(os.fsencode(path), C.byref(n), prd.ctypes.data_as(rp), C.byref(mass), None, None) < 0:
+        raise MMDError(L.mmd_last_error().decode())
+    x, v = np.zeros((n.value, 3), L._real), np.zeros((n.value, 3), L._real)
+    if L.mmd_lammps_data_read(os.fsencode(path), C.byref(n), prd.ctypes.data_as(rp), C.byref(mass), x.ctypes.data_as(rp), v.ctypes.data_as(rp)) < 0:
+        raise MMDError(L.mmd_last_error().decode())
+    return n.value, prd, (None if mass.value < 0 else mass.value), x, v
+
+
+def lammps_data_select(x_all, v_all, lo, hi, ntypes=4, precision="dp"):
+    """atoms of sub-box [lo,hi) in file order (ref/setup.cpp:281-286): x, v, type, tag(= file id)"""
+    L = load_library(precision)
+    rp, ipt = C.POINTER(L._creal), C.POINTER(C.c_int)
+    xa, va = np.ascontiguousarray(x_all, L._real), np.ascontiguousarray(v_all, L._real)
+    lo, hi = np.ascontiguousarray(lo, L._real), np.ascontiguousarray(hi, L._real)
+    n = C.c_int()
+    args = (len(xa), xa.ctypes.data_as(rp), va.ctypes.data_as(rp), lo.ctypes.data_as(rp), hi.ctypes.data_as(rp), ntypes)
+    if L.mmd_lammps_data_select(*args, None, None, None, None, C.byref(n)) < 0:
+        raise MMDError(L.mmd_last_error().decode())
+    x, v = np.zeros((n.value, 3), L._real), np.zeros((n.value, 3), L._real)
+    t, tag = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
+    if L.mmd_lammps_data_select(*args, x.ctypes.data_as(rp), v.ctypes.data_as(rp), t.ctypes.data_as(ipt), tag.ctypes.data_as(ipt), C.byref(n)) < 0:
+        raise MMDError(L.mmd_last_error().decode())
     return x, v, t, tag
 
 

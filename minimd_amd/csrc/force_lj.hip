@@ -160,8 +160,8 @@ typedef __attribute__((address_space(3))) const volatile real lds_cvreal;
 template <int RD>
 __device__ __forceinline__ void lds_read3(unsigned a, real& qx, real& qy, real& qz)
 {
-  if(RD == 1) { lds_cvreal* q = (lds_cvreal*)a; qx = q[0]; qy = q[1]; qz = q[2]; }
-  else        { lds_creal* q = (lds_creal*)a; qx = q[0]; qy = q[1]; qz = q[2]; }
+  if(RD == 1) { lds_cvreal* q = (lds_cvreal*)(size_t)a; qx = q[0]; qy = q[1]; qz = q[2]; }
+  else        { lds_creal* q = (lds_creal*)(size_t)a; qx = q[0]; qy = q[1]; qz = q[2]; }
 }
 
 // dynamic LDS of the tile kernel: [positions: pos_bytes][wave-slice forces: 3*64*(W-1) reals][16 doubles].

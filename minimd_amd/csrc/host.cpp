@@ -152,6 +152,121 @@ extern "C" int mmd_create_atoms(int nx, int ny, int nz, double rho, const mmd_fl
 }
 
 // ---------------------------------------------------------------------------------------------------
+// LAMMPS data file — read_lammps_data and helpers, ref/setup.cpp:55-301 (host part: parsing; the caller
+// does comm/neighbor/thermo setup and keeps the atoms of its sub-box)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct LammpsData {
+  FILE* fp = nullptr;
+  std::string keyword;                      // current section name, empty at end of file
+  static bool blank(const char* l) { return strspn(l, " \t\n\r") == strlen(l); }
+  // next section keyword (ref :55-93): the first non-blank line (optionally the one already in `cur`), trimmed;
+  // the line after it is consumed too
+  void next_keyword(char* cur, bool have_cur)
+  {
+    char buf[1024];
+    bool eof = false;
+    if(!have_cur && !fgets(cur, 1024, fp)) eof = true;
+    while(!eof && blank(cur)) if(!fgets(cur, 1024, fp)) eof = true;
+    if(!eof && !fgets(buf, 1024, fp)) eof = true;
+    if(eof) { keyword.clear(); return; }
+    const size_t a = strspn(cur, " \t\n\r");
+    size_t b = strlen(cur);
+    while(b > a && strchr(" \t\n\r", cur[b - 1])) b--;
+    keyword.assign(cur + a, b - a);
+  }
+};
+}  // namespace
+
+extern "C" int mmd_lammps_data_read(const char* file, int* natoms, mmd_float prd[3], mmd_float* mass, mmd_float* x, mmd_float* v)
+{
+  if(!file || !natoms || !prd) { mmd_set_error("mmd_lammps_data_read: bad arguments"); return -1; }
+  LammpsData d;
+  d.fp = fopen(file, "r");
+  if(!d.fp) { mmd_set_error("Cannot open file %s", file); return -1; }
+  char line[1024];
+  // ---- header (ref :95-163): line 1 is a title; then "<n> atoms", "<n> atom types", "<lo> <hi> xlo xhi" ...
+  // ('#' starts a comment, blank lines are skipped) until the first line that is none of these
+  *natoms = 0;
+  prd[0] = prd[1] = prd[2] = 0;
+  bool have_line = false;
+  if(!fgets(line, sizeof(line), d.fp)) line[0] = '\0';
+  while(true) {
+    if(!fgets(line, sizeof(line), d.fp)) { line[0] = '\0'; break; }
+    if(char* c = strchr(line, '#')) *c = '\0';
+    if(LammpsData::blank(line)) continue;
+    double lo = 0, hi = 0;
+    int ntypes_file = 0;
+    if(strstr(line, "atoms")) sscanf(line, "%i", natoms);
+    else if(strstr(line, "atom types")) sscanf(line, "%i", &ntypes_file);     // read and ignored, like the reference
+    else if(strstr(line, "xlo xhi")) { sscanf(line, "%lg %lg", &lo, &hi); prd[0] = hi - lo; }
+    else if(strstr(line, "ylo yhi")) { sscanf(line, "%lg %lg", &lo, &hi); prd[1] = hi - lo; }
+    else if(strstr(line, "zlo zhi")) { sscanf(line, "%lg %lg", &lo, &hi); prd[2] = hi - lo; }
+    else { have_line = true; break; }
+  }
+  if(*natoms <= 0 || !(prd[0] > 0 && prd[1] > 0 && prd[2] > 0)) {
+    fclose(d.fp);
+    mmd_set_error("%s: data file header needs '<n> atoms' and the xlo xhi / ylo yhi / zlo zhi lines", file);
+    return -1;
+  }
+  if(!have_line) { fclose(d.fp); mmd_set_error("%s: no Atoms section", file); return -1; }
+  if(mass) *mass = -1;                       // stays -1 when the file has no Masses section
+  const bool fill = x && v;
+  if(fill) for(size_t i = 0; i < (size_t)3 * *natoms; i++) { x[i] = 0; v[i] = 0; }
+  d.next_keyword(line, true);
+  bool atoms_seen = false;
+  int rc = 0;
+  while(!d.keyword.empty() && rc == 0) {
+    if(d.keyword == "Atoms" || d.keyword == "Velocities") {          // ref :165-216: <id> [<type>] <a> <b> <c>, 1-based ids
+      const bool pos = d.keyword == "Atoms";
+      if(!pos && !atoms_seen) { mmd_set_error("%s: Must read Atoms before Velocities", file); rc = -1; break; }
+      for(int n = 0; n < *natoms; n++) {
+        if(!fgets(line, sizeof(line), d.fp)) { mmd_set_error("%s: unexpected end of file in section %s", file, d.keyword.c_str()); rc = -1; break; }
+        int id = 0, type = 0;
+        double a = 0, b = 0, c = 0;
+        const int got = pos ? sscanf(line, "%i %i %lg %lg %lg", &id, &type, &a, &b, &c) : sscanf(line, "%i %lg %lg %lg", &id, &a, &b, &c);
+        if(got != (pos ? 5 : 4) || id < 1 || id > *natoms) { mmd_set_error("%s: bad line in section %s: %s", file, d.keyword.c_str(), line); rc = -1; break; }
+        if(fill) { mmd_float* q = (pos ? x : v) + 3 * (size_t)(id - 1); q[0] = a; q[1] = b; q[2] = c; }
+      }
+      atoms_seen = atoms_seen || pos;
+    } else if(d.keyword == "Masses") {                                 // ref :267-276: one line "<type> <mass>"
+      double m = 0; int t = 0;
+      if(fgets(line, sizeof(line), d.fp) && sscanf(line, "%i %lg", &t, &m) == 2 && mass) *mass = (mmd_float)m;
+    } else {
+      mmd_set_error("Unknown identifier in data file: %s", d.keyword.c_str());
+      rc = -1;
+      break;
+    }
+    if(rc == 0) d.next_keyword(line, false);
+  }
+  fclose(d.fp);
+  if(rc == 0 && !atoms_seen) { mmd_set_error("%s: no Atoms section", file); rc = -1; }
+  return rc;
+}
+
+// atoms of the sub-box [lo,hi) in file order (ref/setup.cpp:281-286, Atom::addatom ref/atom.cpp:86-100); tag = file id.
+// Two-call protocol like mmd_create_atoms.
+extern "C" int mmd_lammps_data_select(int natoms, const mmd_float* x_all, const mmd_float* v_all, const mmd_float lo[3], const mmd_float hi[3],
+                                      int ntypes, mmd_float* x, mmd_float* v, int* type, int* tag, int* nlocal)
+{
+  if(!x_all || !v_all || !nlocal || ntypes < 1) { mmd_set_error("mmd_lammps_data_select: bad arguments"); return -1; }
+  TypeStream types;
+  int count = 0;
+  for(int i = 0; i < natoms; i++) {
+    const mmd_float* p = x_all + 3 * (size_t)i;
+    if(!(p[0] >= lo[0] && p[0] < hi[0] && p[1] >= lo[1] && p[1] < hi[1] && p[2] >= lo[2] && p[2] < hi[2])) continue;
+    if(x) {
+      for(int d = 0; d < 3; d++) { x[3 * (size_t)count + d] = p[d]; v[3 * (size_t)count + d] = v_all[3 * (size_t)i + d]; }
+      type[count] = types.next(ntypes);
+      if(tag) tag[count] = i + 1;
+    }
+    count++;
+  }
+  *nlocal = count;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // EAM: DYNAMO funcfl file -> uniform-grid arrays -> 7-coefficient splines (ref/force_eam.cpp:505-793)
 // ---------------------------------------------------------------------------------------------------
 namespace {

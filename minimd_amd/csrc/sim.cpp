@@ -204,7 +204,6 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     else if(is_flag(a, "-h", "--help")) { if(s->me == 0) print_help(); delete s; return 1; }
     // unknown flags are ignored, like the reference (run_one_test passes -dm)
   }
-  if(s->in.has_datafile) { mmd_set_error("LAMMPS data files (-f) are not supported yet"); if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
   // --half_neigh -1 ("original miniMD force", ref/force_lj.cpp:118-176) computes the same half-list physics with
   // force on both partners and a reverse halo; on the device it is the half-list + ghost-newton path
   if(s->halfneigh < 0) s->ghost_newton = s->in.forcetype == 1 ? 0 : 1;
@@ -219,8 +218,25 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     if(ny > 0) s->in.ny = ny; else if(system_size < 0) s->in.ny = nx;
     if(nz > 0) s->in.nz = nz; else if(system_size < 0) s->in.nz = nx;
   }
+  // LAMMPS data file (ref/ljs.cpp:385-391, ref/setup.cpp:218-301): every rank parses the whole file, like the reference
+  std::vector<mmd_float> file_x, file_v;
+  int file_natoms = 0;
+  mmd_float file_mass = -1;
+  if(s->in.has_datafile) {
+    int rc = mmd_lammps_data_read(s->in.datafile, &file_natoms, s->prd, &file_mass, nullptr, nullptr);
+    if(rc == 0) {
+      file_x.resize((size_t)3 * file_natoms); file_v.resize((size_t)3 * file_natoms);
+      rc = mmd_lammps_data_read(s->in.datafile, &file_natoms, s->prd, &file_mass, file_x.data(), file_v.data());
+    }
+    if(rc) { if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
+  }
   if(neighbor_size > 0) s->nbin[0] = s->nbin[1] = s->nbin[2] = neighbor_size;
-  else {
+  else if(s->in.has_datafile) {                   // bins from the number density (ref/setup.cpp:229-236)
+    const mmd_float volume = s->prd[0] * s->prd[1] * s->prd[2];
+    const mmd_float rho = 1.0 * file_natoms / volume;
+    const mmd_float neigh_bin_size = std::pow(rho * 16, mmd_float(1.0 / 3.0));
+    for(int d = 0; d < 3; d++) s->nbin[d] = s->prd[d] / neigh_bin_size;
+  } else {
     const mmd_float neighscale = 5.0 / 6.0;       // evaluated in MMD_float (ref/ljs.cpp:357-362)
     s->nbin[0] = neighscale * s->in.nx; s->nbin[1] = neighscale * s->in.ny; s->nbin[2] = neighscale * s->in.nz;
   }
@@ -232,7 +248,11 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
   if(mmd_create(-1, &s->h)) { if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
   mmd_handle* h = s->h;
 #define SIM_TRY(expr) do { if((expr) < 0) { if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); mmd_sim_destroy(s); return -1; } } while(0)
-  mmd_create_box(s->in.nx, s->in.ny, s->in.nz, s->in.rho, s->prd);
+  if(s->in.has_datafile) {                         // ref/ljs.cpp:387-388
+    const mmd_float volume = s->prd[0] * s->prd[1] * s->prd[2];
+    s->in.rho = 1.0 * file_natoms / volume;
+    if(file_mass >= 0) s->mass = file_mass;        // "Masses" section (ref/setup.cpp:267-276); EAM overrides it below
+  } else mmd_create_box(s->in.nx, s->in.ny, s->in.nz, s->in.rho, s->prd);
   { const mmd_float zero[3] = {0, 0, 0}; SIM_TRY(mmd_atom_set_box(h, s->prd, zero, s->prd)); }
   SIM_TRY(mmd_comm_setup(h, s->in.neigh_cut, s->me, s->nprocs));
   if(s->nprocs > 1 && g_host_sr) {
@@ -267,11 +287,24 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     s->in.force_cut = cutmax;
   }
   SIM_TRY(mmd_atom_set_mass(h, s->mass));
-  // create_atoms (ref/setup.cpp:315-450) for my sub-box
   int nlocal = 0;
+  std::vector<mmd_float> x, v;
+  std::vector<int> type, tag;
+  if(s->in.has_datafile) {
+    // atoms of my sub-box in file order, velocities as read (no create_velocity) — ref/setup.cpp:281-297
+    SIM_TRY(mmd_lammps_data_select(file_natoms, file_x.data(), file_v.data(), h->lo, h->hi, s->ntypes, nullptr, nullptr, nullptr, nullptr, &nlocal));
+    x.resize((size_t)3 * nlocal + 3); v.resize((size_t)3 * nlocal + 3); type.resize(nlocal + 1); tag.resize(nlocal + 1);
+    SIM_TRY(mmd_lammps_data_select(file_natoms, file_x.data(), file_v.data(), h->lo, h->hi, s->ntypes, x.data(), v.data(), type.data(), tag.data(), &nlocal));
+    s->natoms = file_natoms;
+    double cnt = nlocal;
+    SIM_TRY(mmd_transport_allreduce(h, &cnt, 1));
+    if((long long)cnt != s->natoms && s->me == 0 && !quiet) printf("Created incorrect # of atoms\n");   // the reference goes on
+    thermo_setup(s);
+    file_x.clear(); file_x.shrink_to_fit(); file_v.clear(); file_v.shrink_to_fit();
+  } else {
+  // create_atoms (ref/setup.cpp:315-450) for my sub-box
   SIM_TRY(mmd_create_atoms(s->in.nx, s->in.ny, s->in.nz, s->in.rho, h->lo, h->hi, s->ntypes, nullptr, nullptr, nullptr, nullptr, &nlocal));
-  std::vector<mmd_float> x((size_t)3 * nlocal + 3), v((size_t)3 * nlocal + 3);
-  std::vector<int> type(nlocal + 1), tag(nlocal + 1);
+  x.resize((size_t)3 * nlocal + 3); v.resize((size_t)3 * nlocal + 3); type.resize(nlocal + 1); tag.resize(nlocal + 1);
   SIM_TRY(mmd_create_atoms(s->in.nx, s->in.ny, s->in.nz, s->in.rho, h->lo, h->hi, s->ntypes, x.data(), v.data(), type.data(), tag.data(), &nlocal));
   s->natoms = 4 * s->in.nx * s->in.ny * s->in.nz;
   { double cnt = nlocal; SIM_TRY(mmd_transport_allreduce(h, &cnt, 1));
@@ -295,6 +328,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     const double factor = sqrt(s->in.t_request / t);
     for(size_t i = 0; i < (size_t)3 * nlocal; i++) v[i] *= factor;
   }
+  }
   SIM_TRY(mmd_atom_upload(h, x.data(), v.data(), type.data(), tag.data(), nlocal, 0));
   // dtforce chain: 0.5*dt [/mvv2e] /mass (ref/integrate.cpp:43,80-81; ref/thermo.cpp:69)
   SIM_TRY(mmd_integrate_setup(h, s->dt, s->dtforce / s->mass, s->in.neigh_every, s->sort_every));
@@ -306,7 +340,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     fprintf(stdout, "\t# MPI processes: %i\n", s->nprocs);
     fprintf(stdout, "\t# OpenMP threads: %i\n", s->num_threads);
     fprintf(stdout, "\t# Inputfile: %s\n", s->input_file.c_str());
-    fprintf(stdout, "\t# Datafile: %s\n", "None");
+    fprintf(stdout, "\t# Datafile: %s\n", s->in.has_datafile ? s->in.datafile : "None");
     fprintf(stdout, "# Physics Settings: \n");
     fprintf(stdout, "\t# ForceStyle: %s\n", s->in.forcetype == 0 ? "LJ" : "EAM");
     fprintf(stdout, "\t# Force Parameters: %2.2lf %2.2lf\n", (double)s->in.epsilon, (double)s->in.sigma);
@@ -483,7 +517,7 @@ extern "C" int mmd_sim_output(mmd_sim* s, int screen_yaml)
   out("  mpi_processes: %i\n", s->nprocs);
   out("  thread_teams: %i\n", 1);
   out("  threads: %i\n", s->num_threads);
-  out("  datafile: %s\n", "None");
+  out("  datafile: %s\n", s->in.has_datafile ? s->in.datafile : "None");
   out("  units: %s\n", s->in.units == 0 ? "LJ" : "METAL");
   out("  atoms: %i\n", s->natoms);
   out("  atom_types: %i\n", s->ntypes);
