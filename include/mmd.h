@@ -136,6 +136,11 @@ int mmd_comm_download_lists(mmd_handle* h, int iswap, int* sendlist);  /* sendli
 int mmd_integrate_setup(mmd_handle* h, mmd_float dt, mmd_float dtforce, int neigh_every, int sort_every);
 int mmd_integrate_initial(mmd_handle* h);          /* Integrate::initialIntegrate ref/integrate.cpp:46-57 */
 int mmd_integrate_final(mmd_handle* h);            /* Integrate::finalIntegrate   ref/integrate.cpp:59-68 */
+/* --check_exchange (ref/integrate.cpp:112-151, 168-169): mark the owned atoms' positions (the reference's xold copy
+ * after borders) / largest distance any owned atom moved since the mark, with the reference's +-prd correction.
+ * mmd_integrate_run does both and prints the reference's warning when mmd_set_option(h, "check_exchange", 1). */
+int mmd_integrate_mark_positions(mmd_handle* h);
+int mmd_integrate_max_move(mmd_handle* h, double* d_max);
 /* sum_i m v_i^2 over owned atoms (the loop of Thermo::temperature, ref/thermo.cpp:151-157) */
 int mmd_thermo_temperature(mmd_handle* h, double* sum_mv2);
 /* Called on thermo steps with globally reduced raw sums; the host applies the unit scales

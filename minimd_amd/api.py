@@ -72,7 +72,7 @@ def load_library(precision="dp"):
         "mmd_comm_exchange": [P], "mmd_comm_borders": [P], "mmd_comm_communicate": [P],
         "mmd_comm_reverse_communicate": [P], "mmd_comm_download_lists": [P, I, ip],
         "mmd_integrate_setup": [P, creal, creal, I, I], "mmd_integrate_initial": [P], "mmd_integrate_final": [P],
-        "mmd_thermo_temperature": [P, dp], "mmd_integrate_run": [P, I, I, I, P, P],
+        "mmd_thermo_temperature": [P, dp], "mmd_integrate_mark_positions": [P], "mmd_integrate_max_move": [P, dp], "mmd_integrate_run": [P, I, I, I, P, P],
         "mmd_timers": [P, dp, dp, ip], "mmd_profile_kernel": [P, I, I, dp], "mmd_set_option": [P, C.c_char_p, I],
         "mmd_sync": [P],
         "mmd_input_read": [P, C.c_char_p], "mmd_create_box": [I, I, I, D, rp],
@@ -211,6 +211,14 @@ class Handle:
         t = C.c_longlong()
         self._chk(self.L.mmd_neighbor_info(self.h, C.byref(m), C.byref(b), C.byref(t), C.byref(mr)))
         return {"maxneighs": m.value, "mbins": b.value, "total": t.value, "max_row": mr.value}
+
+    def mark_positions(self):
+        self._chk(self.L.mmd_integrate_mark_positions(self.h))
+
+    def max_move(self):
+        d = C.c_double()
+        self._chk(self.L.mmd_integrate_max_move(self.h, C.byref(d)))
+        return d.value
 
     def neighbor_tile_stats(self):
         out = (C.c_longlong * 6)()

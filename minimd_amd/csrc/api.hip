@@ -103,6 +103,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "tile_waves")) h->opt_tile_waves = value;
   else if(!strcmp(name, "tile_unroll")) h->opt_tile_unroll = value;
   else if(!strcmp(name, "tile_read")) h->opt_tile_read = value;
+  else if(!strcmp(name, "check_exchange")) h->opt_check_exchange = value;
   else if(!strcmp(name, "maxneighs")) h->maxneighs = (value + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
   else { mmd_set_error("mmd_set_option: unknown option '%s'", name); return -1; }
   return 0;
@@ -185,6 +186,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     HIP_TRY(hipEventCreateWithFlags(&h->ev_x_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
   }
+  if(h->opt_check_exchange && h->xold_n != h->nlocal) MMD_TRY(mmd_integrate_mark_positions(h));
   for(int n = 0; n < ntimes; n++) {
     if(!initial_done) MMD_TRY(mmd_integrate_initial(h));
     initial_done = false;
@@ -209,10 +211,20 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         MMD_TRY(mmd_comm_communicate(h));
     } else {
       HIP_TRY(hipStreamSynchronize(h->stream));
+      if(h->opt_check_exchange && h->xold_n == h->nlocal) {    // ref/integrate.cpp:112-151 (warning text as there)
+        double d_max = 0;
+        MMD_TRY(mmd_integrate_max_move(h, &d_max));
+        const double sx = h->hi[0] - h->lo[0], sy = h->hi[1] - h->lo[1], sz = h->hi[2] - h->lo[2];
+        if(d_max > sx || d_max > sy || d_max > sz)
+          printf("Warning: Atoms move further than your subdomain size, which will eventually cause lost atoms.\n"
+                 "Increase reneighboring frequency or choose a different processor grid\n"
+                 "Maximum move distance: %lf; Subdomain dimensions: %lf %lf %lf\n", d_max, sx, sy, sz);
+      }
       t_prev = mmd_wall();
       MMD_TRY(mmd_comm_exchange(h));
       if(n + 1 >= next_sort) { MMD_TRY(mmd_atom_sort(h)); next_sort += h->sort_every; }
       MMD_TRY(mmd_comm_borders(h));
+      if(h->opt_check_exchange) MMD_TRY(mmd_integrate_mark_positions(h));
       HIP_TRY(hipStreamSynchronize(h->stream));
       double t = mmd_wall();
       h->timer[4] += t - t_prev; h->timer[1] += t - t_prev;     // TIME_TEST and TIME_COMM (ref :155-166)

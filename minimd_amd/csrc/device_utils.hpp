@@ -10,6 +10,15 @@ __device__ __forceinline__ T wave_sum(T v)
   for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
 __device__ __forceinline__ int wave_max_i(int v)
 {
 #pragma unroll

@@ -109,6 +109,60 @@ int mmd_temperature_async(mmd_handle* h, int slot)
   return 0;
 }
 
+// ---- --check_exchange (ref/integrate.cpp:112-151): largest move of an owned atom since the last re-neighboring ----
+// per-atom distance with the reference's single +-prd correction; squared maxima of non-negative doubles are
+// combined with an integer atomicMax on their bit patterns (order preserving)
+__global__ __launch_bounds__(256) void k_max_move(const real4* __restrict__ x, const real4* __restrict__ xold, int n, real px, real py, real pz,
+                                                  unsigned long long* __restrict__ out)
+{
+  __shared__ double s_red[4];
+  double m = 0;
+  for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const real4 a = x[i], b = xold[i];
+    double dx = (double)a.x - (double)b.x, dy = (double)a.y - (double)b.y, dz = (double)a.z - (double)b.z;
+    if(dx > px) dx -= px;
+    if(dx < -px) dx += px;
+    if(dy > py) dy -= py;
+    if(dy < -py) dy += py;
+    if(dz > pz) dz -= pz;
+    if(dz < -pz) dz += pz;
+    const double d = dx * dx + dy * dy + dz * dz;
+    m = d > m ? d : m;
+  }
+  m = wave_max_d(m);
+  if((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    for(int w = 1; w < (int)(blockDim.x >> 6); w++) m = s_red[w] > m ? s_red[w] : m;
+    atomicMax(out, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+extern "C" int mmd_integrate_mark_positions(mmd_handle* h)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  MMD_TRY(h->xold.ensure((size_t)h->nlocal + 1, false, h->stream));
+  if(h->nlocal) HIP_TRY(hipMemcpyAsync(h->xold.p, h->x.p, (size_t)h->nlocal * sizeof(real4), hipMemcpyDeviceToDevice, h->stream));
+  h->xold_n = h->nlocal;
+  return 0;
+}
+
+extern "C" int mmd_integrate_max_move(mmd_handle* h, double* d_max)
+{
+  if(!h || !d_max) { mmd_set_error("mmd_integrate_max_move: bad arguments"); return -1; }
+  if(h->xold_n != h->nlocal) { mmd_set_error("mmd_integrate_max_move: no marked positions for the current atoms"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemsetAsync(h->d_result + 8, 0, sizeof(double), h->stream));
+  if(h->nlocal) hipLaunchKernelGGL(k_max_move, dim3(512), dim3(256), 0, h->stream, h->x.p, h->xold.p, h->nlocal, h->prd[0], h->prd[1], h->prd[2],
+                                   (unsigned long long*)(h->d_result + 8));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->h_result + 8, h->d_result + 8, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *d_max = sqrt(h->h_result[8]);
+  return 0;
+}
+
 extern "C" int mmd_thermo_temperature(mmd_handle* h, double* sum_mv2)
 {
   if(!h || !sum_mv2) { mmd_set_error("mmd_thermo_temperature: bad arguments"); return -1; }

@@ -116,6 +116,8 @@ struct mmd_handle {
   real mass = 1;
   int nlocal = 0, nghost = 0, nmax = 0;
   DevArr<real4> x, x_alt;
+  DevArr<real4> xold;          // positions marked at the last re-neighboring (--check_exchange, ref/integrate.cpp:168-169)
+  int xold_n = -1;
   DevArr<real> v, v_alt, f;
   DevArr<int> type, type_alt, tag, tag_alt;
   // ---- Neighbor
@@ -149,6 +151,7 @@ struct mmd_handle {
   int opt_tiles = 1;
   int opt_force_transport = 0;   // testing: route self-swaps through the transport too (RCCL loop-back on one GPU)
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
+  int opt_check_exchange = 0;                     // --check_exchange: warn when an atom moved further than a sub-domain
   int opt_tile_read = 0;                          // 1: three separate 8-byte LDS reads per pair (A/B knob)
   int opt_fuse = 1;          // fused final+initial integrate, single-kernel ghost update on one rank
   int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)

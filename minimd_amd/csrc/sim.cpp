@@ -28,7 +28,7 @@ struct mmd_sim {
   mmd_input in;
   std::string input_file = "in.lj.miniMD";
   int me = 0, nprocs = 1, quiet = 0;
-  int num_threads = 1, ntypes = 4, halfneigh = 1, ghost_newton = 1, sort = -1, yaml_output = 0, yaml_screen = 0;
+  int num_threads = 1, ntypes = 4, halfneigh = 1, ghost_newton = 1, sort = -1, yaml_output = 0, yaml_screen = 0, check_exchange = 0;
   int nbin[3] = {1, 1, 1};
   int natoms = 0;
   int sort_every = 0;
@@ -121,7 +121,7 @@ static void print_help()
          "  -gn / --ghost_newton <int> Newton's third law across ghosts (half lists; default 1, EAM forces 0)\n"
          "  --sort <n>                 re-sort atoms every n steps (default: every re-neighboring, 0 never)\n"
          "  -u / --units <lj|metal>    -p / --force <lj|eam>    -t / --num_threads <int> (accepted, unused)\n"
-         "  -o / --yaml_output <int>   --yaml_screen   -f / --data_file <file>   -h / --help\n\n");
+         "  -o / --yaml_output <int>   --yaml_screen   -f / --data_file <file>   --check_exchange   -h / --help\n\n");
 }
 
 static void thermo_setup(mmd_sim* s)
@@ -197,6 +197,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     else if(is_flag(a, "--sort") && has) s->sort = atoi(argv[++i]);
     else if(is_flag(a, "-o", "--yaml_output") && has) s->yaml_output = atoi(argv[++i]);
     else if(is_flag(a, "--yaml_screen")) s->yaml_screen = 1;
+    else if(is_flag(a, "--check_exchange")) s->check_exchange = 1;
     else if(is_flag(a, "-f", "--data_file") && has) { s->in.has_datafile = 1; strncpy(s->in.datafile, argv[++i], sizeof(s->in.datafile) - 1); }
     else if(is_flag(a, "-u", "--units") && has) s->in.units = strcmp(argv[++i], "metal") == 0 ? 1 : 0;
     else if(is_flag(a, "-p", "--force") && has) s->in.forcetype = strcmp(argv[++i], "eam") == 0 ? 1 : 0;
@@ -332,6 +333,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
   SIM_TRY(mmd_atom_upload(h, x.data(), v.data(), type.data(), tag.data(), nlocal, 0));
   // dtforce chain: 0.5*dt [/mvv2e] /mass (ref/integrate.cpp:43,80-81; ref/thermo.cpp:69)
   SIM_TRY(mmd_integrate_setup(h, s->dt, s->dtforce / s->mass, s->in.neigh_every, s->sort_every));
+  if(s->check_exchange) SIM_TRY(mmd_set_option(h, "check_exchange", 1));
 #undef SIM_TRY
   if(s->me == 0 && !quiet) {
     printf("# Done .... \n");
