@@ -182,6 +182,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport) && h->style == 0 && !h->halfneigh;
   bool halo_pending = false;
   int evflag_pending = 0;
+  const bool fuse_force = h->opt_fuse >= 2 && !reverse && !h->halfneigh;
+  bool fused_force = false;          // this step's force launch carries finalIntegrate + the next initialIntegrate
   if(overlap && !h->ev_x_ready) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_x_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
@@ -204,7 +206,12 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         MMD_TRY(rc);
         HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
         if(h->time_force_events) MMD_TRY(ev_begin(h));
-        MMD_TRY(mmd_lj_compute_tiles_split(h, ev_now, 0));
+        fused_force = fuse_force && !ev_now && n + 1 < ntimes && mmd_lj_can_fuse_integrate(h);
+        if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
+        h->fuse_now = fused_force;
+        const int rc0 = mmd_lj_compute_tiles_split(h, ev_now, 0);
+        h->fuse_now = 0;
+        MMD_TRY(rc0);
         halo_pending = true;
         evflag_pending = ev_now;
       } else
@@ -239,13 +246,26 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     if(halo_pending) {
       // overlapped step: interior tiles ran under the halo; now wait for the ghosts and finish the boundary tiles
       HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
-      MMD_TRY(mmd_lj_compute_tiles_split(h, evflag_pending, 1));
+      h->fuse_now = fused_force;
+      const int rc1 = mmd_lj_compute_tiles_split(h, evflag_pending, 1);
+      h->fuse_now = 0;
+      MMD_TRY(rc1);
       if(h->time_force_events) MMD_TRY(ev_end(h));
       halo_pending = false;
-    } else
-      MMD_TRY(force_compute_async(h, evflag, nullptr, nullptr, true));
+    } else {
+      fused_force = fuse_force && !evflag && n + 1 < ntimes && h->style == 0 && mmd_lj_can_fuse_integrate(h);
+      if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
+      h->fuse_now = fused_force;
+      const int rc = force_compute_async(h, evflag, nullptr, nullptr, true);
+      h->fuse_now = 0;
+      MMD_TRY(rc);
+    }
     if(reverse) MMD_TRY(mmd_comm_reverse_communicate(h));
-    if(h->opt_fuse && !evflag && n + 1 < ntimes) {
+    if(fused_force) {
+      std::swap(h->x, h->x_alt);                 // the tile kernel wrote v and the next positions of every owned atom
+      initial_done = true;
+      fused_force = false;
+    } else if(h->opt_fuse && !evflag && n + 1 < ntimes) {
       MMD_TRY(mmd_integrate_final_initial(h));
       initial_done = true;
     } else MMD_TRY(mmd_integrate_final(h));

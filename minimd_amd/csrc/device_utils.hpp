@@ -53,6 +53,38 @@ __device__ __forceinline__ float wave_max_f(float v)
   MMD_DPP_STEP(fmaxf, 0x143, 0xc);
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// the same reductions on unsigned keys: integer min/max need no NaN canonicalisation, so every step is ONE
+// v_min_u32 / v_max_u32 with the DPP modifier folded in (the float versions cost ~5 instructions per step).
+// float_key() is the usual order-preserving map float -> unsigned (flip the sign bit of non-negative values, all
+// bits of negative ones); key_float() inverts it.
+__device__ __forceinline__ unsigned float_key(float f)
+{
+  const unsigned b = __builtin_bit_cast(unsigned, f);
+  return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k)
+{
+  return __builtin_bit_cast(float, k ^ ((k & 0x80000000u) ? 0x80000000u : 0xffffffffu));
+}
+// (lanes a step does not feed receive the operation's identity: that is the form the compiler folds into *_dpp)
+#define MMD_DPP_STEP_U(OP, IDENT, ctrl, rmask)                                                                      \
+  { const unsigned t_ = (unsigned)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, ctrl, rmask, 0xf, false); v = OP(v, t_); }
+__device__ __forceinline__ unsigned wave_min_u(unsigned v)
+{
+#define MMD_UMIN(a, b) ((a) < (b) ? (a) : (b))
+  MMD_DPP_STEP_U(MMD_UMIN, 0xffffffffu, 0x111, 0xf); MMD_DPP_STEP_U(MMD_UMIN, 0xffffffffu, 0x112, 0xf); MMD_DPP_STEP_U(MMD_UMIN, 0xffffffffu, 0x114, 0xf);
+  MMD_DPP_STEP_U(MMD_UMIN, 0xffffffffu, 0x118, 0xf); MMD_DPP_STEP_U(MMD_UMIN, 0xffffffffu, 0x142, 0xa); MMD_DPP_STEP_U(MMD_UMIN, 0xffffffffu, 0x143, 0xc);
+#undef MMD_UMIN
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u(unsigned v)
+{
+#define MMD_UMAX(a, b) ((a) > (b) ? (a) : (b))
+  MMD_DPP_STEP_U(MMD_UMAX, 0u, 0x111, 0xf); MMD_DPP_STEP_U(MMD_UMAX, 0u, 0x112, 0xf); MMD_DPP_STEP_U(MMD_UMAX, 0u, 0x114, 0xf);
+  MMD_DPP_STEP_U(MMD_UMAX, 0u, 0x118, 0xf); MMD_DPP_STEP_U(MMD_UMAX, 0u, 0x142, 0xa); MMD_DPP_STEP_U(MMD_UMAX, 0u, 0x143, 0xc);
+#undef MMD_UMAX
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // inclusive prefix sum over a wavefront
 __device__ __forceinline__ int wave_incl_scan(int v)
 {

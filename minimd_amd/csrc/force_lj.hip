@@ -168,13 +168,26 @@ __device__ __forceinline__ void lds_read3(unsigned a, real& qx, real& qy, real& 
 // Nothing static precedes it, so the 16-bit values of nl16 ARE the ds_read addresses of the records.
 __host__ __device__ constexpr int lj_tile_sf_bytes(int waves) { return 3 * 64 * (waves - 1) * (int)sizeof(real); }
 
-template <int EV, bool EXACT, int LJ_TILE_WAVES, int UNR, int RD>
+// v += dtf*f ; x += dt*v with separately rounded multiply and add, like integrate.hip (built without contraction).
+// This file is compiled with -ffp-contract=fast, which lets the backend fuse across a `#pragma clang fp contract(off)`
+// (seen for float); the empty asm makes the product opaque, so no fma can be formed.
+__device__ __forceinline__ real mul_add_unfused(real a, real b, real c)
+{
+  real p = a * b;
+  asm volatile("" : "+v"(p));
+  return p + c;
+}
+
+// FUSE=1 appends finalIntegrate of this step and initialIntegrate of the next one (ref/integrate.cpp:46-68) for the
+// tile's atoms: v and the NEW positions go to v / xnew (a second position buffer: other tiles still read the old x),
+// the caller swaps the buffers. Same operations in the same order as k_final_initial_integrate => same bits.
+template <int EV, bool EXACT, int LJ_TILE_WAVES, int UNR, int RD, int FUSE>
 __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, int pos_bytes, LJParams P, real* __restrict__ f,
-    double* __restrict__ partials, int ablate)
+    double* __restrict__ partials, int ablate, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   real* s_f = (real*)(s_raw + pos_bytes);
@@ -215,6 +228,8 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   for(int u = 0; u < UNR; u++) s[u] = k0 < k1 ? np[u * 64] : 0;
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
+  real vx0 = 0, vy0 = 0, vz0 = 0;          // FUSE: the velocity travels under the pair loop (wave 0 integrates)
+  if(FUSE && wv == 0 && i >= 0) { vx0 = v[3 * (size_t)i + 0]; vy0 = v[3 * (size_t)i + 1]; vz0 = v[3 * (size_t)i + 2]; }
   __syncthreads();
 
   real fx = 0, fy = 0, fz = 0;
@@ -256,7 +271,15 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   if(wv == 0 && i >= 0) {
 #pragma unroll
     for(int q = 0; q < LJ_TILE_WAVES - 1; q++) { const real* d = s_f + 3 * 64 * q; fx += d[lane]; fy += d[64 + lane]; fz += d[128 + lane]; }
-    f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz;
+    // (a fused step consumes the force here; f[] is next read after the unfused thermo / last step, which stores it)
+    if(!FUSE) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
+    if(FUSE) {
+      real vx = vx0, vy = vy0, vz = vz0;
+      vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
+      vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
+      v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
+      xnew[i] = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
+    }
   }
   if(EV) {
     if(i < 0) { e_acc = 0; v_acc = 0; }
@@ -401,6 +424,12 @@ int mmd_lj_tiles_available(mmd_handle* h)
   return h->style == 0 && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && lj_tile_pos_bytes(h) <= 60 * 1024 && h->neigh_nlocal == h->nlocal;
 }
 
+// the production tile kernel can carry finalIntegrate(n) + initialIntegrate(n+1) (no energy/virial on that step)
+int mmd_lj_can_fuse_integrate(mmd_handle* h)
+{
+  return mmd_lj_tiles_available(h) && h->opt_tile_waves == 2 && h->opt_tile_unroll == 8 && h->opt_tile_read == 0 && !h->opt_exact_div;
+}
+
 // launch the tile kernel over `count` tiles: tile ids from `list` (device) or 0..count-1
 static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
 {
@@ -409,19 +438,21 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   const int nlocal = h->nlocal;
   const int ev = evflag ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
   bool launched = false;
-#define TK(EVv, Xv, Wv, Uv, Rv) if(!launched && ev == EVv && ex == Xv && tw == Wv && tu == Uv && rd == Rv) { launched = true;        \
-    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv, Rv>), dim3(xcd_grid(count)), dim3(64 * Wv),                           \
+  const int fz = h->fuse_now ? 1 : 0;
+#define TK(EVv, Xv, Wv, Uv, Rv, Fv) if(!launched && ev == EVv && ex == Xv && tw == Wv && tu == Uv && rd == Rv && fz == Fv) { launched = true;  \
+    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv, Rv, Fv>), dim3(xcd_grid(count)), dim3(64 * Wv),                       \
                        pos_bytes + lj_tile_sf_bytes(Wv) + 16 * sizeof(double), h->stream, h->x.p,                                    \
                        h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
                        count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,              \
-                       h->partials.p, h->opt_ablate); }
+                       h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce); }
   const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = h->opt_tile_read;
-  TK(0, 0, 2, 8, 0); TK(1, 0, 2, 8, 0); TK(0, 1, 2, 8, 0); TK(1, 1, 2, 8, 0);      // production shape (+ exact-division check)
-  TK(0, 0, 2, 8, 1); TK(1, 0, 2, 8, 1); TK(0, 1, 2, 8, 1); TK(1, 1, 2, 8, 1);
-  TK(0, 0, 4, 8, 0); TK(1, 0, 4, 8, 0); TK(0, 0, 4, 8, 1); TK(1, 0, 4, 8, 1);      // tuning shapes
-  TK(0, 0, 1, 8, 0); TK(1, 0, 1, 8, 0); TK(0, 0, 1, 8, 1); TK(1, 0, 1, 8, 1);
-  TK(0, 0, 2, 4, 0); TK(1, 0, 2, 4, 0); TK(0, 0, 2, 4, 1); TK(1, 0, 2, 4, 1);
-  TK(0, 0, 4, 4, 0); TK(1, 0, 4, 4, 0); TK(0, 0, 4, 4, 1); TK(1, 0, 4, 4, 1);
+  TK(0, 0, 2, 8, 0, 1);                                                                          // production, integrator fused
+  TK(0, 0, 2, 8, 0, 0); TK(1, 0, 2, 8, 0, 0); TK(0, 1, 2, 8, 0, 0); TK(1, 1, 2, 8, 0, 0);        // production shape (+ exact-division check)
+  TK(0, 0, 2, 8, 1, 0); TK(1, 0, 2, 8, 1, 0);
+  TK(0, 0, 4, 8, 0, 0); TK(1, 0, 4, 8, 0, 0);                                                    // tuning shapes
+  TK(0, 0, 1, 8, 0, 0); TK(1, 0, 1, 8, 0, 0);
+  TK(0, 0, 2, 4, 0, 0); TK(1, 0, 2, 4, 0, 0);
+  TK(0, 0, 4, 4, 0, 0); TK(1, 0, 4, 4, 0, 0);
 #undef TK
   if(!launched) { mmd_set_error("tile force kernel: unsupported tile_waves/tile_unroll/tile_read combination"); return -1; }
   HIP_TRY(hipGetLastError());

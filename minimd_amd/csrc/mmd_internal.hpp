@@ -153,7 +153,9 @@ struct mmd_handle {
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
   int opt_check_exchange = 0;                     // --check_exchange: warn when an atom moved further than a sub-domain
   int opt_tile_read = 0;                          // 1: three separate 8-byte LDS reads per pair (A/B knob)
-  int opt_fuse = 1;          // fused final+initial integrate, single-kernel ghost update on one rank
+  int opt_fuse = 2;          // >=1: fused final+initial integrate, single-kernel ghost update on one rank; 2: integrator inside the LJ tile kernel
+  int fuse_now = 0;          // transient: the next tile launch carries the integrator
+  const void* xalt_dummy_ptr = nullptr; int xalt_dummy_slot = -1;
   int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)
   // ---- Force
   int style = 0;             // 0 LJ, 1 EAM
@@ -207,6 +209,8 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_zero_forces(mmd_handle* h, int n);
 int mmd_lj_tiles_available(mmd_handle* h);
+int mmd_lj_can_fuse_integrate(mmd_handle* h);
+int mmd_prepare_x_alt(mmd_handle* h);        // second position buffer (capacity + dummy atom) for the fused force+integrate kernel
 int mmd_lj_compute_tiles_split(mmd_handle* h, int evflag, int part);   // part 0: interior tiles, 1: boundary tiles + energy sum
 int mmd_order_tiles(mmd_handle* h);
 int mmd_ensure_rows(mmd_handle* h);       // materialise `neigh` from the tile form when a kernel needs it

@@ -432,10 +432,10 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
   for(int c = 0; c < NB_CHUNKS; c++) {
     if(c < nchunks && !(ablate & 4)) {
       const bool valid = cj[c] >= 0;
-      const float fx = (float)cx[c], fy = (float)cy[c], fz = (float)cz[c];
-      const float mnx = wave_min_f(valid ? fx : 3.0e38f), mxx = wave_max_f(valid ? fx : -3.0e38f);
-      const float mny = wave_min_f(valid ? fy : 3.0e38f), mxy = wave_max_f(valid ? fy : -3.0e38f);
-      const float mnz = wave_min_f(valid ? fz : 3.0e38f), mxz = wave_max_f(valid ? fz : -3.0e38f);
+      const unsigned kx = float_key((float)cx[c]), ky = float_key((float)cy[c]), kz = float_key((float)cz[c]);
+      const float mnx = key_float(wave_min_u(valid ? kx : 0xffffffffu)), mxx = key_float(wave_max_u(valid ? kx : 0u));
+      const float mny = key_float(wave_min_u(valid ? ky : 0xffffffffu)), mxy = key_float(wave_max_u(valid ? ky : 0u));
+      const float mnz = key_float(wave_min_u(valid ? kz : 0xffffffffu)), mxz = key_float(wave_max_u(valid ? kz : 0u));
       if(lane == c) { bx0 = mnx; bx1 = mxx; by0 = mny; by1 = mxy; bz0 = mnz; bz1 = mxz; }
     }
   }

@@ -117,6 +117,18 @@ __global__ void k_set_dummy(real4* x, int slot)
   x[slot] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
 }
 
+int mmd_prepare_x_alt(mmd_handle* h)
+{
+  MMD_TRY(h->x_alt.ensure((size_t)h->nmax + 1, false, h->stream));
+  const int slot = h->nlocal + h->nghost;
+  if(h->xalt_dummy_ptr != (const void*)h->x_alt.p || h->xalt_dummy_slot != slot) {
+    hipLaunchKernelGGL(k_set_dummy, dim3(1), dim3(1), 0, h->stream, h->x_alt.p, slot);
+    HIP_TRY(hipGetLastError());
+    h->xalt_dummy_ptr = h->x_alt.p; h->xalt_dummy_slot = slot;
+  }
+  return 0;
+}
+
 int mmd_set_dummy(mmd_handle* h)
 {
   hipLaunchKernelGGL(k_set_dummy, dim3(1), dim3(1), 0, h->stream, h->x.p, h->nlocal + h->nghost);

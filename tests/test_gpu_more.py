@@ -421,3 +421,23 @@ def test_check_exchange_flag_is_silent_on_a_healthy_run_and_changes_nothing():
         outs.append(r.stdout)
     assert "Warning: Atoms move further" not in outs[1]          # (the reference's own check misfires here: DESIGN.md §7)
     assert [r_[:4] for r_ in parse_thermo(outs[0])] == [r_[:4] for r_ in parse_thermo(outs[1])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_integrator_inside_the_force_kernel_is_bit_identical(prec):
+    """fuse=2 (default: finalIntegrate(n)+initialIntegrate(n+1) at the end of the LJ tile kernel, positions double
+    buffered) against fuse=1 (separate k_final_initial_integrate) and fuse=0 (reference call order): same bits after
+    130 steps with 6 re-neighborings, thermo rows included"""
+    res = []
+    for fuse in (2, 1, 0):
+        s = mm().Sim(["-s", "8", "-n", "130", "--half_neigh", "0"], precision=prec)
+        s.handle.set_option("fuse", fuse)
+        s.initial(); s.run()
+        d = s.handle.download()
+        res.append((s.rows(), d["x"][:d["nlocal"]].copy(), d["v"].copy(), d["f"].copy(), d["tag"].copy()))
+        s.close()
+    for other in res[1:]:
+        assert res[0][0] == other[0]
+        for a, b in zip(res[0][1:], other[1:]):
+            assert np.array_equal(a, b)

@@ -29,7 +29,7 @@ print("atoms", nl, "ghosts", ng, "kbar %.2f" % (info["total"] / nl), "maxneighs"
 print("tile stats", h.neighbor_tile_stats())
 names = {0: "force", 1: "neighbor_build(+binning)", 2: "initial_integrate", 3: "final_integrate", 4: "communicate"}
 for k in [int(q) for q in a.kernels.split(",")]:
-    ms = h.profile_kernel(k, a.reps if k != 1 else 3)
+    ms = h.profile_kernel(k, a.reps if k != 1 else 12)
     print("%-28s %.4f ms" % (names[k], ms))
 if a.ab:
     for rnd in range(3):
@@ -40,7 +40,7 @@ if os.environ.get("BUILDAB"):
     for ab in (0, 1, 8, 9, 13, 16):
         h.set_option("ablate", ab)
         try:
-            print("ablate=%d  neighbor build %.4f ms" % (ab, h.profile_kernel(1, 3)))
+            print("ablate=%d  neighbor build %.4f ms" % (ab, h.profile_kernel(1, 12)))
         except Exception as e:
             print("ablate=%d failed: %s" % (ab, e))
     h.set_option("ablate", 0)
