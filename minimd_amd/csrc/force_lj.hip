@@ -51,6 +51,9 @@ __device__ __forceinline__ float recip(float a)
   return __builtin_fmaf(e, r, r);
 }
 
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 struct LJTables {       // general (non-uniform) case: per type-pair tables staged in LDS by the kernel
   const real* cutforcesq;
   const real* sigma6;
@@ -248,29 +251,32 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     }
 #pragma unroll
     for(int u = 0; u < UNR; u++) {
+      // every multiply-add is written as an explicit fma: with -ffp-contract=fast the compiler would otherwise be
+      // free to pick WHICH product of a sum it fuses, and the instantiations of this template must round alike
       const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
-      const real rsq = dx * dx + dy * dy + dz * dz;
+      const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));
       const bool in = rsq < P.cutforcesq;
       const real sr2 = keep_if(in, EXACT ? recip<true>(rsq) : recip_fast(rsq));   // out of range => everything below is 0
       const real A = (sr2 * sr2) * sr2;
-      const real t = A * P.sigma6 - (real)0.5;
+      const real t = fma_r(A, P.sigma6, (real)-0.5);
       const real fs = (A * sr2) * t;               // force / c_out
-      fx += dx * fs; fy += dy * fs; fz += dz * fs;
+      fx = fma_r(dx, fs, fx); fy = fma_r(dy, fs, fy); fz = fma_r(dz, fs, fz);
       if(EV) {
         const real sr6 = A * P.sigma6;
-        e_acc += (double)(sr6 * (sr6 - (real)1.0) * P.epsilon);
-        v_acc += (double)(rsq * fs);
+        e_acc = __builtin_fma((double)(sr6 * (sr6 - (real)1.0)), (double)P.epsilon, e_acc);
+        v_acc = __builtin_fma((double)rsq, (double)fs, v_acc);
       }
     }
   }
-  fx *= c_out; fy *= c_out; fz *= c_out;
   v_acc *= (double)c_out;
-  // combine the wave slices
+  // combine the wave slices, THEN apply the folded constant: (a + b) * c leaves the compiler no multiply-add to
+  // contract, so every instantiation of this kernel rounds the force identically
   if(wv > 0) { real* d = s_f + 3 * 64 * (wv - 1); d[lane] = fx; d[64 + lane] = fy; d[128 + lane] = fz; }
   __syncthreads();
   if(wv == 0 && i >= 0) {
 #pragma unroll
     for(int q = 0; q < LJ_TILE_WAVES - 1; q++) { const real* d = s_f + 3 * 64 * q; fx += d[lane]; fy += d[64 + lane]; fz += d[128 + lane]; }
+    fx *= c_out; fy *= c_out; fz *= c_out;
     // (a fused step consumes the force here; f[] is next read after the unfused thermo / last step, which stores it)
     if(!FUSE) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
     if(FUSE) {

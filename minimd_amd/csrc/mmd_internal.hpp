@@ -126,6 +126,7 @@ struct mmd_handle {
   int halfneigh = 0, ghost_newton = 0, ntypes = 1;
   BinGeom bg;
   DevArr<int> bin_count, bin_start, binned, scan_tmp, atom_bin;
+  DevArr<int> atom_rank;       // arrival rank of each atom inside its bin (k_bin_count)
   int maxneighs = 100;       // row stride (multiple of MMD_UNROLL)
   DevArr<int> neigh, numneigh, wave_max;
   int neigh_nlocal = 0;      // nlocal the list was built for
@@ -155,7 +156,7 @@ struct mmd_handle {
   int opt_tile_read = 0;                          // 1: three separate 8-byte LDS reads per pair (A/B knob)
   int opt_fuse = 2;          // >=1: fused final+initial integrate, single-kernel ghost update on one rank; 2: integrator inside the LJ tile kernel
   int fuse_now = 0;          // transient: the next tile launch carries the integrator
-  const void* xalt_dummy_ptr = nullptr; int xalt_dummy_slot = -1;
+  const void* xalt_dummy_ptr[2] = {nullptr, nullptr}; int xalt_dummy_slot[2] = {-1, -1}; int xalt_dummy_next = 0;
   int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)
   // ---- Force
   int style = 0;             // 0 LJ, 1 EAM

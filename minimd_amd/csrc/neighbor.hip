@@ -93,24 +93,25 @@ __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
 // ---------------------------------------------------------------------------------------------------
 // Neighbor::binatoms (ref/neighbor.cpp:215-268): histogram, scan, fill, in-bin sort
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_bin_count(const real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ bin_count)
+// the histogram atomic also hands every atom its arrival rank inside the bin, so the fill pass needs neither a
+// second round of atomics nor a zeroed cursor array (the arrival order is made deterministic by k_bin_sort)
+__global__ void k_bin_count(const real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ atom_rank,
+                            int* __restrict__ bin_count)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n) return;
   const real4 p = x[i];
   const int b = bin_of(g, p.x, p.y, p.z);
   atom_bin[i] = b;
-  atomicAdd(&bin_count[b], 1);
+  atom_rank[i] = atomicAdd(&bin_count[b], 1);
 }
 
-__global__ void k_bin_fill(const int* __restrict__ atom_bin, int n, const int* __restrict__ bin_start, int* __restrict__ cursor,
+__global__ void k_bin_fill(const int* __restrict__ atom_bin, const int* __restrict__ atom_rank, int n, const int* __restrict__ bin_start,
                            int* __restrict__ binned)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n) return;
-  const int b = atom_bin[i];
-  const int slot = atomicAdd(&cursor[b], 1);
-  binned[bin_start[b] + slot] = i;
+  binned[bin_start[atom_bin[i]] + atom_rank[i]] = i;
 }
 
 // one thread per bin: insertion sort of its (short) slice -> ascending atom index, run-to-run identical
@@ -132,13 +133,13 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   const int n = count < 0 ? h->nlocal + h->nghost : count;
   const BinGeom& g = h->bg;
   MMD_TRY(h->atom_bin.ensure((size_t)n + 1, false, h->stream));
+  MMD_TRY(h->atom_rank.ensure((size_t)n + 1, false, h->stream));
   MMD_TRY(h->binned.ensure((size_t)n + 1, false, h->stream));
   HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
-  if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->bin_count.p);
+  if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p);
   HIP_TRY(hipMemcpyAsync(h->bin_start.p, h->bin_count.p, ((size_t)g.mbins + 1) * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
   MMD_TRY(mmd_exclusive_scan(h, h->bin_start.p, g.mbins, nullptr));
-  HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));   // reused as fill cursor
-  if(n) hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->atom_bin.p, n, h->bin_start.p, h->bin_count.p, h->binned.p);
+  if(n) hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p);
   hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -121,10 +121,14 @@ int mmd_prepare_x_alt(mmd_handle* h)
 {
   MMD_TRY(h->x_alt.ensure((size_t)h->nmax + 1, false, h->stream));
   const int slot = h->nlocal + h->nghost;
-  if(h->xalt_dummy_ptr != (const void*)h->x_alt.p || h->xalt_dummy_slot != slot) {
+  // the two position buffers alternate every fused step; each needs its dummy atom written once per re-neighboring
+  int q = -1;
+  for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x_alt.p) q = k;
+  if(q < 0) { q = h->xalt_dummy_next; h->xalt_dummy_next ^= 1; h->xalt_dummy_ptr[q] = h->x_alt.p; h->xalt_dummy_slot[q] = -1; }
+  if(h->xalt_dummy_slot[q] != slot) {
     hipLaunchKernelGGL(k_set_dummy, dim3(1), dim3(1), 0, h->stream, h->x_alt.p, slot);
     HIP_TRY(hipGetLastError());
-    h->xalt_dummy_ptr = h->x_alt.p; h->xalt_dummy_slot = slot;
+    h->xalt_dummy_slot[q] = slot;
   }
   return 0;
 }
@@ -133,5 +137,6 @@ int mmd_set_dummy(mmd_handle* h)
 {
   hipLaunchKernelGGL(k_set_dummy, dim3(1), dim3(1), 0, h->stream, h->x.p, h->nlocal + h->nghost);
   HIP_TRY(hipGetLastError());
+  for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x.p) h->xalt_dummy_slot[k] = h->nlocal + h->nghost;
   return 0;
 }
