@@ -113,6 +113,9 @@ def main():
     sim_args = ["-i", "in.lj.miniMD", "-nx", nx, "-ny", ny, "-nz", nz, "--half_neigh", "0", "-n", args.steps]
     sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
     natoms = sim.natoms()
+    for kv in filter(None, os.environ.get("MMD_BENCH_OPTIONS", "").split(",")):     # A/B knobs, e.g. "build_waves=1,fuse=1"
+        k, v = kv.split("=")
+        sim.handle.set_option(k, int(v))
     sim.initial()
     if args.warmup > 0:
         sim.run_steps(args.warmup)
