@@ -13,6 +13,7 @@
 // general kernels index the per-pair tables in global memory.
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"
+#include "tile_lds.hpp"
 
 #define EAM_MAX_KNOTS 1024
 #define EAM_UNR 4
@@ -177,6 +178,22 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_force(const real4* __restrict
 }
 
 
+// 1/sqrt(a) for a in the pair range (0.1 .. 100): v_rsq + one Newton step with the second-order term
+// (y(1 + e/2 + 3e^2/8), e = 1 - a y^2) => ~1 ulp, instead of the ~25-instruction IEEE sqrt and the ~13-instruction
+// IEEE divide the compiler expands sqrt(rsq) and 1.0/r into; r = a * rsqrt(a).
+__device__ __forceinline__ double rsqrt_fast(double a)
+{
+  const double y = __builtin_amdgcn_rsq(a);
+  const double e = __builtin_fma(-(a * y), y, 1.0);
+  return __builtin_fma(y, e * __builtin_fma(0.375, e, 0.5), y);
+}
+__device__ __forceinline__ float rsqrt_fast(float a)
+{
+  const float y = __builtin_amdgcn_rsqf(a);
+  const float e = __builtin_fmaf(-(a * y), y, 1.0f);
+  return __builtin_fmaf(y, e * __builtin_fmaf(0.375f, e, 0.5f), y);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Tile forms of the two sweeps (same data structure as k_lj_full_tile, force_lj.hip): the tile's candidate
 // union is staged in LDS ({x,y,z} records, and fp for sweep 2) next to the re-packed spline knots; every pair
@@ -186,21 +203,27 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_force(const real4* __restrict
 #define EAM_TU 4
 #define EAM_STAGE 4
 
+// dynamic LDS of both kernels (nothing static precedes it, see tile_lds.hpp):
+//   [{x,y,z} records of the candidates: eam_pos_bytes(cmax)] [force sweep only: fp of the candidates] [spline knots] [partials] [16 doubles]
+__host__ __device__ constexpr size_t eam_pos_bytes(int cmax) { return (((size_t)3 * (cmax + 2) * sizeof(real)) + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t eam_fp_bytes(int cmax) { return (((size_t)(cmax + 2) * sizeof(real)) + 15) & ~(size_t)15; }
+
 template <int EV>
 __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
-    const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, real rdr, real rdrho, real* __restrict__ fp,
+    const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, int cmax, real rdr, real rdrho, real* __restrict__ fp,
     double* __restrict__ partials)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
-  __shared__ real s_part[64 * (EAM_TW - 1) + 1];
-  __shared__ double s_red[16];
   constexpr int NT = 64 * EAM_TW;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  real* s_tab = (real*)s_raw;                           // [knot][4]: coeffs 3..6 of rhor_spline
-  unsigned char* s_pos = s_raw + (size_t)(nr + 1) * 4 * sizeof(real);   // {x,y,z} records, byte offsets = nl16 values
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: the k loop runs on the scalar unit
+  real* s_pos = (real*)s_raw;
+  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax));                // [knot][4]: coeffs 3..6 of rhor_spline
+  real* s_part = s_tab + (size_t)(nr + 1) * 4;
+  double* s_red = (double*)(((size_t)(s_part + 64 * (EAM_TW - 1)) + 7) & ~(size_t)7);
   for(int t = tid; t < (nr + 1) * 4; t += NT) s_tab[t] = rhor_spline[(t >> 2) * 7 + 3 + (t & 3)];
   // persistent workgroups: the knots are staged once, then the workgroup walks its share of the tiles of "its" XCD
   // (workgroup b runs on XCD b % 8; XCD e owns the contiguous tile range [e*per, (e+1)*per))
@@ -211,18 +234,15 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   __syncthreads();                                      // previous tile's readers are done with s_pos / s_part
   const int ncand = tile_ncand[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int tb = tid; tb <= ncand; tb += EAM_STAGE * NT) {
-    int jj[EAM_STAGE];
+  for(int t0 = 0; t0 <= ncand; t0 += EAM_STAGE * NT) {  // branch-free: cl[ncand] holds the dummy atom's index
+    int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) { const int t = tb + u * NT; jj[u] = t < ncand ? cl[t] : nall; }
+    for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
     real4 pp[EAM_STAGE];
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) pp[u] = x[jj[u]];
 #pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) {
-      const int t = tb + u * NT;
-      if(t <= ncand) { real* q = (real*)s_pos + 3 * t; q[0] = pp[u].x; q[1] = pp[u].y; q[2] = pp[u].z; }
-    }
+    for(int u = 0; u < EAM_STAGE; u++) { s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; }
   }
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
   if(i >= nlocal) i = -1;
@@ -230,20 +250,31 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   const int kmax = tile_max[tile];
   const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
-  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
+  int sl[EAM_TU];
+#pragma unroll
+  for(int u = 0; u < EAM_TU; u++) sl[u] = 0;
+  if(k0 < k1) {
+#pragma unroll
+    for(int u = 0; u < EAM_TU; u++) sl[u] = np[u * 64];
+  }
   __syncthreads();
   real rhoi = 0;
   for(int k = k0; k < k1; k += EAM_TU) {
-    int sl[EAM_TU];
+    real xj[EAM_TU], yj[EAM_TU], zj[EAM_TU];
 #pragma unroll
-    for(int u = 0; u < EAM_TU; u++) sl[u] = np[(size_t)(k + u) * 64];
+    for(int u = 0; u < EAM_TU; u++) lds_read3<0>((unsigned)sl[u], xj[u], yj[u], zj[u]);
+    np += EAM_TU * 64;
+    if(k + EAM_TU < k1) {                               // the next trip's slots travel under this trip's arithmetic
+#pragma unroll
+      for(int u = 0; u < EAM_TU; u++) sl[u] = np[u * 64];
+    }
 #pragma unroll
     for(int u = 0; u < EAM_TU; u++) {
-      const real* q = (const real*)(s_pos + sl[u]);
-      const real dx = xi.x - q[0], dy = xi.y - q[1], dz = xi.z - q[2];
+      const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
       const real rsq = dx * dx + dy * dy + dz * dz;
       if(rsq < cutforcesq) {
-        real p = sqrt(rsq) * rdr + (real)1.0;
+        real p = (rsq * rsqrt_fast(rsq)) * rdr + (real)1.0;
         int m = (int)p;
         m = m < nr - 1 ? m : nr - 1;
         p -= m;
@@ -284,12 +315,14 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
     double* __restrict__ partials)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
-  __shared__ real s_f[3 * 64 * (EAM_TW - 1) + 3];
-  __shared__ double s_red[16];
   constexpr int NT = 64 * EAM_TW;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  real* s_tab = (real*)s_raw;                           // [knot][10]: rhor 0..2, z2r 0..6
-  unsigned char* s_pos = s_raw + (size_t)(nr + 1) * 10 * sizeof(real);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  real* s_pos = (real*)s_raw;
+  real* s_fp = (real*)(s_raw + eam_pos_bytes(cmax));                 // fp of the candidates, indexed by slot
+  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax) + eam_fp_bytes(cmax));   // [knot][10]: rhor 0..2, z2r 0..6
+  real* s_f = s_tab + (size_t)(nr + 1) * 10;
+  double* s_red = (double*)(((size_t)(s_f + 3 * 64 * (EAM_TW - 1)) + 7) & ~(size_t)7);
   for(int t = tid; t < (nr + 1) * 10; t += NT) {
     const int m = t / 10, c = t % 10;
     s_tab[t] = c < 3 ? rhor_spline[m * 7 + c] : z2r_spline[m * 7 + (c - 3)];
@@ -300,21 +333,17 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   if(tile >= ntiles) break;
   __syncthreads();
   const int ncand = tile_ncand[tile];
-  real* s_fp = (real*)(s_pos + (size_t)3 * (cmax + 2) * sizeof(real));        // fp of the candidates, indexed by slot
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int tb = tid; tb <= ncand; tb += EAM_STAGE * NT) {
-    int jj[EAM_STAGE];
+  for(int t0 = 0; t0 <= ncand; t0 += EAM_STAGE * NT) {
+    int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) { const int t = tb + u * NT; jj[u] = t < ncand ? cl[t] : nall; }
+    for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
     real4 pp[EAM_STAGE];
     real ff[EAM_STAGE];
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) { pp[u] = x[jj[u]]; ff[u] = fp[jj[u]]; }
 #pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) {
-      const int t = tb + u * NT;
-      if(t <= ncand) { real* q = (real*)s_pos + 3 * t; q[0] = pp[u].x; q[1] = pp[u].y; q[2] = pp[u].z; s_fp[t] = ff[u]; }
-    }
+    for(int u = 0; u < EAM_STAGE; u++) { s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; s_fp[tt[u]] = ff[u]; }
   }
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
   if(i >= nlocal) i = -1;
@@ -323,22 +352,36 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   const int kmax = tile_max[tile];
   const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
-  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
+  int sl[EAM_TU];
+#pragma unroll
+  for(int u = 0; u < EAM_TU; u++) sl[u] = 0;
+  if(k0 < k1) {
+#pragma unroll
+    for(int u = 0; u < EAM_TU; u++) sl[u] = np[u * 64];
+  }
   __syncthreads();
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
   for(int k = k0; k < k1; k += EAM_TU) {
-    int sl[EAM_TU];
-#pragma unroll
-    for(int u = 0; u < EAM_TU; u++) sl[u] = np[(size_t)(k + u) * 64];
+    real xj[EAM_TU], yj[EAM_TU], zj[EAM_TU], fpj[EAM_TU];
 #pragma unroll
     for(int u = 0; u < EAM_TU; u++) {
-      const real* q = (const real*)(s_pos + sl[u]);
-      const real dx = xi.x - q[0], dy = xi.y - q[1], dz = xi.z - q[2];
+      lds_read3<0>((unsigned)sl[u], xj[u], yj[u], zj[u]);
+      fpj[u] = s_fp[(unsigned)sl[u] / (3u * (unsigned)sizeof(real))];
+    }
+    np += EAM_TU * 64;
+    if(k + EAM_TU < k1) {
+#pragma unroll
+      for(int u = 0; u < EAM_TU; u++) sl[u] = np[u * 64];
+    }
+#pragma unroll
+    for(int u = 0; u < EAM_TU; u++) {
+      const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
       const real rsq = dx * dx + dy * dy + dz * dz;
       if(rsq < cutforcesq) {
-        const real fpj = s_fp[sl[u] / (3 * (int)sizeof(real))];
-        const real r = sqrt(rsq);
+        const real recip = rsqrt_fast(rsq);
+        const real r = rsq * recip;
         real p = r * rdr + (real)1.0;
         int m = (int)p;
         m = m < nr - 1 ? m : nr - 1;
@@ -348,10 +391,9 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
         const real rhoip = (c[0] * p + c[1]) * p + c[2];
         const real z2p = (c[3] * p + c[4]) * p + c[5];
         const real z2 = ((c[6] * p + c[7]) * p + c[8]) * p + c[9];
-        const real recip = (real)1.0 / r;
         const real phi = z2 * recip;
         const real phip = z2p * recip - phi * recip;
-        const real psip = fpi * rhoip + fpj * rhoip + phip;
+        const real psip = fpi * rhoip + fpj[u] * rhoip + phip;
         real fpair = -psip * recip;
         fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
         if(EV) {
@@ -456,15 +498,16 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
   // ---- tile path: LDS-staged candidates + knots (uniform tables, device-built list)
-  const size_t tl1 = (size_t)(h->nr + 1) * 4 * sizeof(real) + (size_t)3 * (h->tile_cmax + 2) * sizeof(real);
-  const size_t tl2 = (size_t)(h->nr + 1) * 10 * sizeof(real) + (size_t)4 * (h->tile_cmax + 2) * sizeof(real);
+  const size_t tl1 = eam_pos_bytes(h->tile_cmax) + (size_t)(h->nr + 1) * 4 * sizeof(real) + (size_t)64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
+  const size_t tl2 = eam_pos_bytes(h->tile_cmax) + eam_fp_bytes(h->tile_cmax) + (size_t)(h->nr + 1) * 10 * sizeof(real) +
+                     (size_t)3 * 64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
   if(h->tiles_ready && h->opt_tiles && h->eam_uniform && tl2 <= 144 * 1024) {
     const int nt = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)3 * nt + 8, false, h->stream));
     // persistent grids: as many workgroups as fit the LDS budget of every CU (multiple of 8 for the XCD split)
     const int cus = h->prop.multiProcessorCount;
-    const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl1 + 4096)))) / 8 * 8);
-    const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 8192)))) / 8 * 8);
+    const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl1 + 512)))) / 8 * 8);
+    const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 512)))) / 8 * 8);
     static bool attr_set = false;
     if(!attr_set) {            // > 64 KiB of dynamic LDS needs the opt-in
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -476,7 +519,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define DT(EVv) hipLaunchKernelGGL((k_eam_density_tile<EVv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
-                                   h->nrho, h->rdr, h->rdrho, h->fp.p, h->partials.p)
+                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p)
 #define FT(EVv) hipLaunchKernelGGL((k_eam_force_tile<EVv>), dim3(pgrid2), dim3(64 * EAM_TW), tl2, h->stream, h->x.p, h->binned.p,       \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \

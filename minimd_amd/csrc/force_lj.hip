@@ -9,6 +9,7 @@
 // This file is compiled WITH FMA contraction; parity against the (uncontracted) oracle is to ~1e-13.
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"
+#include "tile_lds.hpp"
 
 // 1/r^2: v_rcp_f64 + two Newton steps (<= 1 ulp class) instead of the 11-instruction IEEE divide;
 // exact division available through mmd_set_option("exact_div", 1) for verification.
@@ -154,18 +155,6 @@ __device__ __forceinline__ double keep_if(bool in, double v)
   return __hiloint2double(in ? (int)(b >> 32) : 0, (int)b);
 }
 __device__ __forceinline__ float keep_if(bool in, float v) { return in ? v : 0.0f; }
-
-// read one {x,y,z} record at LDS byte address `a`. The dynamic LDS segment starts at address 0 (the tile kernels
-// declare no static __shared__), so slot offsets are used as addresses as they are — no per-pair base add.
-// RD=1 keeps the three 8-byte reads separate (volatile: not fused into ds_read2_b64).
-typedef __attribute__((address_space(3))) const real lds_creal;
-typedef __attribute__((address_space(3))) const volatile real lds_cvreal;
-template <int RD>
-__device__ __forceinline__ void lds_read3(unsigned a, real& qx, real& qy, real& qz)
-{
-  if(RD == 1) { lds_cvreal* q = (lds_cvreal*)(size_t)a; qx = q[0]; qy = q[1]; qz = q[2]; }
-  else        { lds_creal* q = (lds_creal*)(size_t)a; qx = q[0]; qy = q[1]; qz = q[2]; }
-}
 
 // dynamic LDS of the tile kernel: [positions: pos_bytes][wave-slice forces: 3*64*(W-1) reals][16 doubles].
 // Nothing static precedes it, so the 16-bit values of nl16 ARE the ds_read addresses of the records.
