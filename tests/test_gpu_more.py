@@ -169,6 +169,35 @@ def test_two_ranks_match_one_rank(half, port, tmp_path):
     o.close()
 
 
+@pytest.mark.parametrize("nprocs,size,half,port", [(4, ["-nx", "8", "-ny", "9", "-nz", "10"], 0, 29641), (8, ["-s", "10"], 0, 29642),
+                                                   (8, ["-s", "10"], 1, 29643)])
+def test_four_and_eight_ranks_match_one_rank(nprocs, size, half, port, tmp_path):
+    """the decompositions the 4- and 8-GPU runs use (2x2x1 / 2x2x2: both neighbours of a dimension are the same rank,
+    corner ghosts travel through chained swaps, atoms migrate in every dimension), here with all ranks sharing this GPU
+    over the gloo host transport: rows equal the one-rank run to summation order, per-rank owned/ghost counts equal the
+    oracle's virtual ranks"""
+    args = size + ["-n", "100", "--half_neigh", str(half)]
+    base = sim_rows(args)
+    out = str(tmp_path / "mp.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nprocs), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "sim", out, "dp"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert sum(c[0] for c in res["counts"]) == res["natoms"]
+    rows = [tuple(x) for x in res["rows"]]
+    assert [r_[0] for r_ in rows] == [b[0] for b in base]
+    for a, b in zip(rows, base):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+    o = Oracle(args, nprocs=nprocs)
+    o.initial(); o.run()
+    assert [o.nlocal(r_) for r_ in range(nprocs)] == [c[0] for c in res["counts"]]
+    assert [o.nghost(r_) for r_ in range(nprocs)] == [c[1] for c in res["counts"]]
+    o.close()
+
+
 @pytest.mark.parametrize("lists", [["--half_neigh", 1, "-gn", 1], ["--half_neigh", 0]])
 def test_rccl_loopback_single_rank(lists):
     """exercise the production transport calls (ncclCommInitRank, grouped ncclSend/ncclRecv, ncclAllReduce) on ONE
