@@ -253,7 +253,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       if(h->time_force_events) MMD_TRY(ev_end(h));
       halo_pending = false;
     } else {
-      fused_force = fuse_force && !evflag && n + 1 < ntimes && h->style == 0 && mmd_lj_can_fuse_integrate(h);
+      fused_force = fuse_force && !evflag && n + 1 < ntimes && (h->style == 0 ? mmd_lj_can_fuse_integrate(h) : mmd_eam_can_fuse_integrate(h));
       if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
       h->fuse_now = fused_force;
       const int rc = force_compute_async(h, evflag, nullptr, nullptr, true);

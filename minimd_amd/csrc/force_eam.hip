@@ -272,15 +272,15 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
 #pragma unroll
     for(int u = 0; u < EAM_TU; u++) {
       const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
-      const real rsq = dx * dx + dy * dy + dz * dz;
+      const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));
       if(rsq < cutforcesq) {
-        real p = (rsq * rsqrt_fast(rsq)) * rdr + (real)1.0;
+        real p = fma_r(rsq * rsqrt_fast(rsq), rdr, (real)1.0);
         int m = (int)p;
         m = m < nr - 1 ? m : nr - 1;
         p -= m;
         p = p < (real)1.0 ? p : (real)1.0;
         const real* c = &s_tab[m * 4];
-        rhoi += ((c[0] * p + c[1]) * p + c[2]) * p + c[3];
+        rhoi += fma_r(fma_r(fma_r(c[0], p, c[1]), p, c[2]), p, c[3]);
       }
     }
   }
@@ -306,13 +306,14 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   }   // tile loop
 }
 
-template <int EV>
+// FUSE=1: wave 0 also applies finalIntegrate(n) + initialIntegrate(n+1) to the tile's atoms (see k_lj_full_tile)
+template <int EV, int FUSE>
 __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
-    double* __restrict__ partials)
+    double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_TW;
@@ -378,27 +379,27 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
 #pragma unroll
     for(int u = 0; u < EAM_TU; u++) {
       const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
-      const real rsq = dx * dx + dy * dy + dz * dz;
+      const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));      // explicit fma throughout: see tile_lds.hpp
       if(rsq < cutforcesq) {
         const real recip = rsqrt_fast(rsq);
         const real r = rsq * recip;
-        real p = r * rdr + (real)1.0;
+        real p = fma_r(r, rdr, (real)1.0);
         int m = (int)p;
         m = m < nr - 1 ? m : nr - 1;
         p -= m;
         p = p < (real)1.0 ? p : (real)1.0;
         const real* c = &s_tab[m * 10];
-        const real rhoip = (c[0] * p + c[1]) * p + c[2];
-        const real z2p = (c[3] * p + c[4]) * p + c[5];
-        const real z2 = ((c[6] * p + c[7]) * p + c[8]) * p + c[9];
+        const real rhoip = fma_r(fma_r(c[0], p, c[1]), p, c[2]);
+        const real z2p = fma_r(fma_r(c[3], p, c[4]), p, c[5]);
+        const real z2 = fma_r(fma_r(fma_r(c[6], p, c[7]), p, c[8]), p, c[9]);
         const real phi = z2 * recip;
-        const real phip = z2p * recip - phi * recip;
-        const real psip = fpi * rhoip + fpj[u] * rhoip + phip;
+        const real phip = fma_r(z2p, recip, -(phi * recip));
+        const real psip = fma_r(fpi, rhoip, fma_r(fpj[u], rhoip, phip));
         real fpair = -psip * recip;
-        fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
+        fx = fma_r(dx, fpair, fx); fy = fma_r(dy, fpair, fy); fz = fma_r(dz, fpair, fz);
         if(EV) {
           fpair *= (real)0.5;
-          v_acc += (double)(dx * dx * fpair + dy * dy * fpair + dz * dz * fpair);
+          v_acc += (double)(rsq * fpair);
           e_acc += (double)((real)0.5 * phi);
         }
       }
@@ -409,7 +410,14 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   if(wv == 0 && i >= 0) {
 #pragma unroll
     for(int q = 0; q < EAM_TW - 1; q++) { const real* d = s_f + 3 * 64 * q; fx += d[lane]; fy += d[64 + lane]; fz += d[128 + lane]; }
-    f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz;
+    if(!FUSE) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
+    if(FUSE) {          // same operations, same order as k_final_initial_integrate (integrate.hip)
+      real vx = v[3 * (size_t)i + 0], vy = v[3 * (size_t)i + 1], vz = v[3 * (size_t)i + 2];
+      vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
+      vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
+      v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
+      xnew[i] = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
+    }
   }
   if(EV) {
     if(i < 0) { e_acc = 0; v_acc = 0; }
@@ -490,6 +498,23 @@ extern "C" int mmd_force_eam_setup(mmd_handle* h, int ntypes, int nr, int nrho, 
   return 0;
 }
 
+static size_t eam_tile_lds_density(const mmd_handle* h)
+{
+  return eam_pos_bytes(h->tile_cmax) + (size_t)(h->nr + 1) * 4 * sizeof(real) + (size_t)64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
+}
+static size_t eam_tile_lds_force(const mmd_handle* h)
+{
+  return eam_pos_bytes(h->tile_cmax) + eam_fp_bytes(h->tile_cmax) + (size_t)(h->nr + 1) * 10 * sizeof(real) +
+         (size_t)3 * 64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
+}
+static bool eam_tiles_available(const mmd_handle* h)
+{
+  return h->style == 1 && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->eam_uniform && eam_tile_lds_force(h) <= 144 * 1024 &&
+         h->neigh_nlocal == h->nlocal;
+}
+// the force sweep of the tile path can carry finalIntegrate(n) + initialIntegrate(n+1) (no energy/virial on that step)
+int mmd_eam_can_fuse_integrate(mmd_handle* h) { return eam_tiles_available(h) ? 1 : 0; }
+
 int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 {
   if(h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_force_compute: neighbor list is stale (build or upload one first)"); return -1; }
@@ -498,10 +523,8 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
   // ---- tile path: LDS-staged candidates + knots (uniform tables, device-built list)
-  const size_t tl1 = eam_pos_bytes(h->tile_cmax) + (size_t)(h->nr + 1) * 4 * sizeof(real) + (size_t)64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
-  const size_t tl2 = eam_pos_bytes(h->tile_cmax) + eam_fp_bytes(h->tile_cmax) + (size_t)(h->nr + 1) * 10 * sizeof(real) +
-                     (size_t)3 * 64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
-  if(h->tiles_ready && h->opt_tiles && h->eam_uniform && tl2 <= 144 * 1024) {
+  const size_t tl1 = eam_tile_lds_density(h), tl2 = eam_tile_lds_force(h);
+  if(eam_tiles_available(h)) {
     const int nt = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)3 * nt + 8, false, h->stream));
     // persistent grids: as many workgroups as fit the LDS budget of every CU (multiple of 8 for the XCD split)
@@ -510,8 +533,9 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 512)))) / 8 * 8);
     static bool attr_set = false;
     if(!attr_set) {            // > 64 KiB of dynamic LDS needs the opt-in
-      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       attr_set = true;
@@ -520,14 +544,14 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
                                    h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p)
-#define FT(EVv) hipLaunchKernelGGL((k_eam_force_tile<EVv>), dim3(pgrid2), dim3(64 * EAM_TW), tl2, h->stream, h->x.p, h->binned.p,       \
+#define FT(EVv, Fv) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv>), dim3(pgrid2), dim3(64 * EAM_TW), tl2, h->stream, h->x.p, h->binned.p,       \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
-                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p)
+                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce)
     if(evflag) DT(1); else DT(0);
     HIP_TRY(hipGetLastError());
     MMD_TRY(eam_fp_halo(h));
-    if(evflag) FT(1); else FT(0);
+    if(evflag) FT(1, 0); else if(h->fuse_now) FT(0, 1); else FT(0, 0);
 #undef DT
 #undef FT
     HIP_TRY(hipGetLastError());

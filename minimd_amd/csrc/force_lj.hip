@@ -52,9 +52,6 @@ __device__ __forceinline__ float recip(float a)
   return __builtin_fmaf(e, r, r);
 }
 
-__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
 struct LJTables {       // general (non-uniform) case: per type-pair tables staged in LDS by the kernel
   const real* cutforcesq;
   const real* sigma6;
@@ -159,16 +156,6 @@ __device__ __forceinline__ float keep_if(bool in, float v) { return in ? v : 0.0
 // dynamic LDS of the tile kernel: [positions: pos_bytes][wave-slice forces: 3*64*(W-1) reals][16 doubles].
 // Nothing static precedes it, so the 16-bit values of nl16 ARE the ds_read addresses of the records.
 __host__ __device__ constexpr int lj_tile_sf_bytes(int waves) { return 3 * 64 * (waves - 1) * (int)sizeof(real); }
-
-// v += dtf*f ; x += dt*v with separately rounded multiply and add, like integrate.hip (built without contraction).
-// This file is compiled with -ffp-contract=fast, which lets the backend fuse across a `#pragma clang fp contract(off)`
-// (seen for float); the empty asm makes the product opaque, so no fma can be formed.
-__device__ __forceinline__ real mul_add_unfused(real a, real b, real c)
-{
-  real p = a * b;
-  asm volatile("" : "+v"(p));
-  return p + c;
-}
 
 // FUSE=1 appends finalIntegrate of this step and initialIntegrate of the next one (ref/integrate.cpp:46-68) for the
 // tile's atoms: v and the NEW positions go to v / xnew (a second position buffer: other tiles still read the old x),

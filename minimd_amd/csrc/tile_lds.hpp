@@ -15,3 +15,20 @@ __device__ __forceinline__ void lds_read3(unsigned a, real& qx, real& qy, real& 
   if(RD == 1) { lds_cvreal* q = (lds_cvreal*)(size_t)a; qx = q[0]; qy = q[1]; qz = q[2]; }
   else        { lds_creal* q = (lds_creal*)(size_t)a; qx = q[0]; qy = q[1]; qz = q[2]; }
 }
+
+// explicit fused multiply-add in the build precision: the tile kernels are compiled with -ffp-contract=fast, and a sum of
+// products written with * and + would leave the compiler free to choose WHICH product it fuses, differently per template
+// instantiation; with fma_r every instantiation rounds alike
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// v += dtf*f ; x += dt*v with separately rounded multiply and add, like integrate.hip (built without contraction).
+// The force files are compiled with -ffp-contract=fast, which lets the backend fuse across a `#pragma clang fp contract(off)`
+// (seen for float); the empty asm makes the product opaque, so no fma can be formed.
+__device__ __forceinline__ real mul_add_unfused(real a, real b, real c)
+{
+  real p = a * b;
+  asm volatile("" : "+v"(p));
+  return p + c;
+}
+

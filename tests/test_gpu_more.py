@@ -453,14 +453,15 @@ def test_check_exchange_flag_is_silent_on_a_healthy_run_and_changes_nothing():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("deck", ["in.lj.miniMD", "in.eam.miniMD"])
 @pytest.mark.parametrize("prec", ["dp", "sp"])
-def test_integrator_inside_the_force_kernel_is_bit_identical(prec):
-    """fuse=2 (default: finalIntegrate(n)+initialIntegrate(n+1) at the end of the LJ tile kernel, positions double
+def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
+    """fuse=2 (default: finalIntegrate(n)+initialIntegrate(n+1) at the end of the LJ / EAM tile force kernel, positions double
     buffered) against fuse=1 (separate k_final_initial_integrate) and fuse=0 (reference call order): same bits after
     130 steps with 6 re-neighborings, thermo rows included"""
     res = []
     for fuse in (2, 1, 0):
-        s = mm().Sim(["-s", "8", "-n", "130", "--half_neigh", "0"], precision=prec)
+        s = mm().Sim(["-i", deck, "-s", "8", "-n", "130", "--half_neigh", "0"], precision=prec)
         s.handle.set_option("fuse", fuse)
         s.initial(); s.run()
         d = s.handle.download()
