@@ -328,8 +328,15 @@ __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, cons
 //   * rows leave the CU as coalesced 128-byte lines, already padded with the dummy slot (= ncand).
 // The 32-bit reference-style rows are NOT produced here; mmd_ensure_rows() derives them on demand.
 // ---------------------------------------------------------------------------------------------------
+// MODE as in k_build: 0 full list, 1 half (owned j > i, every ghost), 2 half with ghost newton (every pair once globally).
+// For the half modes the candidate index itself carries the rule: a hit also needs cj > i, which is "j > i" for owned
+// candidates and always true for ghosts (their indices follow the owned atoms); ghost-newton images that must NOT be
+// kept are stored as negative indices (never > i), unshifted ghosts (another rank's atoms) are flagged per chunk and
+// decided by the (z,y,x) order of ref/neighbor.cpp:155-157.
+template <int MODE>
 __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__ x, const int* __restrict__ binned,
-                                                       const int* __restrict__ bin_start, BinGeom g, int nblocks, int nlocal,
+                                                       const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
+                                                       BinGeom g, int nblocks, int nlocal,
                                                        int nall, real cutneighsq, int maxneighs, int cstride, const int* __restrict__ tile_of_block,
                                                        int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
                                                        int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
@@ -424,6 +431,20 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
       }
     }
   }
+  // ---- half-list rules folded into the candidate index (see the kernel comment)
+  unsigned lex = 0;                                           // chunks in which MY candidate is an unshifted ghost
+  if(MODE == 2) {
+#pragma unroll
+    for(int c = 0; c < NB_CHUNKS; c++) {
+      if(cj[c] >= nlocal) {
+        const int code = ghost_image[cj[c] - nlocal];         // (sx+2) + 5*(sy+2) + 25*(sz+2), 62 = unshifted
+        const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
+        if(sx == 0 && sy == 0 && sz == 0) lex |= 1u << c;
+        else if(!(sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0))))) cj[c] = -2 - cj[c];   // mirrored pair keeps it
+      }
+    }
+  }
+  const bool any_lex = MODE == 2 && __builtin_amdgcn_ballot_w64(lex != 0) != 0ull;
   const int nchunks = (total + 63) >> 6;
   // ---- conservative float bounding box of every chunk of 64 candidates; lane c keeps the box of chunk c.
   // An owned atom farther than the cutoff (+0.1% margin for the float rounding) from a box skips that chunk
@@ -479,21 +500,29 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
             if((live >> c) & 1ull) {
               const real dx = xix - cx[c], dy = xiy - cy[c], dz = xiz - cz[c];
               const real rsq = dx * dx + dy * dy + dz * dz;
-              // the atom itself (rsq = 0) is kept here and dropped at write-out: no index compare per pass, and
-              // the v_cmp result IS the hit mask
-              const unsigned long long m = __builtin_amdgcn_fcmp(rsq, cutneighsq, 5 /* ordered <= */);
+              // full lists: the atom itself (rsq = 0) is kept here and dropped at write-out: no index compare per
+              // pass, and the v_cmp result IS the hit mask
+              bool keep = rsq <= cutneighsq;
+              if(MODE != 0) {
+                bool rule = cj[c] > i;
+                if(MODE == 2 && any_lex && ((lex >> c) & 1u))
+                  rule = !(cz[c] < xiz || (cz[c] == xiz && cy[c] < xiy) || (cz[c] == xiz && cy[c] == xiy && cx[c] < xix));
+                keep = keep && rule;
+              }
+              const unsigned long long m = MODE == 0 ? __builtin_amdgcn_fcmp(rsq, cutneighsq, 5 /* ordered <= */)
+                                                     : __builtin_amdgcn_ballot_w64(keep);
               if(m) {
                 // ordered append: rank of this lane among the hits, on top of the n found so far; a row that
                 // overflows keeps overwriting its last slot (the host grows maxneighs and rebuilds, ref :184-208)
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, n));
-                if(rsq <= cutneighsq) rows[min(pos, maxneighs - 1) * 64 + al] = (unsigned short)(c * 64 + lane);
+                if(keep) rows[min(pos, maxneighs - 1) * 64 + al] = (unsigned short)(c * 64 + lane);
                 n += __popcll(m);
               }
             }
           }
         }
       }
-      if(lane == 0) { cnt[al] = n; numneigh[i] = max(n - 1, 0); }      // n counts the atom itself
+      if(lane == 0) { cnt[al] = n; numneigh[i] = MODE == 0 ? max(n - 1, 0) : n; }      // full lists: n counts the atom itself
     }
     __syncthreads();
     if(ablate & 8) continue;
@@ -527,11 +556,11 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     }
     __syncthreads();
     // ---- coalesced write-out of the padded, remapped rows; the atom's own slot is skipped on the way
-    const int myn = max(cnt[lane] - 1, 0);
+    const int myn = MODE == 0 ? max(cnt[lane] - 1, 0) : cnt[lane];
     const int maxn = wave_max_i(myn);
     int kmax = (maxn + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
     if(kmax > maxneighs) kmax = maxneighs;
-    const int selfslot = self0 + tl * 64 + lane;
+    const int selfslot = MODE == 0 ? self0 + tl * 64 + lane : -7;      // (half rows never hold the atom itself)
     unsigned short* out = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
     int ko = 0;                                   // output row of this lane (lags k by one after its own slot)
     for(int k = 0; k <= kmax; k++) {              // stored as the LDS byte offset of the {x,y,z} record (slot * 3 reals)
@@ -641,8 +670,8 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   h->tiles_ready = false;
   h->rows_ready = false;
   h->neigh_nlocal = 0;
-  // ---- tile form (full lists): block-local 16-bit rows + per-tile candidate union, see k_build_tiles
-  bool want_tiles = h->opt_tiles && !h->halfneigh && nlocal > 0;
+  // ---- tile form: block-local 16-bit rows + per-tile candidate union, see k_build_tiles
+  bool want_tiles = h->opt_tiles && nlocal > 0;
   if(want_tiles) {
     MMD_TRY(h->tile_of_block.ensure((size_t)nblocks + 2, false, h->stream));
     hipLaunchKernelGGL(k_tile_count, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->binned.p, h->bin_start.p, nblocks, nlocal, h->tile_of_block.p);
@@ -664,9 +693,14 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
       HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
       const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
-      hipLaunchKernelGGL(k_build_tiles, dim3(xcd_grid(nblocks)), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p, g, nblocks, nlocal, nlocal + h->nghost, h->cutneighsq,
-                         h->maxneighs, h->tile_cstride, h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,
-                         h->tile_max.p, h->tile_ghost.p, h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate);
+      const int tmode = !h->halfneigh ? 0 : (h->ghost_newton ? 2 : 1);
+#define LAUNCH_TILES(M)                                                                                                                 \
+  hipLaunchKernelGGL(k_build_tiles<M>, dim3(xcd_grid(nblocks)), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p,          \
+                     h->ghost_image.p, g, nblocks, nlocal, nlocal + h->nghost, h->cutneighsq, h->maxneighs, h->tile_cstride,             \
+                     h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p, h->tile_max.p, h->tile_ghost.p,      \
+                     h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate)
+      if(tmode == 0) LAUNCH_TILES(0); else if(tmode == 1) LAUNCH_TILES(1); else LAUNCH_TILES(2);
+#undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
