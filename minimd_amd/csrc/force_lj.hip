@@ -344,6 +344,126 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_half(const real4* __restrict__
   }
 }
 
+// ---- half neighbor list, tile form -------------------------------------------------------------------------------------
+// Newton's third law with the scatter kept ON CHIP: next to the {x,y,z} records of the tile's candidate union the LDS holds
+// one force accumulator per candidate; every in-range pair adds to its own atom in registers and to the partner's
+// accumulator with a native LDS floating-point atomic (ds_add_f64 / ds_add_f32), and only at the end of the tile do the
+// ~450 accumulators (and the 64 owned atoms) go to global memory with one atomic each: ~1.5 k global atomics per tile
+// instead of the ~6.5 k of k_lj_half. Same physics/conventions as compute_halfneigh_threaded<EVFLAG,GHOST_NEWTON>
+// (ref/force_lj.cpp:271-357): without ghost newton the partner gets no force when it is a ghost and the pair counts half
+// in energy and virial. f was zeroed over owned+ghost atoms beforehand. Dynamic LDS:
+//   [positions: pos_bytes][accumulators: pos_bytes][wave-slice forces: 3*64 reals][16 doubles][EV && !GN: ghost flag per slot]
+template <int EV, int GN>
+__global__ __launch_bounds__(128) void k_lj_half_tile(
+    const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
+    const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
+    const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, int pos_bytes, LJParams P, real* __restrict__ f,
+    double* __restrict__ partials)
+{
+  constexpr int UNR = 8, NT = 128, STG = 4;
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  real* sp = (real*)s_raw;
+  real* s_acc = (real*)(s_raw + pos_bytes);
+  real* s_f = (real*)(s_raw + 2 * (size_t)pos_bytes);
+  double* s_red = (double*)(s_raw + 2 * (size_t)pos_bytes + lj_tile_sf_bytes(2));
+  unsigned char* s_ghost = (unsigned char*)(s_red + 16);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_work_item(ntiles);
+  if(tile < 0) return;
+  const int ncand = tile_ncand[tile];
+  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  for(int t0 = 0; t0 <= ncand; t0 += STG * NT) {              // positions in, accumulators cleared
+    int tt[STG], jj[STG];
+#pragma unroll
+    for(int u = 0; u < STG; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
+    real4 pp[STG];
+#pragma unroll
+    for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
+#pragma unroll
+    for(int u = 0; u < STG; u++) {
+      sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z;
+      s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0;
+      if(EV && !GN) s_ghost[tt[u]] = jj[u] >= nlocal ? 1 : 0;
+    }
+  }
+  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
+  const int kmax = tile_max[tile];
+  const int per = ((kmax / UNR + 1) / 2) * UNR;
+  const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
+  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
+  int s[UNR];
+#pragma unroll
+  for(int u = 0; u < UNR; u++) s[u] = 0;
+  if(k0 < k1) {
+#pragma unroll
+    for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
+  }
+  if(i >= nlocal) i = -1;
+  const real4 xi = x[i >= 0 ? i : 0];
+  __syncthreads();
+
+  real fx = 0, fy = 0, fz = 0;
+  double e_acc = 0, v_acc = 0;
+  const real c_out = (real)48.0 * P.epsilon * P.sigma6;      // folded constant, applied when the sums leave the chip
+  for(int k = k0; k < k1; k += UNR) {
+    real xj[UNR], yj[UNR], zj[UNR];
+    int sc[UNR];
+#pragma unroll
+    for(int u = 0; u < UNR; u++) { sc[u] = s[u]; lds_read3<0>((unsigned)s[u], xj[u], yj[u], zj[u]); }
+    np += UNR * 64;
+    if(k + UNR < k1) {
+#pragma unroll
+      for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
+    }
+#pragma unroll
+    for(int u = 0; u < UNR; u++) {
+      const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
+      const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));
+      if(rsq < P.cutforcesq) {                             // (also keeps the padded lanes off the dummy slot's accumulator)
+        const real sr2 = recip_fast(rsq);
+        const real A = (sr2 * sr2) * sr2;
+        const real fs = (A * sr2) * fma_r(A, P.sigma6, (real)-0.5);          // force / c_out
+        const real px = dx * fs, py = dy * fs, pz = dz * fs;
+        fx += px; fy += py; fz += pz;
+        real* a = (real*)((unsigned char*)s_acc + sc[u]);   // the partner's accumulator collects +p, negated at the flush
+        unsafeAtomicAdd(a + 0, px); unsafeAtomicAdd(a + 1, py); unsafeAtomicAdd(a + 2, pz);
+        if(EV) {
+          real scale = (real)1.0;
+          if(!GN) scale = s_ghost[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))] ? (real)0.5 : (real)1.0;
+          const real sr6 = A * P.sigma6;
+          e_acc += (double)(scale * ((real)4.0 * sr6 * (sr6 - (real)1.0)) * P.epsilon);
+          v_acc += (double)(scale * rsq * fs);
+        }
+      }
+    }
+  }
+  v_acc *= (double)c_out;
+  if(wv > 0) { s_f[lane] = fx; s_f[64 + lane] = fy; s_f[128 + lane] = fz; }
+  __syncthreads();                                          // every pair of the tile has been accumulated
+  if(wv == 0 && i >= 0) {
+    fx += s_f[lane]; fy += s_f[64 + lane]; fz += s_f[128 + lane];
+    real* fi = f + 3 * (size_t)i;
+    unsafeAtomicAdd(fi + 0, fx * c_out); unsafeAtomicAdd(fi + 1, fy * c_out); unsafeAtomicAdd(fi + 2, fz * c_out);
+  }
+  for(int t = tid; t < ncand; t += NT) {                    // partners: ONE global atomic per component and candidate
+    const int j = cl[t];
+    if(GN || j < nlocal) {
+      const real ax = s_acc[3 * t], ay = s_acc[3 * t + 1], az = s_acc[3 * t + 2];
+      if(ax != 0 || ay != 0 || az != 0) {
+        real* fj = f + 3 * (size_t)j;
+        unsafeAtomicAdd(fj + 0, -(ax * c_out)); unsafeAtomicAdd(fj + 1, -(ay * c_out)); unsafeAtomicAdd(fj + 2, -(az * c_out));
+      }
+    }
+  }
+  if(EV) {
+    if(i < 0) { e_acc = 0; v_acc = 0; }
+    const double es = block_sum(e_acc, s_red);
+    const double vs = block_sum(v_acc, s_red);
+    if(tid == 0) { partials[2 * (size_t)tile] = es; partials[2 * (size_t)tile + 1] = vs; }
+  }
+}
+
 // fixed-order sum of the per-workgroup partials -> out[0..nval)
 __global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict__ partials, int nblocks, int nval, double* __restrict__ out,
                                                        double scale0, double scale1)
@@ -479,6 +599,20 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define F(EVv, Uv, Xv) if(ev == EVv && uni == Uv && ex == Xv) launch_full<EVv, Uv, (Xv != 0)>(h, nblocks, T)
     F(0, 0, 0); F(0, 0, 1); F(0, 1, 0); F(0, 1, 1); F(1, 0, 0); F(1, 0, 1); F(1, 1, 0); F(1, 1, 1);
 #undef F
+  } else if(h->tiles_ready && h->opt_tiles && uni && !ex && 2 * lj_tile_pos_bytes(h) + 4096 <= 64 * 1024) {
+    // half lists in tile form: on-chip scatter (k_lj_half_tile)
+    MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));     // ref/force_lj.cpp:286-291
+    nsum = h->ntiles;
+    MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
+    const size_t pos_bytes = lj_tile_pos_bytes(h);
+    const size_t lds = 2 * pos_bytes + lj_tile_sf_bytes(2) + 16 * sizeof(double) + (size_t)(h->tile_cmax + 2) + 16;
+    const int gn = h->ghost_newton ? 1 : 0;
+#define HT(EVv, Gv) if(ev == EVv && gn == Gv)                                                                                        \
+      hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(h->ntiles)), dim3(128), lds, h->stream, h->x.p, h->binned.p,          \
+                         h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->ntiles,     \
+                         h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p, h->partials.p)
+    HT(0, 0); HT(0, 1); HT(1, 0); HT(1, 1);
+#undef HT
   } else {
     MMD_TRY(mmd_ensure_rows(h));
     MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));     // ref/force_lj.cpp:286-291
