@@ -94,16 +94,28 @@ __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
 // Neighbor::binatoms (ref/neighbor.cpp:215-268): histogram, scan, fill, in-bin sort
 // ---------------------------------------------------------------------------------------------------
 // the histogram atomic also hands every atom its arrival rank inside the bin, so the fill pass needs neither a
-// second round of atomics nor a zeroed cursor array (the arrival order is made deterministic by k_bin_sort)
-__global__ void k_bin_count(const real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ atom_rank,
-                            int* __restrict__ bin_count)
+// second round of atomics nor a zeroed cursor array (the arrival order is made deterministic by k_bin_sort).
+// Atoms arrive (nearly) sorted by bin, so the lanes of a wavefront form runs of equal bins: the first lane of a run
+// adds the run length once and the others derive their rank from it — ~7x fewer atomics on a sorted system.
+__global__ __launch_bounds__(256) void k_bin_count(const real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ atom_rank,
+                                                   int* __restrict__ bin_count)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n) return;
-  const real4 p = x[i];
-  const int b = bin_of(g, p.x, p.y, p.z);
-  atom_bin[i] = b;
-  atom_rank[i] = atomicAdd(&bin_count[b], 1);
+  const int lane = threadIdx.x & 63;
+  const bool valid = i < n;
+  int b = -1 - lane;                                          // lanes past the end never join a run
+  if(valid) { const real4 p = x[i]; b = bin_of(g, p.x, p.y, p.z); }
+  const int prev = __shfl_up(b, 1, 64);
+  const bool head = lane == 0 || b != prev;
+  const unsigned long long heads = __builtin_amdgcn_ballot_w64(head);
+  const unsigned long long upto = heads & (~0ull >> (63 - lane));              // run heads at or below my lane
+  const int start = 63 - __clzll(upto);                                         // first lane of my run
+  const unsigned long long after = lane == 63 ? 0ull : heads >> (lane + 1);     // run heads above my lane
+  const int len = (after ? lane + 1 + __ffsll((long long)after) - 1 : 64) - start;   // (meaningful on the head lane)
+  int base = 0;
+  if(head && valid) base = atomicAdd(&bin_count[b], len);
+  base = __shfl(base, start, 64);
+  if(valid) { atom_bin[i] = b; atom_rank[i] = base + (lane - start); }
 }
 
 __global__ void k_bin_fill(const int* __restrict__ atom_bin, const int* __restrict__ atom_rank, int n, const int* __restrict__ bin_start,
