@@ -161,6 +161,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_lj_full_tile (ForceLJ::compute_fullneigh + fused Integrate)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "kernel_ms": k_ms, "launches": tm["force_launches"], "bytes_per_atom": bpa, "atoms_per_launch": nlocal,
+                     # informational: the same launches with the fused integrator's own compulsory bytes counted too
+                     # (+ v read/write 48 B, + new x 32 B, - the f store it skips 24 B)
+                     "achieved_incl_fused_integrator": ((bpa + 56.0) * nlocal / (k_ms * 1e-3) / 1e9) if k_ms > 0 else None,
                      "kbar": kbar, "ghost_ratio": nghost / max(nlocal, 1)},
         "phases_s": {k: tm[k] for k in ("total", "comm", "force", "neigh", "extra")},
     }
