@@ -358,7 +358,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, int pos_bytes, LJParams P, real* __restrict__ f,
-    double* __restrict__ partials)
+    double* __restrict__ partials, int ablate)
 {
   constexpr int UNR = 8, NT = 128, STG = 4;
   extern __shared__ __align__(16) unsigned char s_raw[];
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
         const real px = dx * fs, py = dy * fs, pz = dz * fs;
         fx += px; fy += py; fz += pz;
         real* a = (real*)((unsigned char*)s_acc + sc[u]);   // the partner's accumulator collects +p, negated at the flush
-        unsafeAtomicAdd(a + 0, px); unsafeAtomicAdd(a + 1, py); unsafeAtomicAdd(a + 2, pz);
+        if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, px); unsafeAtomicAdd(a + 1, py); unsafeAtomicAdd(a + 2, pz); }   // (ablate: profiling only)
         if(EV) {
           real scale = (real)1.0;
           if(!GN) scale = s_ghost[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))] ? (real)0.5 : (real)1.0;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     real* fi = f + 3 * (size_t)i;
     unsafeAtomicAdd(fi + 0, fx * c_out); unsafeAtomicAdd(fi + 1, fy * c_out); unsafeAtomicAdd(fi + 2, fz * c_out);
   }
-  for(int t = tid; t < ncand; t += NT) {                    // partners: ONE global atomic per component and candidate
+  for(int t = tid; t < ncand && !(ablate & 2); t += NT) {   // partners: ONE global atomic per component and candidate
     const int j = cl[t];
     if(GN || j < nlocal) {
       const real ax = s_acc[3 * t], ay = s_acc[3 * t + 1], az = s_acc[3 * t + 2];
@@ -610,7 +610,7 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define HT(EVv, Gv) if(ev == EVv && gn == Gv)                                                                                        \
       hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(h->ntiles)), dim3(128), lds, h->stream, h->x.p, h->binned.p,          \
                          h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->ntiles,     \
-                         h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p, h->partials.p)
+                         h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p, h->partials.p, h->opt_ablate)
     HT(0, 0); HT(0, 1); HT(1, 0); HT(1, 1);
 #undef HT
   } else {
