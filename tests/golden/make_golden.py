@@ -106,6 +106,8 @@ def ref_runs(big):
             ("lj_s80_half_n100", "dp", ["-i", "in.lj.miniMD", "-s", "80", "-n", "100", "--half_neigh", "1", "-t", "8"]),
             ("eam_s64_full_n100", "dp", ["-i", "in.eam.miniMD", "-s", "64", "-n", "100", "--half_neigh", "0", "-t", "8"]),
         ]
+        # (ref_runs.json also holds "lj_s144_full_n100", 11.9 M atoms: its rows were taken from a separate 9-minute run of
+        #  oracle/_ref/miniMD_ref_dp -i in.lj.miniMD -s 144 -n 100 --half_neigh 0 -t 8 and are kept when this script rewrites the file)
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         for f in ("in.lj.miniMD", "in.eam.miniMD", "Cu_u6.eam"):

@@ -259,6 +259,14 @@ def test_baseline_s80_full_and_half():
     rows_close(rows_h, ent["rows"], 2e-6)
 
 
+def test_beyond_baseline_s144_rows_equal_the_reference():
+    """11.9 M atoms (5.8x the BASELINE -s 80): index arithmetic, tile counts and list sizes far past the tested sizes"""
+    ent = REFRUNS["lj_s144_full_n100"]
+    rows = sim_rows(ent["args"][2:-2])
+    rows_close(rows, ent["rows"], 2e-6)
+    assert [fmt7(v) for v in rows[-1][1:4]] == [fmt7(v) for v in ent["rows"][-1][1:4]]
+
+
 def test_baseline_eam_s64():
     ent = REFRUNS["eam_s64_full_n100"]
     s = mm().Sim(["-i", "in.eam.miniMD", "-s", 64, "-n", 100, "--half_neigh", 0])
