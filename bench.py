@@ -149,6 +149,24 @@ def main():
         # HBM bytes per launch of the same kernel on the same workload from the committed PMC passes
         # (rocprofv3 cannot be run from inside the timed process); see profiles/README.md
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+    copy_gbs = None
+    if rank == 0:
+        # measured device-copy bandwidth of this GPU (read + write bytes of a 1 GiB device-to-device copy), the practical
+        # ceiling next to the 8 TB/s datasheet peak
+        try:
+            a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+            b = torch.empty_like(a)
+            b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del a, b
+        except Exception:
+            copy_gbs = None
     out = {
         "metric": "Matom-steps/sec (LJ, full-neigh)", "value": natoms * args.steps / dt / 1e6, "unit": "Matom-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -160,6 +178,7 @@ def main():
         # new x: +80 B/atom, and skips the f store: -24 B); `achieved` still counts only SURVEY §8d's force-kernel bytes
         "roofline": {"bound": "hbm", "kernel": "k_lj_full_tile (ForceLJ::compute_fullneigh + fused Integrate)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "measured_copy_GBs": copy_gbs,
                      "kernel_ms": k_ms, "launches": tm["force_launches"], "bytes_per_atom": bpa, "atoms_per_launch": nlocal,
                      # informational: the same launches with the fused integrator's own compulsory bytes counted too
                      # (+ v read/write 48 B, + new x 32 B, - the f store it skips 24 B)

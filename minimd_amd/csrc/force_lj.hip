@@ -7,6 +7,7 @@
 // wave-uniform and branch-free (the cutoff test is a select). Energy/virial are reduced with wavefront
 // shuffles, one partial per workgroup, summed in fixed order by k_sum_partials => deterministic.
 // This file is compiled WITH FMA contraction; parity against the (uncontracted) oracle is to ~1e-13.
+#include <type_traits>
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"
 #include "tile_lds.hpp"
@@ -199,12 +200,19 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   // ---- my atom and my slice of its neighbor row (wave w takes k in [k0,k1))
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;     // a tile never straddles blocks
   const int kmax = (ablate & 2) ? 0 : tile_max[tile];
-  const int per = ((kmax / UNR + LJ_TILE_WAVES - 1) / LJ_TILE_WAVES) * UNR;
+  // rows are padded to a multiple of 4 (NB_ROW_PAD): the wave slices are multiples of 4, run as trips of UNR pairs plus,
+  // where 4 rows remain, one half trip
+  constexpr int QR = 4;
+  const int per = ((kmax / QR + LJ_TILE_WAVES - 1) / LJ_TILE_WAVES) * QR;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
   int s[UNR];
 #pragma unroll
-  for(int u = 0; u < UNR; u++) s[u] = k0 < k1 ? np[u * 64] : 0;
+  for(int u = 0; u < UNR; u++) s[u] = 0;
+  if(k0 < k1) {                                   // (a slice of 4 rows reads 4 rows of padding / of the next slice: in bounds, unused)
+#pragma unroll
+    for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
+  }
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   real vx0 = 0, vy0 = 0, vz0 = 0;          // FUSE: the velocity travels under the pair loop (wave 0 integrates)
@@ -216,17 +224,20 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   // force = 48 eps sr6 (sr6 - 1/2) sr2 with sr6 = s6 A, A = sr2^3  ==  [48 eps s6] * (A sr2) * (s6 A - 1/2):
   // the bracket is uniform and applied once after the loop
   const real c_out = (real)48.0 * P.epsilon * P.sigma6;
-  for(int k = k0; k < k1; k += UNR) {
-    real xj[UNR], yj[UNR], zj[UNR];
+  // one trip: U pairs of every lane. Positions come from LDS (s[u] IS the record's address); once the addresses are
+  // consumed the same registers receive the slots of the next trip, which travel under this trip's arithmetic
+  auto trip = [&](auto nu, int k) {
+    constexpr int U = decltype(nu)::value;
+    real xj[U], yj[U], zj[U];
 #pragma unroll
-    for(int u = 0; u < UNR; u++) lds_read3<RD>((unsigned)s[u], xj[u], yj[u], zj[u]);   // s[u] IS the record's LDS address
-    np += UNR * 64;
-    if(k + UNR < k1) {                    // the next trip's slots travel under this trip's arithmetic
+    for(int u = 0; u < U; u++) lds_read3<RD>((unsigned)s[u], xj[u], yj[u], zj[u]);
+    np += U * 64;
+    if(k + U < k1) {
 #pragma unroll
       for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
     }
 #pragma unroll
-    for(int u = 0; u < UNR; u++) {
+    for(int u = 0; u < U; u++) {
       // every multiply-add is written as an explicit fma: with -ffp-contract=fast the compiler would otherwise be
       // free to pick WHICH product of a sum it fuses, and the instantiations of this template must round alike
       const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
@@ -243,7 +254,10 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
         v_acc = __builtin_fma((double)rsq, (double)fs, v_acc);
       }
     }
-  }
+  };
+  int k = k0;
+  for(; k + UNR <= k1; k += UNR) trip(std::integral_constant<int, UNR>{}, k);
+  if(UNR > QR && k < k1) trip(std::integral_constant<int, QR>{}, k);
   v_acc *= (double)c_out;
   // combine the wave slices, THEN apply the folded constant: (a + b) * c leaves the compiler no multiply-add to
   // contract, so every instantiation of this kernel rounds the force identically
@@ -389,7 +403,8 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   }
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
   const int kmax = tile_max[tile];
-  const int per = ((kmax / UNR + 1) / 2) * UNR;
+  constexpr int QR = 4;                                     // rows are padded to 4: trips of UNR pairs + one half trip
+  const int per = ((kmax / QR + 1) / 2) * QR;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
   int s[UNR];
@@ -406,18 +421,19 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
   const real c_out = (real)48.0 * P.epsilon * P.sigma6;      // folded constant, applied when the sums leave the chip
-  for(int k = k0; k < k1; k += UNR) {
-    real xj[UNR], yj[UNR], zj[UNR];
-    int sc[UNR];
+  auto trip = [&](auto nu, int k) {
+    constexpr int U = decltype(nu)::value;
+    real xj[U], yj[U], zj[U];
+    int sc[U];
 #pragma unroll
-    for(int u = 0; u < UNR; u++) { sc[u] = s[u]; lds_read3<0>((unsigned)s[u], xj[u], yj[u], zj[u]); }
-    np += UNR * 64;
-    if(k + UNR < k1) {
+    for(int u = 0; u < U; u++) { sc[u] = s[u]; lds_read3<0>((unsigned)s[u], xj[u], yj[u], zj[u]); }
+    np += U * 64;
+    if(k + U < k1) {
 #pragma unroll
       for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
     }
 #pragma unroll
-    for(int u = 0; u < UNR; u++) {
+    for(int u = 0; u < U; u++) {
       const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
       const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));
       if(rsq < P.cutforcesq) {                             // (also keeps the padded lanes off the dummy slot's accumulator)
@@ -437,7 +453,10 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
         }
       }
     }
-  }
+  };
+  int k = k0;
+  for(; k + UNR <= k1; k += UNR) trip(std::integral_constant<int, UNR>{}, k);
+  if(k < k1) trip(std::integral_constant<int, QR>{}, k);
   v_acc *= (double)c_out;
   if(wv > 0) { s_f[lane] = fx; s_f[64 + lane] = fy; s_f[128 + lane] = fz; }
   __syncthreads();                                          // every pair of the tile has been accumulated

@@ -178,6 +178,7 @@ int mmd_bin_atoms(mmd_handle* h, int count)
 #define NB_CHUNKS 28
 #endif
 #define NB_SLOT_BYTES (3 * (int)sizeof(real))   // nl16 holds slot * NB_SLOT_BYTES (<= 43008 DP / 24576 SP)
+#define NB_ROW_PAD 4           // padding granularity of the tile rows (tile_max)
 #define NB_FASTR 9             // slices handled by the branch-free slot addressing (3x3 rows of blocks)
 #define NB_MAXA 512            // owned atoms of one block handled per pass (counts live in LDS)
 #define NB_IDX_MASK 0x1FFFFFFF // candidate word = index | info << 29
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     // ---- coalesced write-out of the padded, remapped rows; the atom's own slot is skipped on the way
     const int myn = MODE == 0 ? max(cnt[lane] - 1, 0) : cnt[lane];
     const int maxn = wave_max_i(myn);
-    int kmax = (maxn + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
+    int kmax = (maxn + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD;     // rows padded to 4: the tile kernels run trips of 8 + one of 4
     if(kmax > maxneighs) kmax = maxneighs;
     const int selfslot = MODE == 0 ? self0 + tl * 64 + lane : -7;      // (half rows never hold the atom itself)
     unsigned short* out = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
@@ -701,7 +702,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p);
     HIP_TRY(hipGetLastError());
     for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
-      MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 64, false, h->stream));
+      MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 16 * 64, false, h->stream));   // (+ prefetch overrun of the last tile)
       HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
       HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
       const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
