@@ -2,6 +2,8 @@
 // over the wave-interleaved neighbor rows, with the derivative-of-embedding halo (ForceEAM::communicate,
 // ref/force_eam.cpp:851-913) between them.
 //
+// (production: the tile forms k_eam_density_tile / k_eam_force_tile further down; the kernels on wave-interleaved rows
+//  are the fallback for uploaded lists and non-uniform tables)
 //   sweep 1  k_eam_density : rho_i = sum_j rho(r_ij) (cubic spline), fp_i = F'(rho_i), [EV] E_embed
 //   halo     fp of owned atoms -> ghosts (same send lists as Comm::communicate, 1 scalar per atom)
 //   sweep 2  k_eam_force   : f_i = -sum_j (fp_i rho' + fp_j rho' + phi') / r * del ; [EV] phi/2, virial

@@ -1,12 +1,15 @@
 // minimd_amd/csrc/force_lj.hip — ForceLJ::compute (ref/force_lj.cpp:72-113) as CDNA4 HIP kernels.
 //
-// One owned atom per lane; a wavefront walks its 64 wave-interleaved neighbor rows in lock-step:
-//   index load  neigh[(w*maxneighs + k)*64 + lane]   -> one coalesced 256 B line per k
-//   gather      x[j] (real4: xyz + type)             -> one aligned 32 B (DP) / 16 B (SP) load per pair
-// rows are padded with the far-away dummy atom up to the wavefront's longest row, so the loop is
-// wave-uniform and branch-free (the cutoff test is a select). Energy/virial are reduced with wavefront
-// shuffles, one partial per workgroup, summed in fixed order by k_sum_partials => deterministic.
-// This file is compiled WITH FMA contraction; parity against the (uncontracted) oracle is to ~1e-13.
+// Production kernels work on the TILE form of the neighbor list (neighbor.hip: <= 64 atoms of one 2x2x2-bin block, the
+// positions of the ~450 atoms their rows reference staged in LDS, 16-bit row entries that are LDS addresses):
+//   k_lj_full_tile   full lists (compute_fullneigh); can carry finalIntegrate(n) + initialIntegrate(n+1)
+//   k_lj_half_tile   half lists (compute_halfneigh_threaded): Newton's third law scattered into LDS accumulators
+// General fallbacks on the reference-style 32-bit rows (one owned atom per lane, wave-interleaved rows
+// neigh[(w*maxneighs + k)*64 + lane], one x[j] gather per pair) for uploaded lists and non-uniform type tables:
+//   k_lj_full, k_lj_half (global FP atomics)
+// Rows are padded with a far-away dummy atom, so the pair loops are wave-uniform and the cutoff is a select.
+// Energy/virial: wavefront shuffles -> one partial per workgroup -> fixed-order sum (k_sum_partials) => deterministic
+// for full lists. This file is compiled WITH FMA contraction; parity against the (uncontracted) oracle is ~1e-13.
 #include <type_traits>
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"

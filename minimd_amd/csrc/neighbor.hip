@@ -5,8 +5,9 @@
 //    are numbered block-major: 2x2x2 bins form a block (~57 atoms at LJ liquid density = one wavefront)
 //    and the bins of a block are consecutive, so a counting sort by bin id makes every block a contiguous
 //    slice of `binned[]`, and the blocks of one x-row contiguous too.
-//  * binning = atomic histogram + exclusive scan + atomic fill + in-bin index sort (=> deterministic
-//    order, identical to the reference run single-threaded inside each bin).
+//  * binning = atomic histogram that also hands out in-bin ranks (one atomic per run of equal bins in a
+//    wavefront) + exclusive scan + plain scatter + in-bin index sort (=> deterministic order, identical to
+//    the reference run single-threaded inside each bin).
 //  * build = one wavefront per block: the candidate atoms of the (2R+1)^3 surrounding blocks (contiguous
 //    slices of `binned`, coalesced loads) are held transposed in registers and every owned atom of the
 //    block is tested against 64 candidates per VALU pass; hits are appended in candidate order with
