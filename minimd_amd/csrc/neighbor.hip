@@ -18,6 +18,7 @@
 //  * overflow protocol as the reference's (ref/neighbor.cpp:184-208): rows count past maxneighs but store
 //    guarded; the host reads the maximum, grows maxneighs to 1.2*max and relaunches.
 #include "device_utils.hpp"
+#include <algorithm>
 #include "mmd_internal.hpp"
 #include <vector>
 
@@ -127,17 +128,50 @@ __global__ void k_bin_fill(const int* __restrict__ atom_bin, const int* __restri
   binned[bin_start[atom_bin[i]] + atom_rank[i]] = i;
 }
 
-// one thread per bin: insertion sort of its (short) slice -> ascending atom index, run-to-run identical
-__global__ void k_bin_sort(const int* __restrict__ bin_start, int mbins, int* __restrict__ binned)
+// one thread per bin: insertion sort of its (short) slice -> ascending atom index, run-to-run identical.
+// Bins longer than NB_BIGBIN (e.g. `-b 1`: every atom in one bin) are left to k_bin_sort_big.
+#define NB_BIGBIN 96
+__global__ void k_bin_sort(const int* __restrict__ bin_start, int mbins, int* __restrict__ binned, int* __restrict__ big_flag)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b >= mbins) return;
   const int s = bin_start[b], e = bin_start[b + 1];
+  if(e - s > NB_BIGBIN) { *big_flag = 1; return; }
   for(int a = s + 1; a < e; a++) {
     const int key = binned[a];
     int c = a - 1;
     while(c >= s && binned[c] > key) { binned[c + 1] = binned[c]; c--; }
     binned[c + 1] = key;
+  }
+}
+// long bins: every entry finds its rank by counting the smaller entries of its bin (O(n^2) compares spread over the whole
+// grid instead of one thread's insertion sort); `scratch` holds as many ints as `binned`; a second launch copies the
+// ranked entries back. Both exit at once when no bin is long.
+__global__ __launch_bounds__(256) void k_bin_rank_big(const int* __restrict__ bin_start, int mbins, const int* __restrict__ binned,
+                                                      int* __restrict__ scratch, const int* __restrict__ big_flag)
+{
+  if(*big_flag == 0) return;
+  const int stride = gridDim.x * blockDim.x;
+  for(int b = 0; b < mbins; b++) {
+    const int s = bin_start[b], n = bin_start[b + 1] - s;
+    if(n <= NB_BIGBIN) continue;
+    for(int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+      const int key = binned[s + t];
+      int rank = 0;
+      for(int u = 0; u < n; u++) rank += binned[s + u] < key ? 1 : 0;
+      scratch[s + rank] = key;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_bin_copy_big(const int* __restrict__ bin_start, int mbins, int* __restrict__ binned,
+                                                      const int* __restrict__ scratch, const int* __restrict__ big_flag)
+{
+  if(*big_flag == 0) return;
+  const int stride = gridDim.x * blockDim.x;
+  for(int b = 0; b < mbins; b++) {
+    const int s = bin_start[b], n = bin_start[b + 1] - s;
+    if(n <= NB_BIGBIN) continue;
+    for(int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) binned[s + t] = scratch[s + t];
   }
 }
 
@@ -153,7 +187,11 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   HIP_TRY(hipMemcpyAsync(h->bin_start.p, h->bin_count.p, ((size_t)g.mbins + 1) * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
   MMD_TRY(mmd_exclusive_scan(h, h->bin_start.p, g.mbins, nullptr));
   if(n) hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p);
-  hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p);
+  HIP_TRY(hipMemsetAsync(h->d_flags + 12, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->d_flags + 12);
+  // (atom_bin is free again after the fill: scratch of the long-bin sort)
+  hipLaunchKernelGGL(k_bin_rank_big, dim3(1024), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
+  hipLaunchKernelGGL(k_bin_copy_big, dim3(1024), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
   HIP_TRY(hipGetLastError());
   return 0;
 }
