@@ -80,7 +80,7 @@ int mmd_neighbor_build(mmd_handle* h);
 int mmd_neighbor_geometry(mmd_handle* h, int mbin[3], int mbinlo[3], int nblk[3], int reach[3]);
 /* maxneighs (row stride), number of device bins, sum over rows, max row length of the last build */
 int mmd_neighbor_info(mmd_handle* h, int* maxneighs, int* mbins, long long* total_neigh, int* max_row);
-/* diagnostics of the device tile form of a full list: out = {tiles, largest candidate union, sum of
+/* diagnostics of the device tile form of the list (full or half): out = {tiles, largest candidate union, sum of
  * candidate unions, sum of padded row counts, sum of atoms in tiles, longest padded row}; zeros when no tiles exist */
 int mmd_neighbor_tile_stats(mmd_handle* h, long long out[6]);
 /* rows in REFERENCE layout neighbors[i*maxneighs + k] (ref/neighbor.cpp:128); maxneighs = caller's stride */
