@@ -374,8 +374,8 @@ template <int EV, int GN>
 __global__ __launch_bounds__(128) void k_lj_half_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
-    const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, int pos_bytes, LJParams P, real* __restrict__ f,
-    double* __restrict__ partials, int ablate)
+    const unsigned short* __restrict__ nl16, const unsigned short* __restrict__ tile_self, int nlocal, int nall, int maxneighs, int pos_bytes,
+    LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate)
 {
   constexpr int UNR = 8, NT = 128, STG = 4;
   extern __shared__ __align__(16) unsigned char s_raw[];
@@ -465,9 +465,15 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   __syncthreads();                                          // every pair of the tile has been accumulated
   if(wv == 0 && i >= 0) {
     fx += s_f[lane]; fy += s_f[64 + lane]; fz += s_f[128 + lane];
-    real* fi = f + 3 * (size_t)i;
-    unsafeAtomicAdd(fi + 0, fx * c_out); unsafeAtomicAdd(fi + 1, fy * c_out); unsafeAtomicAdd(fi + 2, fz * c_out);
+    const unsigned own = tile_self[(size_t)tile * 64 + lane];
+    if(own != 0xffffu) {          // the atom is one of the tile's candidates: its own force joins that accumulator (sign: see flush)
+      s_acc[3 * own] -= fx; s_acc[3 * own + 1] -= fy; s_acc[3 * own + 2] -= fz;
+    } else {
+      real* fi = f + 3 * (size_t)i;
+      unsafeAtomicAdd(fi + 0, fx * c_out); unsafeAtomicAdd(fi + 1, fy * c_out); unsafeAtomicAdd(fi + 2, fz * c_out);
+    }
   }
+  __syncthreads();
   for(int t = tid; t < ncand && !(ablate & 2); t += NT) {   // partners: ONE global atomic per component and candidate
     const int j = cl[t];
     if(GN || j < nlocal) {
@@ -632,7 +638,8 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define HT(EVv, Gv) if(ev == EVv && gn == Gv)                                                                                        \
       hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(h->ntiles)), dim3(128), lds, h->stream, h->x.p, h->binned.p,          \
                          h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->ntiles,     \
-                         h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p, h->partials.p, h->opt_ablate)
+                         h->nl16.p, h->tile_self.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,            \
+                         h->partials.p, h->opt_ablate)
     HT(0, 0); HT(0, 1); HT(1, 0); HT(1, 1);
 #undef HT
   } else {

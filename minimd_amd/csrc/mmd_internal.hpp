@@ -143,6 +143,7 @@ struct mmd_handle {
   int ntiles = 0, tile_tmax = 0;          // tile_tmax: largest candidate count of any block (LDS sizing)
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
+  DevArr<unsigned short> tile_self;       // half lists: union slot of each tile atom itself (0xffff: not in the union)
   DevArr<int> tile_ghost, tile_order;     // per tile: references a ghost atom?; tiles ordered interior-first
   int ntiles_interior = 0;
   hipEvent_t ev_x_ready = nullptr, ev_halo_done = nullptr;

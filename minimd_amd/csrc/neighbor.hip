@@ -392,8 +392,8 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
                                                        int nall, real cutneighsq, int maxneighs, int cstride, const int* __restrict__ tile_of_block,
                                                        int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
                                                        int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
-                                                       int* __restrict__ tile_max, int* __restrict__ tile_ghost, int* __restrict__ flags,
-                                                       unsigned long long* __restrict__ total_out, int ablate)
+                                                       int* __restrict__ tile_max, int* __restrict__ tile_ghost, unsigned short* __restrict__ tile_self,
+                                                       int* __restrict__ flags, unsigned long long* __restrict__ total_out, int ablate)
 {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   unsigned short* rows = (unsigned short*)s_dyn;              // [maxneighs][64]
@@ -602,11 +602,14 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
         if(bit) {
           tile_cand[(size_t)tile * cstride + pos] = cj[c];
           remap[c * 64 + lane] = (unsigned short)pos;
-        }
+        } else if(MODE != 0) remap[c * 64 + lane] = 0xffff;
         base += __popcll(m);
       }
     }
     __syncthreads();
+    // half lists: where the atom itself sits in the tile's union (0xffff: no tile mate references it) — the half force
+    // kernel adds the atom's own force to that accumulator instead of issuing separate global atomics
+    if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = ta + lane < te ? remap[self0 + tl * 64 + lane] : (unsigned short)0xffff;
     // ---- coalesced write-out of the padded, remapped rows; the atom's own slot is skipped on the way
     const int myn = MODE == 0 ? max(cnt[lane] - 1, 0) : cnt[lane];
     const int maxn = wave_max_i(myn);
@@ -736,6 +739,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     MMD_TRY(h->tile_ncand.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_cnt.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_ghost.ensure((size_t)nt + 2, false, h->stream));
+    if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
     hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p);
@@ -750,6 +754,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   hipLaunchKernelGGL(k_build_tiles<M>, dim3(xcd_grid(nblocks)), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p,          \
                      h->ghost_image.p, g, nblocks, nlocal, nlocal + h->nghost, h->cutneighsq, h->maxneighs, h->tile_cstride,             \
                      h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p, h->tile_max.p, h->tile_ghost.p,      \
+                     h->tile_self.p,                                                                                                     \
                      h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate)
       if(tmode == 0) LAUNCH_TILES(0); else if(tmode == 1) LAUNCH_TILES(1); else LAUNCH_TILES(2);
 #undef LAUNCH_TILES
