@@ -380,9 +380,12 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   constexpr int UNR = 8, NT = 128, STG = 4;
   extern __shared__ __align__(16) unsigned char s_raw[];
   real* sp = (real*)s_raw;
-  real* s_acc = (real*)(s_raw + pos_bytes);
-  real* s_f = (real*)(s_raw + 2 * (size_t)pos_bytes);
-  double* s_red = (double*)(s_raw + 2 * (size_t)pos_bytes + lj_tile_sf_bytes(2));
+  // accumulators are doubles in both precisions: ds_add_f64 runs ~8x faster than ds_add_f32 on this part (measured: 0.10 vs
+  // 0.81 ms of LDS atomics at -s 80), and the per-candidate sums lose nothing before the single rounding at the flush
+  double* s_acc = (double*)(s_raw + pos_bytes);
+  const int acc_bytes = pos_bytes * (int)(sizeof(double) / sizeof(real));
+  real* s_f = (real*)(s_raw + (size_t)pos_bytes + acc_bytes);
+  double* s_red = (double*)(s_raw + (size_t)pos_bytes + acc_bytes + lj_tile_sf_bytes(2));
   unsigned char* s_ghost = (unsigned char*)(s_red + 16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -445,8 +448,9 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
         const real fs = (A * sr2) * fma_r(A, P.sigma6, (real)-0.5);          // force / c_out
         const real px = dx * fs, py = dy * fs, pz = dz * fs;
         fx += px; fy += py; fz += pz;
-        real* a = (real*)((unsigned char*)s_acc + sc[u]);   // the partner's accumulator collects +p, negated at the flush
-        if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, px); unsafeAtomicAdd(a + 1, py); unsafeAtomicAdd(a + 2, pz); }   // (ablate: profiling only)
+        // the partner's accumulator collects +p, negated at the flush (sc = slot * 3 reals in bytes -> slot * 3 doubles)
+        double* a = (double*)((unsigned char*)s_acc + sc[u] * (int)(sizeof(double) / sizeof(real)));
+        if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, (double)px); unsafeAtomicAdd(a + 1, (double)py); unsafeAtomicAdd(a + 2, (double)pz); }   // (ablate: profiling only)
         if(EV) {
           real scale = (real)1.0;
           if(!GN) scale = s_ghost[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))] ? (real)0.5 : (real)1.0;
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     fx += s_f[lane]; fy += s_f[64 + lane]; fz += s_f[128 + lane];
     const unsigned own = tile_self[(size_t)tile * 64 + lane];
     if(own != 0xffffu) {          // the atom is one of the tile's candidates: its own force joins that accumulator (sign: see flush)
-      s_acc[3 * own] -= fx; s_acc[3 * own + 1] -= fy; s_acc[3 * own + 2] -= fz;
+      s_acc[3 * own] -= (double)fx; s_acc[3 * own + 1] -= (double)fy; s_acc[3 * own + 2] -= (double)fz;
     } else {
       real* fi = f + 3 * (size_t)i;
       unsafeAtomicAdd(fi + 0, fx * c_out); unsafeAtomicAdd(fi + 1, fy * c_out); unsafeAtomicAdd(fi + 2, fz * c_out);
@@ -477,10 +481,11 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   for(int t = tid; t < ncand && !(ablate & 2); t += NT) {   // partners: ONE global atomic per component and candidate
     const int j = cl[t];
     if(GN || j < nlocal) {
-      const real ax = s_acc[3 * t], ay = s_acc[3 * t + 1], az = s_acc[3 * t + 2];
+      const double ax = s_acc[3 * t], ay = s_acc[3 * t + 1], az = s_acc[3 * t + 2];
       if(ax != 0 || ay != 0 || az != 0) {
         real* fj = f + 3 * (size_t)j;
-        unsafeAtomicAdd(fj + 0, -(ax * c_out)); unsafeAtomicAdd(fj + 1, -(ay * c_out)); unsafeAtomicAdd(fj + 2, -(az * c_out));
+        unsafeAtomicAdd(fj + 0, (real)(-(ax * (double)c_out))); unsafeAtomicAdd(fj + 1, (real)(-(ay * (double)c_out)));
+        unsafeAtomicAdd(fj + 2, (real)(-(az * (double)c_out)));
       }
     }
   }
@@ -627,13 +632,14 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define F(EVv, Uv, Xv) if(ev == EVv && uni == Uv && ex == Xv) launch_full<EVv, Uv, (Xv != 0)>(h, nblocks, T)
     F(0, 0, 0); F(0, 0, 1); F(0, 1, 0); F(0, 1, 1); F(1, 0, 0); F(1, 0, 1); F(1, 1, 0); F(1, 1, 1);
 #undef F
-  } else if(h->tiles_ready && h->opt_tiles && uni && !ex && 2 * lj_tile_pos_bytes(h) + 4096 <= 64 * 1024) {
+  } else if(h->tiles_ready && h->opt_tiles && uni && !ex && 3 * lj_tile_pos_bytes(h) + 4096 <= 64 * 1024) {
     // half lists in tile form: on-chip scatter (k_lj_half_tile)
     MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));     // ref/force_lj.cpp:286-291
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
     const size_t pos_bytes = lj_tile_pos_bytes(h);
-    const size_t lds = 2 * pos_bytes + lj_tile_sf_bytes(2) + 16 * sizeof(double) + (size_t)(h->tile_cmax + 2) + 16;
+    const size_t acc_bytes = pos_bytes * (sizeof(double) / sizeof(real));
+    const size_t lds = pos_bytes + acc_bytes + lj_tile_sf_bytes(2) + 16 * sizeof(double) + (size_t)(h->tile_cmax + 2) + 16;
     const int gn = h->ghost_newton ? 1 : 0;
 #define HT(EVv, Gv) if(ev == EVv && gn == Gv)                                                                                        \
       hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(h->ntiles)), dim3(128), lds, h->stream, h->x.p, h->binned.p,          \
