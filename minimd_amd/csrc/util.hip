@@ -75,11 +75,15 @@ __global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ d, int n, 
 // d[n] must be writable: the grand total is also stored there (bin_start[mbins] convention)
 int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host)
 {
-  const int ntiles = div_up(n, SCAN_TILE);
-  MMD_TRY(h->scan_tmp.ensure((size_t)ntiles + 8, false, h->stream));
-  hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, h->stream, data, n, h->scan_tmp.p);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, h->scan_tmp.p, ntiles, data + n);
-  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, h->stream, data, n, h->scan_tmp.p);
+  if(n <= 16384) {            // short arrays (per-tile counts of the compactions): one workgroup scans in place
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, data, n, data + n);
+  } else {
+    const int ntiles = div_up(n, SCAN_TILE);
+    MMD_TRY(h->scan_tmp.ensure((size_t)ntiles + 8, false, h->stream));
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, h->stream, data, n, h->scan_tmp.p);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, h->scan_tmp.p, ntiles, data + n);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, h->stream, data, n, h->scan_tmp.p);
+  }
   HIP_TRY(hipGetLastError());
   if(total_host) {
     HIP_TRY(hipMemcpyAsync(h->h_flags, data + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
