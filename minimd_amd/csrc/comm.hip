@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void k_pack_border(const real4* __restrict__ x
                                                      const int* __restrict__ ghost_root, int nlocal,
                                                      const int* __restrict__ list, int n, real sx, real sy, real sz, int pbc_any,
                                                      int px, int py, int pz, real4* __restrict__ dst, int* __restrict__ dst_img,
-                                                     int* __restrict__ dst_root)
+                                                     int* __restrict__ dst_root, int* __restrict__ dst_type)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= n) return;
@@ -560,6 +560,7 @@ __global__ __launch_bounds__(256) void k_pack_border(const real4* __restrict__ x
   const int code = i < nlocal ? IMAGE_NONE : ghost_image[i - nlocal];
   dst_img[k] = image_add(code, px, py, pz);
   if(dst_root) dst_root[k] = i < nlocal ? i : ghost_root[i - nlocal];
+  if(dst_type) dst_type[k] = (int)p.w;          // Atom::unpack_border tail (ref/atom.cpp:216-226) for a self swap
 }
 
 // One-rank fast path of Comm::communicate: every ghost is a periodic image of an owned atom; replay its chain of
@@ -624,7 +625,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
         if(nsend)
           hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->ghost_root.p,
                              h->nlocal, s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], h->x.p + nall,
-                             h->ghost_image.p + h->nghost, h->ghost_root.p + h->nghost);
+                             h->ghost_image.p + h->nghost, h->ghost_root.p + h->nghost, h->type.p + nall);
       } else {
         // message = nsend real4 followed by nsend image codes
         const size_t bytes_s = (size_t)nsend * (sizeof(real4) + sizeof(int));
@@ -634,7 +635,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
         if(nsend)
           hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->ghost_root.p,
                              h->nlocal, s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], (real4*)h->buf_send.p, simg,
-                             (int*)nullptr);
+                             (int*)nullptr, (int*)nullptr);
         MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, s.sendproc, &nrecv, s.recvproc));
         const size_t bytes_r = (size_t)nrecv * (sizeof(real4) + sizeof(int));
         MMD_TRY(h->buf_recv.ensure(bytes_r / sizeof(real) + 8, false, h->stream));
@@ -646,7 +647,8 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
           HIP_TRY(hipMemcpyAsync(h->ghost_image.p + h->nghost, (real4*)h->buf_recv.p + nrecv, (size_t)nrecv * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
         }
       }
-      if(nrecv) hipLaunchKernelGGL(k_ghost_types, dim3(div_up(nrecv, 256)), dim3(256), 0, h->stream, h->x.p, nall, nrecv, h->type.p);
+      const bool self_swap = s.sendproc == h->me && !h->opt_force_transport;      // (its pack kernel wrote the types too)
+      if(nrecv && !self_swap) hipLaunchKernelGGL(k_ghost_types, dim3(div_up(nrecv, 256)), dim3(256), 0, h->stream, h->x.p, nall, nrecv, h->type.p);
       HIP_TRY(hipGetLastError());
       s.sendnum = nsend;
       s.recvnum = nrecv;
