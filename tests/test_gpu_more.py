@@ -198,6 +198,29 @@ def test_four_and_eight_ranks_match_one_rank(nprocs, size, half, port, tmp_path)
     o.close()
 
 
+@pytest.mark.parametrize("prec,deck,nprocs,port", [("dp", "in.eam.miniMD", 2, 29651), ("sp", "in.lj.miniMD", 4, 29652), ("dp", "in.eam.miniMD", 8, 29653)])
+def test_eam_and_sp_on_several_ranks(prec, deck, nprocs, port, tmp_path):
+    """EAM needs a second halo per step (fp of the ghosts, ForceEAM::communicate ref/force_eam.cpp:851-913) and the SP build
+    moves float4 halos: both on several ranks sharing this GPU against the one-rank run"""
+    size = ["-s", "8"] if "eam" in deck else ["-nx", "8", "-ny", "9", "-nz", "10"]
+    args = ["-i", deck] + size + ["-n", "60", "--half_neigh", "0"]
+    base = sim_rows(args, precision=prec)
+    out = str(tmp_path / "mp.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nprocs), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "sim", out, prec] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.join(REPO, "data"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert sum(c[0] for c in res["counts"]) == res["natoms"]
+    rows = [tuple(x) for x in res["rows"]]
+    tol = 1e-9 if prec == "dp" else 2e-5
+    assert [r_[0] for r_ in rows] == [b[0] for b in base]
+    for a, b in zip(rows, base):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(b[k])), (a, b)
+
+
 @pytest.mark.parametrize("lists", [["--half_neigh", 1, "-gn", 1], ["--half_neigh", 0]])
 def test_rccl_loopback_single_rank(lists):
     """exercise the production transport calls (ncclCommInitRank, grouped ncclSend/ncclRecv, ncclAllReduce) on ONE
