@@ -502,3 +502,37 @@ def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
         assert res[0][0] == other[0]
         for a, b in zip(res[0][1:], other[1:]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_bench_contract_two_ranks_sharing_the_gpu(tmp_path):
+    """bench.py's N>1 plumbing (torch.distributed.run, gloo control plane, barrier + max-over-ranks timing, one JSON line from
+    rank 0) with the halo on the host-staged debug transport, since two RCCL ranks cannot share one GPU"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MMD_BENCH_TRANSPORT="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29661", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20", "--size", "16"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 20 and d["scaling"] == "weak" and d["value"] > 0
+    assert "32x16x16" in d["config"]["workload"] and d["cpu_baseline"] is None      # (CPU baseline only at N=1)
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+
+
+@pytest.mark.gpu
+def test_bench_contract_single_gpu():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "40", "--warmup", "20", "--size", "24", "--cpu-steps", "20"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["metric"].startswith("Matom-steps/sec") and d["unit"] == "Matom-steps/s" and d["dtype"] == "f64"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["unit"] == "GB/s"
+    cb = d["cpu_baseline"]
+    assert cb and cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
