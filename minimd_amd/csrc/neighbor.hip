@@ -190,8 +190,8 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   HIP_TRY(hipMemsetAsync(h->d_flags + 12, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->d_flags + 12);
   // (atom_bin is free again after the fill: scratch of the long-bin sort)
-  hipLaunchKernelGGL(k_bin_rank_big, dim3(1024), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
-  hipLaunchKernelGGL(k_bin_copy_big, dim3(1024), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
+  hipLaunchKernelGGL(k_bin_rank_big, dim3(128), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
+  hipLaunchKernelGGL(k_bin_copy_big, dim3(128), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
   HIP_TRY(hipGetLastError());
   return 0;
 }
