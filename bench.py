@@ -2,18 +2,23 @@
 """bench.py — Matom-steps/s of the miniMD hot path (LJ, full neighbor lists, double precision) on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    (N > 1: either under  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+            or as a plain process: bench.py then re-launches itself through torch.distributed.run on a free port)
 
 A "step" is one MD timestep of BASELINE.json configs[1]: in.lj.miniMD, -s 80 per GPU (2,048,000 atoms per GPU,
 weak scaling: the global box is 160x80x80 / 160x160x80 / 160^3 unit cells at 2/4/8 GPUs), full neighbor list,
 re-neighboring every 20 steps, thermo every 100 — i.e. exactly the loop the reference times
 (Integrate::run, ref/ljs.cpp:470-472). Atoms are resident in HBM when the timed region starts.
+Before the W warm-up steps the system is equilibrated for --equil steps (default 100, untimed, part of the set-up):
+the lattice has melted and the timed window sees the state SURVEY.md §8(d) names for the roofline figure (positions
+and neighbor lists "as they exist at step 100"), whatever K and W are. Re-neighboring follows the global step number,
+so every 20 timed steps contain exactly one rebuild.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
-import re
+import socket
 import subprocess
 import sys
 import time
@@ -66,16 +71,27 @@ def main():
     ap.add_argument("--size", type=int, default=80, help="unit cells per GPU edge (BASELINE configs[1]: 80)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--equil", type=int, default=100, help="untimed equilibration steps before the warm-up (set-up, see the module docstring)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher — one rank per GPU through torch.distributed.run on a free
+        # loop-back port; the ranks' stdout (rank 0's single JSON line) passes straight through
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; running with the %d rank(s) that exist" % (args.gpus, world, world), file=sys.stderr)
 
     import torch
     import minimd_amd
@@ -85,7 +101,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
-        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        ndev = max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank % ndev)
+        if ndev < world and "MMD_BENCH_TRANSPORT" not in os.environ:
+            # fewer GPUs than ranks: RCCL refuses two ranks on one device, so the halos fall back to the host-staged
+            # transport (the JSON line says so: "transport": "host")
+            os.environ["MMD_BENCH_TRANSPORT"] = "gloo"
+            if rank == 0:
+                print("bench.py: %d ranks on %d GPU(s): host-staged halos instead of RCCL" % (world, ndev), file=sys.stderr)
         if os.environ.get("MMD_BENCH_TRANSPORT") == "gloo":
             # debugging aid (e.g. two ranks sharing one GPU): host-staged halos over gloo instead of RCCL
             from minimd_amd import api
@@ -117,6 +140,8 @@ def main():
         k, v = kv.split("=")
         sim.handle.set_option(k, int(v))
     sim.initial()
+    if args.equil > 0:
+        sim.run_steps(args.equil)
     if args.warmup > 0:
         sim.run_steps(args.warmup)
 
@@ -143,12 +168,19 @@ def main():
     bpa = algorithmic_bytes_per_atom(kbar, nghost / max(nlocal, 1))
     k_ms = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
     achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if world == 1 and args.size == 80 and os.path.exists(tpath):
-        # HBM bytes per launch of the same kernel on the same workload from the committed PMC passes
-        # (rocprofv3 cannot be run from inside the timed process); see profiles/README.md
-        traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+    traffic, traffic_source = None, None
+    for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(REPO, "profiles", tname)
+        if world == 1 and args.size == 80 and os.path.exists(tpath):
+            # HBM bytes per launch of the same kernel on the same workload from the committed rocprofv3 --pmc passes
+            # (counters cannot be collected from inside the timed process); see profiles/README.md
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            traffic_source = "profiles/%s (separate rocprofv3 --pmc passes of this kernel on this workload, FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)" % tname
+            break
+    # SURVEY §8(d) kernel-only figure: 20 back-to-back launches of the force kernel alone (evflag 0, no fused integrator) on the
+    # state the timed region left behind, hipEvents on the compute stream
+    k_only_ms = sim.handle.profile_kernel(0, 20) if nlocal else None
+    tinfo = sim.handle.transport_info()
     copy_gbs = None
     if rank == 0:
         # measured device-copy bandwidth of this GPU (read + write bytes of a 1 GiB device-to-device copy), the practical
@@ -172,12 +204,16 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "in.lj.miniMD -s %d per GPU (global %dx%dx%d cells, %d atoms), full neighbor list, DP, "
-                               "reneigh 20, thermo 100" % (args.size, nx, ny, nz, natoms),
-                   "parallelism": "spatial %dx%dx%d, RCCL p2p halos" % dims},
+                               "reneigh 20, thermo 100; %d untimed equilibration steps before the warm-up" % (args.size, nx, ny, nz, natoms, args.equil),
+                   "parallelism": "spatial %dx%dx%d, %s" % (dims + ({"rccl": "RCCL p2p halos over xGMI", "host": "host-staged halos (debug transport)",
+                                                                      "none": "single rank"}[tinfo["kind"]],)),
+                   "transport": tinfo["kind"], "transport_ranks": tinfo["nranks"]},
         # the launched kernel is the LJ force WITH the velocity-Verlet update fused in (it also reads/writes v and writes the
         # new x: +80 B/atom, and skips the f store: -24 B); `achieved` still counts only SURVEY §8d's force-kernel bytes
         "roofline": {"bound": "hbm", "kernel": "k_lj_full_tile (ForceLJ::compute_fullneigh + fused Integrate)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel_only_ms": k_only_ms,
+                     "frac_kernel_only": (bpa * nlocal / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_only_ms else None,
                      "measured_copy_GBs": copy_gbs,
                      "kernel_ms": k_ms, "launches": tm["force_launches"], "bytes_per_atom": bpa, "atoms_per_launch": nlocal,
                      # informational: the same launches with the fused integrator's own compulsory bytes counted too

@@ -117,6 +117,8 @@ int mmd_comm_swap_info(mmd_handle* h, int iswap, double slab[2], int pbc[4], int
 /* attach the multi-GPU transport: RCCL communicator built from a 128-byte ncclUniqueId */
 int mmd_comm_unique_id(unsigned char id[128]);
 int mmd_comm_init_rccl(mmd_handle* h, const unsigned char id[128], int rank, int nranks);
+/* transport in use: kind 1 = RCCL (nranks / rank from ncclCommCount / ncclCommUserRank), 2 = host-staged callbacks, 0 = none */
+int mmd_comm_transport_info(mmd_handle* h, int* kind, int* nranks, int* rank);
 /* host-staged transport for tests / fallback (e.g. torch.distributed gloo): the callback must
  * exchange nsend bytes to `dest` and receive up to nrecv_max bytes from `src`, returning bytes received */
 typedef long long (*mmd_sendrecv_fn)(void* ctx, const void* sendbuf, long long nsend, int dest, void* recvbuf,

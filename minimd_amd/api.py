@@ -69,6 +69,7 @@ def load_library(precision="dp"):
         "mmd_comm_setup": [P, creal, I, I], "mmd_comm_info": [P, ip, ip, ip, ip, ip],
         "mmd_comm_swap_info": [P, I, dp, ip, ip, ip], "mmd_comm_unique_id": [C.c_char_p],
         "mmd_comm_init_rccl": [P, C.c_char_p, I, I], "mmd_comm_set_host_transport": [P, P, P, P],
+        "mmd_comm_transport_info": [P, ip, ip, ip],
         "mmd_comm_exchange": [P], "mmd_comm_borders": [P], "mmd_comm_communicate": [P],
         "mmd_comm_reverse_communicate": [P], "mmd_comm_download_lists": [P, I, ip],
         "mmd_integrate_setup": [P, creal, creal, I, I], "mmd_integrate_initial": [P], "mmd_integrate_final": [P],
@@ -304,6 +305,11 @@ class Handle:
 
     def init_rccl(self, unique_id, rank, nranks):
         self._chk(self.L.mmd_comm_init_rccl(self.h, unique_id, rank, nranks))
+
+    def transport_info(self):
+        k, n, r = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.mmd_comm_transport_info(self.h, C.byref(k), C.byref(n), C.byref(r)))
+        return {"kind": {0: "none", 1: "rccl", 2: "host"}[k.value], "nranks": n.value, "rank": r.value}
 
     def unique_id(self):
         buf = C.create_string_buffer(128)

@@ -96,6 +96,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   if(!strcmp(name, "exact_div")) h->opt_exact_div = value;
   else if(!strcmp(name, "time_force_events")) h->time_force_events = value != 0;
   else if(!strcmp(name, "tiles")) h->opt_tiles = value;
+  else if(!strcmp(name, "build")) h->opt_build = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) h->opt_ablate = value;
   else if(!strcmp(name, "fuse")) h->opt_fuse = value;
@@ -110,7 +111,9 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
 }
 
 // ---- event pairs around the force kernel (GPU time of the kernel itself, for the roofline) ------------
-static int ev_begin(mmd_handle* h)
+// kind 0: Force::compute (TIME_FORCE), kind 1: Comm::communicate / reverse_communicate (added to TIME_COMM like
+// ref/integrate.cpp:103-105,190-195). Pairs are recorded on the stream the work is enqueued on (h->stream at that moment).
+static int ev_begin(mmd_handle* h, int kind = 0)
 {
   if(h->ev_used == h->ev_pool.size()) {
     EventPair p;
@@ -118,6 +121,7 @@ static int ev_begin(mmd_handle* h)
     HIP_TRY(hipEventCreate(&p.b));
     h->ev_pool.push_back(p);
   }
+  h->ev_pool[h->ev_used].kind = kind;
   HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used].a, h->stream));
   return 0;
 }
@@ -130,11 +134,12 @@ static int ev_end(mmd_handle* h)
 static int ev_collect(mmd_handle* h)
 {
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if(h->comm_stream) HIP_TRY(hipStreamSynchronize(h->comm_stream));
   for(size_t i = 0; i < h->ev_used; i++) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
-    h->force_ms += ms;
-    h->force_launches++;
+    if(h->ev_pool[i].kind == 0) { h->force_ms += ms; h->force_launches++; }
+    else h->comm_ms += ms;
   }
   h->ev_used = 0;
   return 0;
@@ -168,14 +173,16 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   if(!h) { mmd_set_error("null handle"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
   for(int i = 0; i < 5; i++) h->timer[i] = 0;
-  h->force_ms = 0; h->force_launches = 0; h->ev_used = 0;
+  h->force_ms = 0; h->comm_ms = 0; h->force_launches = 0; h->ev_used = 0;
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double t_start = mmd_wall();
   double t_prev;
   // host-side phase clocks need the device drained at phase boundaries only when a phase is to be
   // attributed; kernels are enqueued asynchronously, so the COMM/NEIGH/FORCE buckets are sampled
   // with a stream sync on re-neighbor steps (where the host must read counts anyway) and on thermo steps.
-  int next_sort = h->sort_every > 0 ? h->sort_every : ntimes + 1;
+  // the re-neighbor / sort schedule follows the GLOBAL step number (first_step + n + 1), so a run cut into slices of any
+  // length re-neighbors on exactly the steps one uninterrupted run does (ref/integrate.cpp:84,101,159-160)
+  if(first_step == 0 || h->next_sort < 0) h->next_sort = h->sort_every > 0 ? h->sort_every : 0x7fffffff;
   const bool reverse = h->halfneigh && h->ghost_newton;
   bool initial_done = false;        // initialIntegrate of this step already ran fused with the previous finalIntegrate
   // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
@@ -192,7 +199,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   for(int n = 0; n < ntimes; n++) {
     if(!initial_done) MMD_TRY(mmd_integrate_initial(h));
     initial_done = false;
-    if((n + 1) % h->neigh_every) {
+    if((first_step + n + 1) % h->neigh_every) {
       const int step_now = first_step + n + 1;
       const int ev_now = thermo_nstat > 0 && (step_now % thermo_nstat == 0);
       if(overlap && mmd_lj_tiles_available(h)) {
@@ -201,7 +208,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         HIP_TRY(hipEventRecord(h->ev_x_ready, h->stream));
         HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_x_ready, 0));
         std::swap(h->stream, h->comm_stream);
-        const int rc = mmd_comm_communicate(h);
+        int rc = h->time_force_events ? ev_begin(h, 1) : 0;
+        if(rc >= 0) rc = mmd_comm_communicate(h);
+        if(rc >= 0 && h->time_force_events) rc = ev_end(h);
         std::swap(h->stream, h->comm_stream);
         MMD_TRY(rc);
         HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
@@ -214,10 +223,13 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         MMD_TRY(rc0);
         halo_pending = true;
         evflag_pending = ev_now;
-      } else
+      } else {
+        if(h->time_force_events) MMD_TRY(ev_begin(h, 1));
         MMD_TRY(mmd_comm_communicate(h));
+        if(h->time_force_events) MMD_TRY(ev_end(h));
+      }
     } else {
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      MMD_TRY(ev_collect(h));                  // drains the stream; keeps the event pool at <= neigh_every pairs
       if(h->opt_check_exchange && h->xold_n == h->nlocal) {    // ref/integrate.cpp:112-151 (warning text as there)
         double d_max = 0;
         MMD_TRY(mmd_integrate_max_move(h, &d_max));
@@ -229,7 +241,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       }
       t_prev = mmd_wall();
       MMD_TRY(mmd_comm_exchange(h));
-      if(n + 1 >= next_sort) { MMD_TRY(mmd_atom_sort(h)); next_sort += h->sort_every; }
+      if(first_step + n + 1 >= h->next_sort) { MMD_TRY(mmd_atom_sort(h)); h->next_sort += h->sort_every; }
       MMD_TRY(mmd_comm_borders(h));
       if(h->opt_check_exchange) MMD_TRY(mmd_integrate_mark_positions(h));
       HIP_TRY(hipStreamSynchronize(h->stream));
@@ -260,7 +272,11 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       h->fuse_now = 0;
       MMD_TRY(rc);
     }
-    if(reverse) MMD_TRY(mmd_comm_reverse_communicate(h));
+    if(reverse) {
+      if(h->time_force_events) MMD_TRY(ev_begin(h, 1));
+      MMD_TRY(mmd_comm_reverse_communicate(h));
+      if(h->time_force_events) MMD_TRY(ev_end(h));
+    }
     if(fused_force) {
       std::swap(h->x, h->x_alt);                 // the tile kernel wrote v and the next positions of every owned atom
       initial_done = true;
@@ -281,6 +297,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   MMD_TRY(ev_collect(h));
   h->timer[0] = mmd_wall() - t_start;
   h->timer[2] = h->force_ms * 1e-3;          // TIME_FORCE: GPU time between the events around Force::compute
+  h->timer[1] += h->comm_ms * 1e-3;          // TIME_COMM also counts the per-step halos (GPU time between their events)
   return 0;
 }
 

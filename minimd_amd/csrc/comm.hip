@@ -158,6 +158,23 @@ extern "C" int mmd_comm_init_rccl(mmd_handle* h, const unsigned char id[128], in
   return 0;
 }
 
+// which transport the halos use: 1 = RCCL (nranks / rank as ncclCommCount / ncclCommUserRank report them), 2 = host-staged
+// callbacks, 0 = none (single rank: every swap is a self swap)
+extern "C" int mmd_comm_transport_info(mmd_handle* h, int* kind, int* nranks, int* rank)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  int k = 0, n = h->nprocs, r = h->me;
+  if(h->rccl) {
+    k = 1;
+    NCCL_TRY(ncclCommCount((ncclComm_t)h->rccl, &n));
+    NCCL_TRY(ncclCommUserRank((ncclComm_t)h->rccl, &r));
+  } else if(h->host_sr) k = 2;
+  if(kind) *kind = k;
+  if(nranks) *nranks = n;
+  if(rank) *rank = r;
+  return 0;
+}
+
 extern "C" int mmd_comm_set_host_transport(mmd_handle* h, mmd_sendrecv_fn sr, mmd_allreduce_fn ar, void* ctx)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }

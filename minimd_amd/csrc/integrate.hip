@@ -77,6 +77,7 @@ extern "C" int mmd_integrate_setup(mmd_handle* h, mmd_float dt, mmd_float dtforc
   if(!h) { mmd_set_error("null handle"); return -1; }
   if(neigh_every < 1) { mmd_set_error("mmd_integrate_setup: neigh_every must be >= 1"); return -1; }
   h->dt = dt; h->dtforce = dtforce; h->neigh_every = neigh_every; h->sort_every = sort_every;
+  h->next_sort = -1;
   return 0;
 }
 

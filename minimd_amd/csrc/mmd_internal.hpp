@@ -104,7 +104,7 @@ struct Swap {                // one of the 2*sum(need) swaps of Comm::setup (ref
   DevArr<int> sendlist;
 };
 
-struct EventPair { hipEvent_t a, b; };
+struct EventPair { hipEvent_t a, b; int kind = 0; };
 
 struct mmd_handle {
   int device = 0;
@@ -151,6 +151,7 @@ struct mmd_handle {
   int tile_cstride = 0, tile_cmax = 0;
   DevArr<unsigned short> nl16;
   int opt_tiles = 1;
+  int opt_build = 1;         // tile build kernel: 1 = one owned atom per lane (k_build_rows), 0 = one candidate per lane (k_build_tiles)
   int opt_force_transport = 0;   // testing: route self-swaps through the transport too (RCCL loop-back on one GPU)
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
   int opt_check_exchange = 0;                     // --check_exchange: warn when an atom moved further than a sub-domain
@@ -184,6 +185,7 @@ struct mmd_handle {
   // ---- Integrate
   real dt = 0, dtforce = 0;
   int neigh_every = 20, sort_every = 20;
+  int next_sort = -1;        // global step number of the next Atom::sort (persists across mmd_integrate_run slices)
   // ---- reductions
   DevArr<double> partials;   // per-block partial sums
   double* h_result = nullptr;  // pinned host: [0..7]
@@ -194,7 +196,7 @@ struct mmd_handle {
   double timer[5] = {0, 0, 0, 0, 0};
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
-  double force_ms = 0;
+  double force_ms = 0, comm_ms = 0;
   int force_launches = 0;
   bool time_force_events = true;
   // ---- options

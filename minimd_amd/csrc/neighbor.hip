@@ -638,6 +638,300 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Tile build, one OWNED ATOM PER LANE (production): a single wavefront builds the rows of one tile.
+//   phase 1 (cull)  the candidates of the surrounding blocks are streamed through registers in batches (coalesced,
+//                   transposed: lane l looks at candidate c*64+l); those within the cutoff of the tile's bounding box
+//                   survive and are appended, in candidate order (ballot/mbcnt), to a small LDS buffer of positions and
+//                   to tile_cand[] — the survivors ARE the tile's candidate union, their running number is the slot;
+//   phase 2 (test)  whenever the buffer fills, every lane tests ITS atom against each buffered candidate (position
+//                   broadcast from LDS, 8 candidates per 6 ds_read_b128): the v_cmp mask of a test is shifted into a
+//                   per-lane bit word with ONE v_addc_co_u32 — no ballot/mbcnt/append per test;
+//   expansion       after 32 candidates the set bits of a lane become row entries (16-bit LDS offsets of the slots),
+//                   written straight to the lane's column of nl16.
+// Nothing is shared between wavefronts: no barriers, ~8 KB of LDS, < 100 VGPRs.
+// Double precision (PF): the buffered positions are FLOATS relative to the tile's corner and phase 2 is a conservative
+// float pre-test with two thresholds (cutneighsq -/+ eps, eps = 4x the worst-case float error of rsq): below the lower
+// one a pair is a hit, above the upper one it is not; the ~0.1 pairs per tile in between are re-tested exactly
+// (double, unfused, `rsq <= cutneighsq` as ref/neighbor.cpp:165,179) from the global positions — rows are bit-identical
+// to an all-double build at half the VALU cycles and a third of the LDS. Single precision tests exactly in float.
+// MODE as in k_build. Half modes: candidates no tile atom may keep (owned j <= the tile's smallest atom index; mirrored
+// ghost-newton images) are dropped in the cull, so a half list's union is about half a full list's.
+// ---------------------------------------------------------------------------------------------------
+#define NB2_BATCH 4            // chunks of 64 candidates in flight per batch of loads
+#define NB2_BUF 448            // LDS candidate buffer (slots); flushed between batches when fewer than 64*NB2_BATCH are free
+#define NB2_LEX 0x40000000     // MODE 2: candidate is an unshifted ghost (another rank's atom): (z,y,x) order decides
+#define NB2_PF (MMD_PRECISION == 2)
+
+// bits = (bits << 1) | (my bit of m): one VALU instruction (carry-in = the compare mask)
+__device__ __forceinline__ unsigned nb2_shift_in(unsigned bits, unsigned long long m)
+{
+  unsigned long long carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits), "=s"(carry_out) : "s"(m));
+  return bits;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, const int* __restrict__ binned,
+                                                   const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
+                                                   BinGeom g, int ntiles, int nlocal, int nall, real cutneigh, real cutneighsq, int maxneighs, int cstride,
+                                                   const int* __restrict__ tile_block, const int* __restrict__ tile_first,
+                                                   const int* __restrict__ tile_cnt, int* __restrict__ numneigh,
+                                                   unsigned short* __restrict__ nl16, int* __restrict__ tile_cand,
+                                                   int* __restrict__ tile_ncand, int* __restrict__ tile_max, int* __restrict__ tile_ghost,
+                                                   unsigned short* __restrict__ tile_self, int* __restrict__ flags,
+                                                   unsigned long long* __restrict__ total_out)
+{
+  __shared__ int rng_start[128], rng_pref[130];
+  __shared__ __align__(16) float s_x[NB2_BUF], s_y[NB2_BUF], s_z[NB2_BUF];      // (PF: relative to the tile's corner)
+  __shared__ int s_cj[MODE != 0 ? NB2_BUF : 8];
+  __shared__ unsigned short s_self[64];
+  const int lane = threadIdx.x;
+  const int tile = xcd_work_item(ntiles);
+  if(tile < 0) return;
+  const int b = tile_block[tile];
+  const int ta = tile_first[tile], tcn = tile_cnt[tile];
+  const int a0 = bin_start[b * 8];
+  const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
+  // ---- candidate slices: for every (dz,dy) one contiguous run of blocks [bx-R, bx+R] in binned[]
+  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
+  const int nr = min(ny * nz, 128);
+  int carry = 0;
+  for(int r0 = 0; r0 < nr; r0 += 64) {
+    const int r = r0 + lane;
+    int len = 0, start = 0;
+    if(r < nr) {
+      const int z = bz + r / ny - g.reach[2], y = by + r % ny - g.reach[1];
+      if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
+        const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
+        const int row = (z * g.nblk[1] + y) * g.nblk[0];
+        start = bin_start[(row + x0) * 8];
+        len = bin_start[(row + x1) * 8 + 8] - start;
+      }
+    }
+    const int incl = wave_incl_scan(len);
+    if(r < nr) { rng_start[r] = start; rng_pref[r] = carry + incl - len; }
+    carry += __shfl(incl, 63, 64);
+  }
+  if(lane == 0) rng_pref[nr] = carry;
+  s_self[lane] = (unsigned short)0xffff;
+  __syncthreads();
+  const int total = __builtin_amdgcn_readfirstlane(rng_pref[nr]);
+  const int rc = g.reach[2] * ny + g.reach[1];                   // the block's own (y,z) row
+  const int selfbase = __builtin_amdgcn_readfirstlane((rc < nr ? rng_pref[rc] + (a0 - rng_start[rc]) : -(1 << 30)) + (ta - a0));   // sequence position of tile atom 0
+  // ---- my atom
+  const int ii = lane < tcn ? binned[ta + lane] : -1;
+  const bool owned = ii >= 0 && ii < nlocal;
+  const real4 pme = x[ii >= 0 ? ii : 0];
+  const unsigned long long own_mask = __builtin_amdgcn_ballot_w64(owned);
+  unsigned short* __restrict__ rowp = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  const size_t cbase = (size_t)tile * cstride;
+  if(own_mask == 0ull) {                                         // (second tile of a block that holds only ghosts)
+    if(lane == 0) { tile_max[tile] = 0; tile_ncand[tile] = 0; tile_cand[cbase] = nall; tile_ghost[tile] = 0; }
+    if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = (unsigned short)0xffff;
+    return;
+  }
+  // bounding box of the tile's owned atoms (float, conservative through the margin of `cull`)
+  const unsigned kx = float_key((float)pme.x), ky = float_key((float)pme.y), kz = float_key((float)pme.z);
+  const float bx0 = key_float(wave_min_u(owned ? kx : 0xffffffffu)), bx1 = key_float(wave_max_u(owned ? kx : 0u));
+  const float by0 = key_float(wave_min_u(owned ? ky : 0xffffffffu)), by1 = key_float(wave_max_u(owned ? ky : 0u));
+  const float bz0 = key_float(wave_min_u(owned ? kz : 0xffffffffu)), bz1 = key_float(wave_max_u(owned ? kz : 0u));
+  const float cull = (float)cutneighsq * 1.001f + 1.0e-4f;
+  const int imin = (int)wave_min_u(owned ? (unsigned)ii : 0x7fffffffu);
+  // PF: local origin = the box's lower corner (exact in `real`); |local coordinate| of my atom and of every candidate that
+  // survives the cull is <= Lmax, which bounds the float error of the pre-test's rsq
+  const real ox = NB2_PF ? (real)bx0 : (real)0, oy = NB2_PF ? (real)by0 : (real)0, oz = NB2_PF ? (real)bz0 : (real)0;
+  const float Lmax = fmaxf(fmaxf(bx1 - bx0, by1 - by0), bz1 - bz0) + 1.01f * (float)cutneigh + 0.01f;
+  const float eps = 4.76837158e-07f /* 2^-21 */ * (3.0f * (float)cutneigh * Lmax + (float)cutneighsq);
+  const float cut_lo = (float)cutneighsq - eps, cut_hi = (float)cutneighsq + eps;
+  // lanes without an owned atom sit far away on the other side of the padding candidates: never a hit
+  const float fxi = owned ? (float)(pme.x - ox) : -1.0e15f, fyi = owned ? (float)(pme.y - oy) : -1.0e15f, fzi = owned ? (float)(pme.z - oz) : -1.0e15f;
+  // branch-free slice addressing (<= NB_FASTR slices): sequence position t lives at binned[t + D(slice of t)]
+  int pq[NB_FASTR], dq[NB_FASTR];
+#pragma unroll
+  for(int q = 0; q < NB_FASTR; q++) {
+    const int d_here = q < nr ? rng_start[q] - rng_pref[q] : 0;
+    const int d_prev = (q > 0 && q < nr) ? rng_start[q - 1] - rng_pref[q - 1] : 0;
+    pq[q] = __builtin_amdgcn_readfirstlane(q < nr ? rng_pref[q] : 0x7fffffff);
+    dq[q] = __builtin_amdgcn_readfirstlane(q < nr ? d_here - d_prev : 0);
+  }
+  const bool fast = nr <= NB_FASTR;
+
+  int S = 0, fill = 0;                     // survivors flushed so far / waiting in the buffer (wave-uniform)
+  int n = 0;                               // my row length
+  bool any_ghost = false;
+
+  // ---- phase 2 + expansion over the buffered candidates
+  auto flush = [&]() {
+    const int fill8 = (fill + 7) & ~7;
+    if(lane < fill8 - fill) {
+      s_x[fill + lane] = 1.0e15f; s_y[fill + lane] = 1.0e15f; s_z[fill + lane] = 1.0e15f;
+      if(MODE != 0) s_cj[fill + lane] = -1;
+    }
+    __syncthreads();
+    const unsigned myslot = s_self[lane];
+    for(int gq = 0; gq < fill8; gq += 32) {
+      const int G = min(32, fill8 - gq);
+      unsigned bits = 0, bits_hi = 0;
+      for(int q = 0; q < G; q += 8) {
+        float cx[8], cy[8], cz[8];
+        const float4* vx = (const float4*)&s_x[gq + q];
+        const float4* vy = (const float4*)&s_y[gq + q];
+        const float4* vz = (const float4*)&s_z[gq + q];
+#pragma unroll
+        for(int u = 0; u < 2; u++) {
+          const float4 tx = vx[u], ty = vy[u], tz = vz[u];
+          cx[4 * u] = tx.x; cx[4 * u + 1] = tx.y; cx[4 * u + 2] = tx.z; cx[4 * u + 3] = tx.w;
+          cy[4 * u] = ty.x; cy[4 * u + 1] = ty.y; cy[4 * u + 2] = ty.z; cy[4 * u + 3] = ty.w;
+          cz[4 * u] = tz.x; cz[4 * u + 1] = tz.y; cz[4 * u + 2] = tz.z; cz[4 * u + 3] = tz.w;
+        }
+#pragma unroll
+        for(int u = 0; u < 8; u++) {
+          const float dx = fxi - cx[u], dy = fyi - cy[u], dz = fzi - cz[u];
+          unsigned long long m, mh = 0;
+          if(NB2_PF) {
+            const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            m = __builtin_amdgcn_fcmpf(rsq, cut_lo, 5 /* ordered <= */);
+            mh = __builtin_amdgcn_fcmpf(rsq, cut_hi, 5);
+          } else {
+            const float rsq = dx * dx + dy * dy + dz * dz;        // (no contraction in this file: rounds like the reference)
+            m = __builtin_amdgcn_fcmpf(rsq, (float)cutneighsq, 5 /* ordered <= : ref/neighbor.cpp:165,179 */);
+          }
+          if(MODE != 0) {
+            const int cju = __builtin_amdgcn_readfirstlane(s_cj[gq + q + u]);
+            unsigned long long rule;
+            if(MODE == 2 && (cju & NB2_LEX)) {
+              // (z,y,x) order on the exact positions (ref/neighbor.cpp:155-157)
+              const real4 pj = x[cju & ~NB2_LEX];
+              rule = __builtin_amdgcn_ballot_w64(owned && !(pj.z < pme.z || (pj.z == pme.z && pj.y < pme.y) || (pj.z == pme.z && pj.y == pme.y && pj.x < pme.x)));
+            } else
+              rule = __builtin_amdgcn_sicmp(cju, ii, 38 /* signed > */);
+            m &= rule; mh &= rule;
+          }
+          bits = nb2_shift_in(bits, m);
+          if(NB2_PF) bits_hi = nb2_shift_in(bits_hi, mh);
+        }
+      }
+      // pass q of the group sits at bit G-1-q
+      if(NB2_PF) {
+        unsigned amb = bits_hi & ~bits;                            // between the thresholds: decide exactly
+        if(__builtin_amdgcn_ballot_w64(amb != 0u) != 0ull) {
+          while(amb) {
+            const int q = __builtin_ctz(amb);
+            amb &= amb - 1;
+            const int slot = S + gq + (G - 1 - q);
+            const real4 pj = x[tile_cand[cbase + slot]];
+            const real dx = pme.x - pj.x, dy = pme.y - pj.y, dz = pme.z - pj.z;
+            const real rsq = dx * dx + dy * dy + dz * dz;
+            if(rsq <= cutneighsq) bits |= 1u << q;
+          }
+        }
+      }
+      unsigned bb = bits;
+      while(bb) {
+        const int q = __builtin_ctz(bb);
+        bb &= bb - 1;
+        const unsigned slot = (unsigned)(S + gq + (G - 1 - q));
+        if(MODE != 0 || slot != myslot) {                        // full lists: the atom itself (rsq = 0) is a hit; dropped here
+          if(n < maxneighs) rowp[(unsigned)n * 64u] = (unsigned short)(slot * NB_SLOT_BYTES);
+          n++;
+        }
+      }
+    }
+    __syncthreads();
+    S += fill;
+    fill = 0;
+  };
+
+  // ---- phase 1: stream the candidates
+  const int nchunks = (total + 63) >> 6;
+  for(int c0 = 0; c0 < nchunks; c0 += NB2_BATCH) {
+    int jj[NB2_BATCH];
+    if(fast) {
+#pragma unroll
+      for(int u = 0; u < NB2_BATCH; u++) {
+        const int gt = (c0 + u) * 64 + lane;
+        int addr = gt;
+#pragma unroll
+        for(int q = 0; q < NB_FASTR; q++) addr += gt >= pq[q] ? dq[q] : 0;
+        jj[u] = gt < total ? binned[addr] : -1;
+      }
+    } else {
+      int r = 0;
+#pragma unroll
+      for(int u = 0; u < NB2_BATCH; u++) {
+        const int gt = (c0 + u) * 64 + lane;
+        jj[u] = -1;
+        if(gt < total) {
+          while(r + 1 < nr && rng_pref[r + 1] <= gt) r++;
+          jj[u] = binned[rng_start[r] + (gt - rng_pref[r])];
+        }
+      }
+    }
+    real4 pp[NB2_BATCH];
+    int code[NB2_BATCH];
+#pragma unroll
+    for(int u = 0; u < NB2_BATCH; u++) {
+      pp[u] = x[jj[u] >= 0 ? jj[u] : 0];
+      if(MODE == 2) code[u] = jj[u] >= nlocal ? ghost_image[jj[u] - nlocal] : 62;    // (sx+2) + 5*(sy+2) + 25*(sz+2), 62 = unshifted
+    }
+#pragma unroll
+    for(int u = 0; u < NB2_BATCH; u++) {
+      if(c0 + u < nchunks) {
+        const int j = jj[u];
+        bool keep = j >= 0;
+        int cjv = j;
+        if(MODE != 0) keep = keep && (j >= nlocal || j > imin);            // an owned j <= every tile atom is nobody's j > i
+        if(MODE == 2 && j >= nlocal) {
+          const int sx = code[u] % 5 - 2, sy = (code[u] / 5) % 5 - 2, sz = code[u] / 25 - 2;
+          if(sx == 0 && sy == 0 && sz == 0) cjv = j | NB2_LEX;
+          else if(!(sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0))))) keep = false;    // the mirrored pair keeps it
+        }
+        const float fx = (float)pp[u].x, fy = (float)pp[u].y, fz = (float)pp[u].z;
+        const float ddx = fmaxf(fmaxf(bx0 - fx, fx - bx1), 0.0f);
+        const float ddy = fmaxf(fmaxf(by0 - fy, fy - by1), 0.0f);
+        const float ddz = fmaxf(fmaxf(bz0 - fz, fz - bz1), 0.0f);
+        keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if(m) {
+          const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+          if(keep) {
+            s_x[pos] = (float)(pp[u].x - ox); s_y[pos] = (float)(pp[u].y - oy); s_z[pos] = (float)(pp[u].z - oz);
+            if(MODE != 0) s_cj[pos] = cjv;
+            if(S + pos < cstride - 1) tile_cand[cbase + S + pos] = j;
+            const unsigned own = (unsigned)((c0 + u) * 64 + lane - selfbase);
+            if(own < 64u) s_self[own] = (unsigned short)(S + pos);
+          }
+          any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(keep && j >= nlocal) != 0ull;
+          fill += __popcll(m);
+        }
+      }
+    }
+    if(fill > NB2_BUF - 64 * NB2_BATCH || c0 + NB2_BATCH >= nchunks) flush();     // (one copy of the test code: flushed between batches only)
+  }
+
+  // ---- rows are complete: pad them with the dummy slot (= S, staged by the force kernels behind the candidates)
+  const int maxn = wave_max_i(n);
+  int kmax = (maxn + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD;
+  if(kmax > maxneighs) kmax = maxneighs;
+  const unsigned short dummy = (unsigned short)(S * NB_SLOT_BYTES);
+  const int nmin = min(-wave_max_i(-n), kmax);
+  for(int k = nmin; k < kmax; k++) if(k >= n) rowp[(unsigned)k * 64u] = dummy;
+  if(owned) numneigh[ii] = n;
+  if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = owned ? s_self[lane] : (unsigned short)0xffff;
+  const long long tsum = wave_sum((long long)n);
+  if(lane == 0) {
+    tile_max[tile] = kmax;
+    tile_ncand[tile] = S;
+    tile_cand[cbase + min(S, cstride - 1)] = nall;          // the dummy atom closes the list
+    tile_ghost[tile] = any_ghost ? 1 : 0;
+    atomicMax(&flags[0], maxn);
+    atomicMax(&flags[2], S);
+    if(S > cstride - 2 || (S + 1) * NB_SLOT_BYTES > 65535) atomicMax(&flags[3], 1);   // union does not fit the 16-bit slot offsets
+    atomicAdd(total_out, (unsigned long long)tsum);
+  }
+}
+
 // reference-style rows from the tile form: neigh[((i>>6)*maxneighs + k)*64 + (i&63)] = tile_cand[slot]
 __global__ __launch_bounds__(64) void k_tiles_to_rows(int nlocal, int maxneighs, int cstride, const int* __restrict__ binned,
                                                       const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
@@ -756,7 +1050,20 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
                      h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p, h->tile_max.p, h->tile_ghost.p,      \
                      h->tile_self.p,                                                                                                     \
                      h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate)
-      if(tmode == 0) LAUNCH_TILES(0); else if(tmode == 1) LAUNCH_TILES(1); else LAUNCH_TILES(2);
+#define LAUNCH_ROWS(M)                                                                                                                  \
+  hipLaunchKernelGGL(k_build_rows<M>, dim3(xcd_grid(h->ntiles)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,           \
+                     h->ghost_image.p, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
+                     h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
+                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->d_flags, (unsigned long long*)h->d_result)
+      if(h->opt_build == 1) {             // one owned atom per lane (production)
+        if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
+      } else if(lds > 64 * 1024) {        // the candidate-per-lane form keeps maxneighs x 64 raw slots in LDS
+        want_tiles = false;
+        break;
+      } else {
+        if(tmode == 0) LAUNCH_TILES(0); else if(tmode == 1) LAUNCH_TILES(1); else LAUNCH_TILES(2);
+      }
+#undef LAUNCH_ROWS
 #undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -99,7 +99,15 @@ def ref_runs(big):
         ("lj_s32_full_n100_sp", "sp", ["-i", "in.lj.miniMD", "-s", "32", "-n", "100", "--half_neigh", "0", "-t", "8"]),
         ("lj_s32_half_n100_sp", "sp", ["-i", "in.lj.miniMD", "-s", "32", "-n", "100", "--half_neigh", "1", "-t", "8"]),
         ("lj_s10_full_n1000_sp", "sp", ["-i", "in.lj.miniMD", "-s", "10", "-n", "1000", "--half_neigh", "0"]),
+        # boxes thinner than the neighbor cutoff: need = 2 ghost layers per dimension (ref/comm.cpp:150-152), chained self swaps
+        ("lj_s1_full_n60", "dp", ["-i", "in.lj.miniMD", "-s", "1", "-n", "60", "--half_neigh", "0"]),
+        ("lj_1x3x2_half_n60", "dp", ["-i", "in.lj.miniMD", "-nx", "1", "-ny", "3", "-nz", "2", "-n", "60", "--half_neigh", "1"]),
+        ("lj_1x3x2_full_n60", "dp", ["-i", "in.lj.miniMD", "-nx", "1", "-ny", "3", "-nz", "2", "-n", "60", "--half_neigh", "0"]),
+        ("eam_2x1x3_full_n60", "dp", ["-i", "in.eam.miniMD", "-nx", "2", "-ny", "1", "-nz", "3", "-n", "60", "--half_neigh", "0"]),
     ]
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    if only:
+        cases = [c for c in cases if c[0] in only[0]]
     if big:
         cases += [
             ("lj_s80_full_n100", "dp", ["-i", "in.lj.miniMD", "-s", "80", "-n", "100", "--half_neigh", "0", "-t", "8"]),
@@ -178,12 +186,15 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("this script needs /root/reference (build container only)")
     subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "ref"], check=True, stdout=subprocess.DEVNULL)
-    json.dump(published_logs(), open(os.path.join(HERE, "reference_output.json"), "w"), indent=0)
+    partial = any(a.startswith("--only=") for a in sys.argv)       # --only=name,name: add / refresh just those ref_runs entries
+    if not partial:
+        json.dump(published_logs(), open(os.path.join(HERE, "reference_output.json"), "w"), indent=0)
     path = os.path.join(HERE, "ref_runs.json")
     old = json.load(open(path)) if os.path.exists(path) else {}
     old.update(ref_runs(big))
     json.dump(old, open(path, "w"), indent=0)
-    array_fixtures()
+    if not partial:
+        array_fixtures()
 
 
 if __name__ == "__main__":

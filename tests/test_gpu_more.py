@@ -301,6 +301,89 @@ def test_baseline_eam_s64():
     s.close()
 
 
+def test_config_e_full_size_sp_half_lists():
+    """BASELINE configs[4] at its real size: -s 160 (16 384 000 atoms), single precision, half neighbor lists with the
+    third-law scatter, 100 steps. No SP row of the reference is pinned at this size (its float sums have lost their digits,
+    DESIGN.md §6), so the run is judged by size-independent properties and against the DP half-list run of the same box:
+    atoms conserved with unique tags, total force ~ 0, the initial lists hold exactly the pairs the DP build finds,
+    rows within the reference's SP pass rule of the DP rows, and U at step 100 = -5.65 (liquid at this state point)."""
+    natoms = 4 * 160 ** 3
+    out = {}
+    for prec in ("dp", "sp"):
+        s = mm().Sim(["-s", 160, "-n", 100, "--half_neigh", 1], precision=prec)
+        s.initial()
+        tot0 = s.handle.neighbor_info()["total"]
+        s.run()
+        nl, ng, _ = s.handle.counts()
+        assert nl == natoms == s.natoms()
+        tot = s.handle.neighbor_info()["total"]
+        if prec == "sp":
+            d = s.handle.download(halfneigh=True)
+            assert len(np.unique(d["tag"])) == natoms
+            f = d["f"][:nl].astype(np.float64)
+            assert np.abs(f.sum(axis=0)).max() <= 2e-6 * np.abs(f).max() * np.sqrt(nl)       # Newton's third law, float sums
+            x = d["x"][:nl]
+            prd = s.handle.get_box()[0]
+            assert (x.min(axis=0) >= -0.6).all() and (x.max(axis=0) <= prd + 0.6).all()       # within a skin of the box between exchanges
+            del d, f, x
+        out[prec] = (s.rows(), tot0, tot, ng)
+        s.close()
+    assert out["sp"][1] == out["dp"][1]                       # the lattice has no pair within float rounding of the cutoff
+    assert abs(out["sp"][2] - out["dp"][2]) <= 2e-5 * out["dp"][2] and abs(out["sp"][3] - out["dp"][3]) <= 2e-4 * out["dp"][3]
+    assert [r[0] for r in out["sp"][0]] == [0, 100]
+    assert ref_pass_rule(out["dp"][0], out["sp"][0], natoms, 4)[0]
+    t, u, p = out["sp"][0][-1][1:]
+    assert abs(u - (-5.652)) < 2e-3 and abs(t - 0.695) < 2e-3
+    # DP rows at this size against the exact lattice values of step 0 (1.44 / -6.773368 / -5.01967)
+    t0, u0, p0 = out["dp"][0][0][1:]
+    assert fmt7(t0) == fmt7(1.44) and fmt7(u0) == fmt7(-6.773368) and abs(p0 - (-5.01967)) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["lj_s1_full_n60", "lj_1x3x2_half_n60", "lj_1x3x2_full_n60", "eam_2x1x3_full_n60"])
+def test_two_ghost_layers_one_rank(name):
+    """boxes thinner than the neighbor cutoff need TWO ghost layers per dimension (need = 2, ref/comm.cpp:150-152,208-269):
+    4 swaps per dimension, images of images, ghost chains of length 2 in the one-kernel halo. Rows equal the
+    unmodified reference's, ghost / neighbor counts equal its YAML report."""
+    ent = REFRUNS[name]
+    s = mm().Sim([a for a in ent["args"]], cwd=os.path.join(REPO, "data"))
+    assert max(s.handle.comm_info()["need"]) == 2
+    s.initial(); s.run()
+    rows_close(s.rows(), ent["rows"], 2e-6)
+    nl, ng, _ = s.handle.counts()
+    assert (nl, ng) == (int(ent["nlocal"]), int(ent["nghost"]))
+    assert s.handle.neighbor_info()["total"] == int(ent["neigh_total"])
+    s.close()
+
+
+@pytest.mark.parametrize("size,nprocs,half,port", [(["-s", "3"], 2, 0, 29671), (["-nx", "3", "-ny", "3", "-nz", "8"], 4, 1, 29672),
+                                                   (["-nx", "4", "-ny", "3", "-nz", "3"], 3, 0, 29673)])
+def test_two_ghost_layers_several_ranks(size, nprocs, half, port, tmp_path):
+    """sub-domains thinner than the cutoff on several ranks (sharing this GPU, gloo host transport): a rank's ghosts come
+    from its neighbor AND from the rank beyond it (second swap pair of the dimension, ref/comm.cpp:208-269). Rows equal the
+    one-rank run to summation order; owned / ghost counts per rank equal the oracle's virtual ranks."""
+    args = size + ["-n", "60", "--half_neigh", str(half)]
+    base = sim_rows(args)
+    out = str(tmp_path / "mp.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nprocs), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "sim", out, "dp"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert sum(c[0] for c in res["counts"]) == res["natoms"]
+    rows = [tuple(x) for x in res["rows"]]
+    assert [r_[0] for r_ in rows] == [b[0] for b in base]
+    for a, b in zip(rows, base):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+    o = Oracle(args, nprocs=nprocs)
+    o.initial(); o.run()
+    assert o.nswap(0) > 6                                   # more than one swap pair in some dimension
+    assert [o.nlocal(r_) for r_ in range(nprocs)] == [c[0] for c in res["counts"]]
+    assert [o.nghost(r_) for r_ in range(nprocs)] == [c[1] for c in res["counts"]]
+    o.close()
+
+
 def test_config_e_sp_half_scaled_down():
     """BASELINE configs[4] (-s 160 SP half lists) at -s 48: runs, conserves atoms, passes the SP rule vs the DP run"""
     ref = sim_rows(["-s", 48, "-n", 100, "--half_neigh", 0])

@@ -72,7 +72,9 @@ def test_published_step0_rows_all_sizes():
 # ---- (b) rows printed by the reference built here ----------------------------------------------
 
 SMALL_REF_CASES = ["lj_s10_full_n1000", "lj_s10_half_gn1_n1000", "lj_s10_half_gn0_n1000", "lj_s16_full_n300",
-                   "lj_nx12_ny8_nz10_full_n200", "eam_s10_full_n1000", "eam_s10_half_n300", "lj_s10_full_n1000_sp"]
+                   "lj_nx12_ny8_nz10_full_n200", "eam_s10_full_n1000", "eam_s10_half_n300", "lj_s10_full_n1000_sp",
+                   # boxes thinner than the neighbor cutoff: two ghost layers per dimension (need = 2, ref/comm.cpp:150-152)
+                   "lj_s1_full_n60", "lj_1x3x2_half_n60", "lj_1x3x2_full_n60", "eam_2x1x3_full_n60"]
 
 
 @pytest.mark.parametrize("name", SMALL_REF_CASES)
@@ -80,6 +82,16 @@ def test_rows_equal_reference_binary(name):
     ent = REFRUNS[name]
     rows = run_oracle(ent["args"], precision=ent["precision"])
     assert rows_as_text(rows) == rows_as_text(ent["rows"])
+
+
+@pytest.mark.parametrize("name", ["lj_s1_full_n60", "lj_1x3x2_half_n60", "lj_1x3x2_full_n60", "eam_2x1x3_full_n60"])
+def test_two_ghost_layers_counts_equal_reference(name):
+    """need = 2: ghost and neighbor counts of the reference's YAML report"""
+    ent = REFRUNS[name]
+    o = Oracle(ent["args"])
+    o.initial(); o.run()
+    assert o.nghost() == int(ent["nghost"]) and int(o.numneigh().sum()) == int(ent["neigh_total"])
+    o.close()
 
 
 @pytest.mark.parametrize("name", ["lj_s32_full_n20", "lj_s20_full_n200"])

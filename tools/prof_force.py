@@ -36,6 +36,15 @@ if a.ab:
         for v in (1, 0):
             h.set_option(a.ab, v)
             print("round %d  %s=%d  force %.4f ms" % (rnd, a.ab, v, h.profile_kernel(0, a.reps)))
+if os.environ.get("BUILDKERNELS"):
+    # A/B of the two tile-build kernels (build=1: one owned atom per lane, build=0: one candidate per lane)
+    for rnd in range(2):
+        for v in (0, 1):
+            h.set_option("build", v)
+            h.neighbor_build()
+            print("round %d  build=%d  neighbor build %.4f ms   tile stats %s  total %d" % (
+                rnd, v, h.profile_kernel(1, 12), h.neighbor_tile_stats(), h.neighbor_info()["total"]))
+    print("force after build=1: %.4f ms" % h.profile_kernel(0, a.reps))
 if os.environ.get("BUILDAB"):
     for ab in (0, 1, 8, 9, 13, 16):
         h.set_option("ablate", ab)
