@@ -177,11 +177,13 @@ class Handle:
         nl, ng, _ = self.counts()
         x = np.zeros((nl + ng, 3), self.real)
         v = np.zeros((nl, 3), self.real)
-        f = np.zeros(((nl + ng) if halfneigh else nl, 3), self.real)
+        # the library writes nlocal rows of f for a full-list handle and nlocal+nghost rows for a half-list one
+        # (include/mmd.h): the buffer always has room for the larger; `halfneigh` only selects what is returned
+        f = np.zeros((nl + ng, 3), self.real)
         t = np.zeros(nl + ng, np.int32)
         tag = np.zeros(nl, np.int32)
         self._chk(self.L.mmd_atom_download(self.h, self._rp(x), self._rp(v), self._rp(f), self._ip(t), self._ip(tag)))
-        return {"x": x, "v": v, "f": f, "type": t, "tag": tag, "nlocal": nl, "nghost": ng}
+        return {"x": x, "v": v, "f": f if halfneigh else f[:nl], "type": t, "tag": tag, "nlocal": nl, "nghost": ng}
 
     def upload_f(self, f):
         f = self._r(f).reshape(-1, 3)

@@ -85,6 +85,15 @@ __device__ __forceinline__ unsigned wave_max_u(unsigned v)
 #undef MMD_UMAX
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// bitwise OR over the 64 lanes (same DPP ladder; identity 0)
+__device__ __forceinline__ unsigned wave_or_u(unsigned v)
+{
+#define MMD_UOR(a, b) ((a) | (b))
+  MMD_DPP_STEP_U(MMD_UOR, 0u, 0x111, 0xf); MMD_DPP_STEP_U(MMD_UOR, 0u, 0x112, 0xf); MMD_DPP_STEP_U(MMD_UOR, 0u, 0x114, 0xf);
+  MMD_DPP_STEP_U(MMD_UOR, 0u, 0x118, 0xf); MMD_DPP_STEP_U(MMD_UOR, 0u, 0x142, 0xa); MMD_DPP_STEP_U(MMD_UOR, 0u, 0x143, 0xc);
+#undef MMD_UOR
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // inclusive prefix sum over a wavefront
 __device__ __forceinline__ int wave_incl_scan(int v)
 {

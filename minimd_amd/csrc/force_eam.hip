@@ -180,6 +180,199 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_eam_force(const real4* __restrict
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Half neighbor lists: ForceEAM::compute_halfneigh (ref/force_eam.cpp:94-270). Every stored pair (i, j) is visited once:
+//   sweep 1  k_eam_half_density : rho_i += rho(r) in registers, rho_j += rho(r) by atomic when j is owned (:152-156)
+//   embed    k_eam_half_fp      : fp_i = F'(rho_i), [EV] E_embed                                        (:165-179)
+//   halo     fp of owned atoms -> ghosts
+//   sweep 2  k_eam_half_force   : f_i += pair force in registers, f_j -= by atomics when j is owned; a ghost partner gets no
+//                                 force and the pair counts half in energy and virial              (:244-257)
+// The list is the reference's half list without ghost newton (owned j > i, every ghost). rho and f are zeroed beforehand
+// (f over owned + ghost atoms like :112-116). Floating-point atomics make the summation order run-dependent.
+// ---------------------------------------------------------------------------------------------------
+template <int UNIFORM>
+__global__ __launch_bounds__(MMD_BLOCK) void k_eam_half_density(const real4* __restrict__ x, const int* __restrict__ neigh,
+                                                                const int* __restrict__ wave_max, int nlocal, int maxneighs,
+                                                                const real* __restrict__ rhor_spline, const real* __restrict__ cutforcesq,
+                                                                int ntypes, int nr, int nr_tot, real rdr, real* __restrict__ rho)
+{
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  real* s_tab = (real*)s_raw;                           // [knot][4] : coeffs 3..6 of rhor_spline (UNIFORM only)
+  if(UNIFORM) {
+    for(int t = threadIdx.x; t < (nr + 1) * 4; t += blockDim.x) s_tab[t] = rhor_spline[(t >> 2) * 7 + 3 + (t & 3)];
+    __syncthreads();
+  }
+  const int wg = xcd_work_item((nlocal + MMD_BLOCK - 1) / MMD_BLOCK);
+  if(wg < 0) return;
+  const int i = wg * MMD_BLOCK + threadIdx.x;
+  const int w = i >> 6, lane = threadIdx.x & 63;
+  const bool owned = i < nlocal;
+  const real4 xi = x[owned ? i : nlocal - 1];
+  const int ti = (int)xi.w;
+  const int nwaves = (nlocal + 63) >> 6;
+  const int kmax = w < nwaves ? __builtin_amdgcn_readfirstlane(wave_max[w]) : 0;
+  const int* __restrict__ np = neigh + ((size_t)w * maxneighs) * 64 + lane;
+  const real cut0 = cutforcesq[0];
+  real rhoi = 0;
+  for(int k = 0; k < kmax; k += EAM_UNR) {
+    int j[EAM_UNR];
+    real4 xj[EAM_UNR];
+#pragma unroll
+    for(int u = 0; u < EAM_UNR; u++) j[u] = np[(size_t)(k + u) * 64];
+#pragma unroll
+    for(int u = 0; u < EAM_UNR; u++) xj[u] = x[j[u]];
+#pragma unroll
+    for(int u = 0; u < EAM_UNR; u++) {
+      const real dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
+      const real rsq = dx * dx + dy * dy + dz * dz;
+      const int tij = UNIFORM ? 0 : ti * ntypes + (int)xj[u].w;
+      const real cut = UNIFORM ? cut0 : cutforcesq[tij];
+      if(rsq < cut) {
+        real p = sqrt(rsq) * rdr + (real)1.0;
+        int m = (int)p;
+        m = m < nr - 1 ? m : nr - 1;
+        p -= m;
+        p = p < (real)1.0 ? p : (real)1.0;
+        real c3, c4, c5, c6;
+        if(UNIFORM) { const real* c = &s_tab[m * 4]; c3 = c[0]; c4 = c[1]; c5 = c[2]; c6 = c[3]; }
+        else { const real* c = &rhor_spline[(size_t)tij * nr_tot + m * 7]; c3 = c[3]; c4 = c[4]; c5 = c[5]; c6 = c[6]; }
+        const real term = ((c3 * p + c4) * p + c5) * p + c6;
+        rhoi += term;
+        if(j[u] < nlocal) unsafeAtomicAdd(rho + j[u], term);
+      }
+    }
+  }
+  if(owned) unsafeAtomicAdd(rho + i, rhoi);
+}
+
+template <int EV>
+__global__ __launch_bounds__(MMD_BLOCK) void k_eam_half_fp(const real4* __restrict__ x, const real* __restrict__ rho, int nlocal,
+                                                           const real* __restrict__ frho_spline, int uniform, int nrho, int nrho_tot,
+                                                           real rdrho, real* __restrict__ fp, double* __restrict__ partials)
+{
+  __shared__ double s_red[16];
+  const int i = blockIdx.x * MMD_BLOCK + threadIdx.x;
+  double e_acc = 0;
+  if(i < nlocal) {
+    const int ti = (int)x[i].w;
+    const int tii = uniform ? 0 : ti * ti;                // sic (ref/force_eam.cpp:168)
+    real p = (real)1.0 * rho[i] * rdrho + (real)1.0;
+    int m = (int)p;
+    m = max(1, min(m, nrho - 1));
+    p -= m;
+    p = p < (real)1.0 ? p : (real)1.0;
+    const real* c = &frho_spline[(size_t)tii * nrho_tot + m * 7];
+    fp[i] = (c[0] * p + c[1]) * p + c[2];
+    if(EV) e_acc = (double)(((c[3] * p + c[4]) * p + c[5]) * p + c[6]);
+  }
+  if(EV) {
+    const double es = block_sum(e_acc, s_red);
+    if(threadIdx.x == 0) partials[blockIdx.x] = es;
+  }
+}
+
+template <int EV, int UNIFORM>
+__global__ __launch_bounds__(MMD_BLOCK) void k_eam_half_force(const real4* __restrict__ x, const int* __restrict__ neigh,
+                                                              const int* __restrict__ wave_max, int nlocal, int maxneighs,
+                                                              const real* __restrict__ rhor_spline, const real* __restrict__ z2r_spline,
+                                                              const real* __restrict__ cutforcesq, int ntypes, int nr, int nr_tot, real rdr,
+                                                              const real* __restrict__ fp, real* __restrict__ f, double* __restrict__ partials)
+{
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  real* s_tab = (real*)s_raw;                           // [knot][12]: rhor 0..2, z2r 0..6, pad (UNIFORM only)
+  __shared__ double s_red[16];
+  if(UNIFORM) {
+    for(int t = threadIdx.x; t < (nr + 1) * 12; t += blockDim.x) {
+      const int m = t / 12, c = t % 12;
+      s_tab[t] = c < 3 ? rhor_spline[m * 7 + c] : (c < 10 ? z2r_spline[m * 7 + (c - 3)] : (real)0);
+    }
+    __syncthreads();
+  }
+  const int wg = xcd_work_item((nlocal + MMD_BLOCK - 1) / MMD_BLOCK);
+  if(wg < 0) return;
+  const int i = wg * MMD_BLOCK + threadIdx.x;
+  const int w = i >> 6, lane = threadIdx.x & 63;
+  const bool owned = i < nlocal;
+  const real4 xi = x[owned ? i : nlocal - 1];
+  const real fpi = fp[owned ? i : nlocal - 1];
+  const int ti = (int)xi.w;
+  const int nwaves = (nlocal + 63) >> 6;
+  const int kmax = w < nwaves ? __builtin_amdgcn_readfirstlane(wave_max[w]) : 0;
+  const int* __restrict__ np = neigh + ((size_t)w * maxneighs) * 64 + lane;
+  const real cut0 = cutforcesq[0];
+  real fx = 0, fy = 0, fz = 0;
+  double e_acc = 0, v_acc = 0;
+  for(int k = 0; k < kmax; k += EAM_UNR) {
+    int j[EAM_UNR];
+    real4 xj[EAM_UNR];
+    real fpj[EAM_UNR];
+#pragma unroll
+    for(int u = 0; u < EAM_UNR; u++) j[u] = np[(size_t)(k + u) * 64];
+#pragma unroll
+    for(int u = 0; u < EAM_UNR; u++) { xj[u] = x[j[u]]; fpj[u] = fp[j[u]]; }
+#pragma unroll
+    for(int u = 0; u < EAM_UNR; u++) {
+      const real dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
+      const real rsq = dx * dx + dy * dy + dz * dz;
+      const int tij = UNIFORM ? 0 : ti * ntypes + (int)xj[u].w;
+      const real cut = UNIFORM ? cut0 : cutforcesq[tij];
+      if(rsq < cut) {
+        const real r = sqrt(rsq);
+        real p = r * rdr + (real)1.0;
+        int m = (int)p;
+        m = m < nr - 1 ? m : nr - 1;
+        p -= m;
+        p = p < (real)1.0 ? p : (real)1.0;
+        real r0, r1, r2, z0, z1, z2c, z3, z4, z5, z6;
+        if(UNIFORM) {
+          const real* c = &s_tab[m * 12];
+          r0 = c[0]; r1 = c[1]; r2 = c[2]; z0 = c[3]; z1 = c[4]; z2c = c[5]; z3 = c[6]; z4 = c[7]; z5 = c[8]; z6 = c[9];
+        } else {
+          const real* cr = &rhor_spline[(size_t)tij * nr_tot + m * 7];
+          const real* cz = &z2r_spline[(size_t)tij * nr_tot + m * 7];
+          r0 = cr[0]; r1 = cr[1]; r2 = cr[2]; z0 = cz[0]; z1 = cz[1]; z2c = cz[2]; z3 = cz[3]; z4 = cz[4]; z5 = cz[5]; z6 = cz[6];
+        }
+        const real rhoip = (r0 * p + r1) * p + r2;
+        const real z2p = (z0 * p + z1) * p + z2c;
+        const real z2 = ((z3 * p + z4) * p + z5) * p + z6;
+        const real recip = (real)1.0 / r;
+        const real phi = z2 * recip;
+        const real phip = z2p * recip - phi * recip;
+        const real psip = fpi * rhoip + fpj[u] * rhoip + phip;
+        real fpair = -psip * recip;
+        fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
+        const bool jown = j[u] < nlocal;
+        if(jown) {
+          real* fj = f + 3 * (size_t)j[u];
+          unsafeAtomicAdd(fj + 0, -dx * fpair); unsafeAtomicAdd(fj + 1, -dy * fpair); unsafeAtomicAdd(fj + 2, -dz * fpair);
+        } else fpair *= (real)0.5;
+        if(EV) {
+          v_acc += (double)(dx * dx * fpair + dy * dy * fpair + dz * dz * fpair);
+          e_acc += (double)(jown ? phi : (real)0.5 * phi);
+        }
+      }
+    }
+  }
+  if(owned) { real* fi = f + 3 * (size_t)i; unsafeAtomicAdd(fi + 0, fx); unsafeAtomicAdd(fi + 1, fy); unsafeAtomicAdd(fi + 2, fz); }
+  if(EV) {
+    const double es = block_sum(e_acc, s_red);
+    const double vs = block_sum(v_acc, s_red);
+    if(threadIdx.x == 0) { partials[2 * (size_t)wg] = es; partials[2 * (size_t)wg + 1] = vs; }
+  }
+}
+
+// eng_vdwl = E_embed + sum phi (ref/force_eam.cpp:269), virial = sum
+__global__ __launch_bounds__(1024) void k_eam_half_sum(const double* __restrict__ embed, int nb_embed, const double* __restrict__ pair, int nb_pair,
+                                                       double* __restrict__ out)
+{
+  __shared__ double s_red[16];
+  double a = 0, b = 0, c = 0;
+  for(int k = threadIdx.x; k < nb_embed; k += blockDim.x) a += embed[k];
+  for(int k = threadIdx.x; k < nb_pair; k += blockDim.x) { b += pair[2 * (size_t)k]; c += pair[2 * (size_t)k + 1]; }
+  const double ta = block_sum(a, s_red), tb = block_sum(b, s_red), tc = block_sum(c, s_red);
+  if(threadIdx.x == 0) { out[0] = ta + tb; out[1] = tc; }
+}
+
 // 1/sqrt(a) for a in the pair range (0.1 .. 100): v_rsq + one Newton step with the second-order term
 // (y(1 + e/2 + 3e^2/8), e = 1 - a y^2) => ~1 ulp, instead of the ~25-instruction IEEE sqrt and the ~13-instruction
 // IEEE divide the compiler expands sqrt(rsq) and 1.0/r into; r = a * rsqrt(a).
@@ -520,10 +713,51 @@ int mmd_eam_can_fuse_integrate(mmd_handle* h) { return eam_tiles_available(h) ? 
 int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 {
   if(h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_force_compute: neighbor list is stale (build or upload one first)"); return -1; }
-  if(h->halfneigh) { mmd_set_error("EAM with half neighbor lists is not implemented on the device yet (use --half_neigh 0)"); return -1; }
+  if(h->halfneigh && h->ghost_newton) { mmd_set_error("EAM needs half lists WITHOUT ghost newton (ref/ljs.cpp:219-223 forces -gn 0)"); return -1; }
   const int nlocal = h->nlocal, nall = nlocal + h->nghost;
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
+  if(h->halfneigh) {
+    // ---- ForceEAM::compute_halfneigh (ref/force_eam.cpp:94-270): third-law scatter with floating-point atomics
+    MMD_TRY(mmd_ensure_rows(h));
+    MMD_TRY(h->rho.ensure((size_t)nall + 64, false, h->stream));
+    const int nblocks = div_up(nlocal, MMD_BLOCK);
+    MMD_TRY(h->partials.ensure((size_t)3 * nblocks + 16, false, h->stream));
+    double* p_embed = h->partials.p;
+    double* p_pair = h->partials.p + nblocks + 8;
+    HIP_TRY(hipMemsetAsync(h->rho.p, 0, (size_t)nlocal * sizeof(real), h->stream));
+    MMD_TRY(mmd_zero_forces(h, nall));
+    const bool uni = h->eam_uniform, ev = evflag != 0;
+    const size_t lds1 = uni ? (size_t)(h->nr + 1) * 4 * sizeof(real) : 0;
+    const size_t lds2 = uni ? (size_t)(h->nr + 1) * 12 * sizeof(real) : 0;
+#define HD(Uv) hipLaunchKernelGGL((k_eam_half_density<Uv>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), lds1, h->stream, h->x.p, h->neigh.p, h->wave_max.p,  \
+                                  nlocal, h->maxneighs, h->rhor_spline.p, h->lj_tables.p, h->ntypes, h->nr, h->nr_tot, h->rdr, h->rho.p)
+#define HP(EVv) hipLaunchKernelGGL((k_eam_half_fp<EVv>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p,         \
+                                   uni ? 1 : 0, h->nrho, h->nrho_tot, h->rdrho, h->fp.p, p_embed)
+#define HF(EVv, Uv) hipLaunchKernelGGL((k_eam_half_force<EVv, Uv>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), lds2, h->stream, h->x.p, h->neigh.p,           \
+                                       h->wave_max.p, nlocal, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->lj_tables.p, h->ntypes, h->nr,            \
+                                       h->nr_tot, h->rdr, h->fp.p, h->f.p, p_pair)
+    if(uni) HD(1); else HD(0);
+    if(ev) HP(1); else HP(0);
+    HIP_TRY(hipGetLastError());
+    MMD_TRY(eam_fp_halo(h));
+    if(ev && uni) HF(1, 1); else if(ev) HF(1, 0); else if(uni) HF(0, 1); else HF(0, 0);
+#undef HD
+#undef HP
+#undef HF
+    HIP_TRY(hipGetLastError());
+    if(evflag) {
+      hipLaunchKernelGGL(k_eam_half_sum, dim3(1), dim3(1024), 0, h->stream, p_embed, nblocks, p_pair, nblocks, h->d_result);
+      HIP_TRY(hipGetLastError());
+      if(eng || vir) {
+        HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if(eng) *eng = h->h_result[0];
+        if(vir) *vir = h->h_result[1];
+      }
+    }
+    return 0;
+  }
   // ---- tile path: LDS-staged candidates + knots (uniform tables, device-built list)
   const size_t tl1 = eam_tile_lds_density(h), tl2 = eam_tile_lds_force(h);
   if(eam_tiles_available(h)) {
@@ -533,14 +767,13 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     const int cus = h->prop.multiProcessorCount;
     const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl1 + 512)))) / 8 * 8);
     const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 512)))) / 8 * 8);
-    static bool attr_set = false;
-    if(!attr_set) {            // > 64 KiB of dynamic LDS needs the opt-in
+    if(!h->eam_attr_set) {     // > 64 KiB of dynamic LDS needs the opt-in (per device: the flag lives in the handle)
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      attr_set = true;
+      h->eam_attr_set = true;
     }
 #define DT(EVv) hipLaunchKernelGGL((k_eam_density_tile<EVv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \

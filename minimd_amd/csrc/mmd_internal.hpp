@@ -170,6 +170,7 @@ struct mmd_handle {
   int nr = 0, nrho = 0, nr_tot = 0, nrho_tot = 0;
   real rdr = 0, rdrho = 0;
   bool eam_uniform = true;
+  bool eam_attr_set = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this handle's device
   DevArr<real> rhor_spline, frho_spline, z2r_spline, fp, rho;
   // ---- Comm
   int me = 0, nprocs = 1;

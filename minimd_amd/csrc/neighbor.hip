@@ -642,13 +642,13 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
 // Tile build, one OWNED ATOM PER LANE (production): a single wavefront builds the rows of one tile.
 //   phase 1 (cull)  the candidates of the surrounding blocks are streamed through registers in batches (coalesced,
 //                   transposed: lane l looks at candidate c*64+l); those within the cutoff of the tile's bounding box
-//                   survive and are appended, in candidate order (ballot/mbcnt), to a small LDS buffer of positions and
-//                   to tile_cand[] — the survivors ARE the tile's candidate union, their running number is the slot;
+//                   survive and are appended, in candidate order (ballot/mbcnt), to a small LDS buffer of positions;
 //   phase 2 (test)  whenever the buffer fills, every lane tests ITS atom against each buffered candidate (position
 //                   broadcast from LDS, 8 candidates per 6 ds_read_b128): the v_cmp mask of a test is shifted into a
 //                   per-lane bit word with ONE v_addc_co_u32 — no ballot/mbcnt/append per test;
-//   expansion       after 32 candidates the set bits of a lane become row entries (16-bit LDS offsets of the slots),
-//                   written straight to the lane's column of nl16.
+//   expansion       after 32 candidates the OR of the lanes' words tells which of them belong to the tile's candidate UNION
+//                   (referenced by at least one row): those get the next slots and go to tile_cand[]; the set bits of a lane
+//                   become row entries (16-bit LDS offsets of the slots), written straight to the lane's column of nl16.
 // Nothing is shared between wavefronts: no barriers, ~8 KB of LDS, < 100 VGPRs.
 // Double precision (PF): the buffered positions are FLOATS relative to the tile's corner and phase 2 is a conservative
 // float pre-test with two thresholds (cutneighsq -/+ eps, eps = 4x the worst-case float error of rsq): below the lower
@@ -684,8 +684,9 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
 {
   __shared__ int rng_start[128], rng_pref[130];
   __shared__ __align__(16) float s_x[NB2_BUF], s_y[NB2_BUF], s_z[NB2_BUF];      // (PF: relative to the tile's corner)
-  __shared__ int s_cj[MODE != 0 ? NB2_BUF : 8];
-  __shared__ unsigned short s_self[64];
+  __shared__ int s_cj[NB2_BUF];                       // candidate's atom index (| NB2_LEX)
+  __shared__ unsigned char s_own[NB2_BUF];            // which tile atom the candidate is (0xff: none)
+  __shared__ unsigned short s_self[64];               // final slot of each tile atom itself (0xffff: not in the union)
   const int lane = threadIdx.x;
   const int tile = xcd_work_item(ntiles);
   if(tile < 0) return;
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   }
   const bool fast = nr <= NB_FASTR;
 
-  int S = 0, fill = 0;                     // survivors flushed so far / waiting in the buffer (wave-uniform)
+  int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int n = 0;                               // my row length
   bool any_ghost = false;
 
@@ -766,10 +767,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     const int fill8 = (fill + 7) & ~7;
     if(lane < fill8 - fill) {
       s_x[fill + lane] = 1.0e15f; s_y[fill + lane] = 1.0e15f; s_z[fill + lane] = 1.0e15f;
-      if(MODE != 0) s_cj[fill + lane] = -1;
+      s_cj[fill + lane] = (int)0x80000000;      // never > i, and not flagged NB2_LEX
+      s_own[fill + lane] = (unsigned char)0xff;
     }
     __syncthreads();
-    const unsigned myslot = s_self[lane];
     for(int gq = 0; gq < fill8; gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0;
@@ -817,29 +818,42 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         unsigned amb = bits_hi & ~bits;                            // between the thresholds: decide exactly
         if(__builtin_amdgcn_ballot_w64(amb != 0u) != 0ull) {
           while(amb) {
-            const int q = __builtin_ctz(amb);
+            const int bq = __builtin_ctz(amb);
             amb &= amb - 1;
-            const int slot = S + gq + (G - 1 - q);
-            const real4 pj = x[tile_cand[cbase + slot]];
+            const real4 pj = x[s_cj[gq + (G - 1 - bq)] & ~NB2_LEX];
             const real dx = pme.x - pj.x, dy = pme.y - pj.y, dz = pme.z - pj.z;
             const real rsq = dx * dx + dy * dy + dz * dz;
-            if(rsq <= cutneighsq) bits |= 1u << q;
+            if(rsq <= cutneighsq) bits |= 1u << bq;
           }
         }
       }
+      // ---- the candidates some lane keeps form the tile's union: they get the next slots, in candidate order
+      const unsigned used = wave_or_u(bits);
+      if(lane < G) {
+        const int bq = G - 1 - lane;
+        if((used >> bq) & 1u) {
+          const int slot = S + __popc(used >> 1 >> bq);           // used candidates before mine
+          if(slot < cstride - 1) tile_cand[cbase + slot] = s_cj[gq + lane] & ~NB2_LEX;
+          const unsigned own = s_own[gq + lane];
+          if(own != 0xffu) s_self[own] = (unsigned short)slot;
+        }
+      }
+      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && (s_cj[gq + lane] & ~NB2_LEX) >= nlocal) != 0ull;
+      __syncthreads();
+      const unsigned myslot = s_self[lane];
       unsigned bb = bits;
       while(bb) {
-        const int q = __builtin_ctz(bb);
+        const int bq = __builtin_ctz(bb);
         bb &= bb - 1;
-        const unsigned slot = (unsigned)(S + gq + (G - 1 - q));
+        const unsigned slot = (unsigned)S + (unsigned)__popc(used >> 1 >> bq);
         if(MODE != 0 || slot != myslot) {                        // full lists: the atom itself (rsq = 0) is a hit; dropped here
           if(n < maxneighs) rowp[(unsigned)n * 64u] = (unsigned short)(slot * NB_SLOT_BYTES);
           n++;
         }
       }
+      S += __popc(used);
     }
     __syncthreads();
-    S += fill;
     fill = 0;
   };
 
@@ -897,12 +911,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
           if(keep) {
             s_x[pos] = (float)(pp[u].x - ox); s_y[pos] = (float)(pp[u].y - oy); s_z[pos] = (float)(pp[u].z - oz);
-            if(MODE != 0) s_cj[pos] = cjv;
-            if(S + pos < cstride - 1) tile_cand[cbase + S + pos] = j;
+            s_cj[pos] = cjv;
             const unsigned own = (unsigned)((c0 + u) * 64 + lane - selfbase);
-            if(own < 64u) s_self[own] = (unsigned short)(S + pos);
+            s_own[pos] = own < 64u ? (unsigned char)own : (unsigned char)0xff;
           }
-          any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(keep && j >= nlocal) != 0ull;
           fill += __popcll(m);
         }
       }

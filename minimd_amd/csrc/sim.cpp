@@ -32,7 +32,8 @@ struct mmd_sim {
   int nbin[3] = {1, 1, 1};
   int natoms = 0;
   int sort_every = 0;
-  int dev_half = 0;          // neighbor-list style used on the device (may differ from the requested one for EAM)
+  int dev_half = 0;          // neighbor-list style used on the device (differs from the requested one only under --eam_half_full)
+  int eam_half_full = 0;
   mmd_float prd[3], mass = 1, dt = 0, dtforce = 0;
   ThermoScales th;
   int steps_done = 0;        // steps integrated so far (bench slices)
@@ -202,6 +203,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     else if(is_flag(a, "-u", "--units") && has) s->in.units = strcmp(argv[++i], "metal") == 0 ? 1 : 0;
     else if(is_flag(a, "-p", "--force") && has) s->in.forcetype = strcmp(argv[++i], "eam") == 0 ? 1 : 0;
     else if(is_flag(a, "-gn", "--ghost_newton") && has) s->ghost_newton = atoi(argv[++i]);
+    else if(is_flag(a, "--eam_half_full")) s->eam_half_full = 1;
     else if(is_flag(a, "-h", "--help")) { if(s->me == 0) print_help(); delete s; return 1; }
     // unknown flags are ignored, like the reference (run_one_test passes -dm)
   }
@@ -263,10 +265,12 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     if(g_have_id) memcpy(id, g_id, 128); else SIM_TRY(exchange_id_tcp(s->me, s->nprocs, id));
     SIM_TRY(mmd_comm_init_rccl(h, id, s->me, s->nprocs));
   }
-  // Device list style. LJ: as requested. EAM with half lists (the reference's serial-only path,
-  // ref/force_eam.cpp:94-270) runs on the full-list kernels: forces are identical and eng_vdwl is converted to the
-  // half-list convention (full lists report 2x, ref/force_eam.cpp:446 vs :269), so thermo rows are unchanged.
-  s->dev_half = (s->in.forcetype == 1) ? 0 : (s->halfneigh != 0 ? 1 : 0);
+  // Device list style: as requested. EAM with half lists is ForceEAM::compute_halfneigh (ref/force_eam.cpp:94-270, third-law
+  // scatter with atomics). `--eam_half_full` (ours; the reference ignores unknown flags) serves such a request on the faster
+  // full-list kernels instead: forces are identical and eng_vdwl is converted to the half-list convention (full lists report
+  // 2x, ref/force_eam.cpp:446 vs :269), so thermo rows are unchanged.
+  s->dev_half = s->halfneigh != 0 ? 1 : 0;
+  if(s->in.forcetype == 1 && s->eam_half_full) s->dev_half = 0;
   SIM_TRY(mmd_neighbor_setup(h, s->nbin, s->in.neigh_cut, s->dev_half, s->ghost_newton, s->ntypes));
   s->dtforce = 0.5 * s->dt;                        // Integrate::setup (ref/integrate.cpp:41-44)
   const int nt2 = s->ntypes * s->ntypes;
