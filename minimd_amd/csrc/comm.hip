@@ -234,6 +234,46 @@ int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv
   return -1;
 }
 
+// the two swaps of one ghost layer of a dimension (towards -1 and towards +1) are independent of each other: their count
+// handshakes share ONE ncclGroup and ONE host synchronisation, and so do their payloads. Sends/receives to the same peer
+// (2-wide grids: both neighbours are the same rank) are matched in the order they are issued, on both sides alike.
+int mmd_transport_sendrecv_counts_pair(mmd_handle* h, const int nsend[2], const int dest[2], int nrecv[2], const int src[2])
+{
+  if(h->rccl) {
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    h->h_flags[8] = nsend[0]; h->h_flags[9] = nsend[1];
+    HIP_TRY(hipMemcpyAsync(h->d_flags + 8, h->h_flags + 8, 2 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(ncclGroupStart());
+    for(int q = 0; q < 2; q++) {
+      NCCL_TRY(ncclSend(h->d_flags + 8 + q, 1, ncclInt, dest[q], c, h->stream));
+      NCCL_TRY(ncclRecv(h->d_flags + 10 + q, 1, ncclInt, src[q], c, h->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    HIP_TRY(hipMemcpyAsync(h->h_flags + 10, h->d_flags + 10, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    nrecv[0] = h->h_flags[10]; nrecv[1] = h->h_flags[11];
+    return 0;
+  }
+  for(int q = 0; q < 2; q++) MMD_TRY(mmd_transport_sendrecv_counts(h, nsend[q], dest[q], &nrecv[q], src[q]));
+  return 0;
+}
+int mmd_transport_sendrecv_pair(mmd_handle* h, const void* const dsend[2], const size_t nsend[2], const int dest[2], void* const drecv[2],
+                                const size_t nrecv[2], const int src[2])
+{
+  if(h->rccl) {
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    NCCL_TRY(ncclGroupStart());
+    for(int q = 0; q < 2; q++) {
+      if(nsend[q]) NCCL_TRY(ncclSend(dsend[q], nsend[q], ncclChar, dest[q], c, h->stream));
+      if(nrecv[q]) NCCL_TRY(ncclRecv(drecv[q], nrecv[q], ncclChar, src[q], c, h->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+  }
+  for(int q = 0; q < 2; q++) MMD_TRY(mmd_transport_sendrecv(h, dsend[q], nsend[q], dest[q], drecv[q], nrecv[q], src[q]));
+  return 0;
+}
+
 // in-place sum over ranks of vals[0..n) (MPI_Allreduce SUM of the thermo scalars, ref/thermo.cpp:131,168,188)
 int mmd_transport_allreduce(mmd_handle* h, double* vals, int n)
 {
@@ -523,17 +563,27 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
       HIP_TRY(hipGetLastError());
     }
     h->nlocal = nlocal - nsend;
-    // send towards -1, receive from +1; and the other way round when the grid is wider than 2 (ref :521-543)
+    // send towards -1, receive from +1; and the other way round when the grid is wider than 2 (ref :521-543): both
+    // directions share one count handshake (one host sync) and one payload group
     int nrecv1 = 0, nrecv2 = 0;
-    MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, h->procneigh[d][0], &nrecv1, h->procneigh[d][1]));
-    if(h->procgrid[d] > 2) MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, h->procneigh[d][1], &nrecv2, h->procneigh[d][0]));
+    if(h->procgrid[d] > 2) {
+      const int ns[2] = {nsend, nsend}, dest[2] = {h->procneigh[d][0], h->procneigh[d][1]}, src[2] = {h->procneigh[d][1], h->procneigh[d][0]};
+      int nr[2] = {0, 0};
+      MMD_TRY(mmd_transport_sendrecv_counts_pair(h, ns, dest, nr, src));
+      nrecv1 = nr[0]; nrecv2 = nr[1];
+      MMD_TRY(h->buf_recv.ensure(rec_reals * (nrecv1 + nrecv2) + 8, false, h->stream));
+      const void* dsend[2] = {h->buf_send.p, h->buf_send.p};
+      void* drecv[2] = {h->buf_recv.p, (ExchRec*)h->buf_recv.p + nrecv1};
+      const size_t bs[2] = {(size_t)nsend * sizeof(ExchRec), (size_t)nsend * sizeof(ExchRec)};
+      const size_t br[2] = {(size_t)nrecv1 * sizeof(ExchRec), (size_t)nrecv2 * sizeof(ExchRec)};
+      MMD_TRY(mmd_transport_sendrecv_pair(h, dsend, bs, dest, drecv, br, src));
+    } else {
+      MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, h->procneigh[d][0], &nrecv1, h->procneigh[d][1]));
+      MMD_TRY(h->buf_recv.ensure(rec_reals * nrecv1 + 8, false, h->stream));
+      MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)nsend * sizeof(ExchRec), h->procneigh[d][0], h->buf_recv.p,
+                                     (size_t)nrecv1 * sizeof(ExchRec), h->procneigh[d][1]));
+    }
     const int nrecv = nrecv1 + nrecv2;
-    MMD_TRY(h->buf_recv.ensure(rec_reals * nrecv + 8, false, h->stream));
-    MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)nsend * sizeof(ExchRec), h->procneigh[d][0], h->buf_recv.p,
-                                   (size_t)nrecv1 * sizeof(ExchRec), h->procneigh[d][1]));
-    if(h->procgrid[d] > 2)
-      MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)nsend * sizeof(ExchRec), h->procneigh[d][1],
-                                     (ExchRec*)h->buf_recv.p + nrecv1, (size_t)nrecv2 * sizeof(ExchRec), h->procneigh[d][0]));
     int nkeep = 0;
     MMD_TRY(compact(h, ArrivePred{(const ExchRec*)h->buf_recv.p, d, lo, hi}, 0, nrecv, keep, &nkeep));
     if(nkeep) {
@@ -624,53 +674,80 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   }
   for(int d = 0; d < 3; d++) {
     int nfirst = 0, nlast = 0;
-    for(int ineed = 0; ineed < 2 * h->need[d]; ineed++, iswap++) {
-      Swap& s = h->swaps[iswap];
-      if(ineed % 2 == 0) { nfirst = nlast; nlast = h->nlocal + h->nghost; }
-      int nsend = 0;
-      if(nb >= 0 && nfirst == 0)
-        MMD_TRY(compact(h, BndSlabPred{h->x.p, h->bnd_list.p, nb, h->nlocal, d, s.slablo, s.slabhi}, 0, nb + (nlast - h->nlocal), s.sendlist, &nsend));
-      else
-        MMD_TRY(compact(h, SlabPred{h->x.p, d, s.slablo, s.slabhi}, nfirst, nlast - nfirst, s.sendlist, &nsend));
-      const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
-      const int nall = h->nlocal + h->nghost;
-      int nrecv = nsend;
-      if(s.sendproc == h->me && !h->opt_force_transport) {
-        MMD_TRY(mmd_ensure_atoms(h, nall + nrecv + 1, true));
-        MMD_TRY(h->ghost_image.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
-        MMD_TRY(h->ghost_root.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
-        if(nsend)
-          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->ghost_root.p,
-                             h->nlocal, s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], h->x.p + nall,
-                             h->ghost_image.p + h->nghost, h->ghost_root.p + h->nghost, h->type.p + nall);
-      } else {
-        // message = nsend real4 followed by nsend image codes
-        const size_t bytes_s = (size_t)nsend * (sizeof(real4) + sizeof(int));
-        MMD_TRY(h->buf_send.ensure(bytes_s / sizeof(real) + 8, false, h->stream));
-        int* simg = (int*)((real4*)h->buf_send.p + nsend);
-        h->ghost_chain_ok = false;
-        if(nsend)
-          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend, 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->ghost_root.p,
-                             h->nlocal, s.sendlist.p, nsend, sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], (real4*)h->buf_send.p, simg,
-                             (int*)nullptr, (int*)nullptr);
-        MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, s.sendproc, &nrecv, s.recvproc));
-        const size_t bytes_r = (size_t)nrecv * (sizeof(real4) + sizeof(int));
-        MMD_TRY(h->buf_recv.ensure(bytes_r / sizeof(real) + 8, false, h->stream));
-        MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, bytes_s, s.sendproc, h->buf_recv.p, bytes_r, s.recvproc));
-        MMD_TRY(mmd_ensure_atoms(h, nall + nrecv + 1, true));
-        MMD_TRY(h->ghost_image.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
-        if(nrecv) {
-          HIP_TRY(hipMemcpyAsync(h->x.p + nall, h->buf_recv.p, (size_t)nrecv * sizeof(real4), hipMemcpyDeviceToDevice, h->stream));
-          HIP_TRY(hipMemcpyAsync(h->ghost_image.p + h->nghost, (real4*)h->buf_recv.p + nrecv, (size_t)nrecv * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-        }
+    for(int layer = 0; layer < h->need[d]; layer++, iswap += 2) {
+      // the two swaps of this ghost layer scan the same atoms [nfirst, nlast) (ref/comm.cpp:766-770: nlast is frozen at the
+      // even swap), so neither depends on the other's ghosts
+      nfirst = nlast; nlast = h->nlocal + h->nghost;
+      Swap* sw[2] = {&h->swaps[iswap], &h->swaps[iswap + 1]};
+      int nsend[2] = {0, 0};
+      for(int q = 0; q < 2; q++) {
+        Swap& s = *sw[q];
+        if(nb >= 0 && nfirst == 0)
+          MMD_TRY(compact(h, BndSlabPred{h->x.p, h->bnd_list.p, nb, h->nlocal, d, s.slablo, s.slabhi}, 0, nb + (nlast - h->nlocal), s.sendlist, &nsend[q]));
+        else
+          MMD_TRY(compact(h, SlabPred{h->x.p, d, s.slablo, s.slabhi}, nfirst, nlast - nfirst, s.sendlist, &nsend[q]));
       }
-      const bool self_swap = s.sendproc == h->me && !h->opt_force_transport;      // (its pack kernel wrote the types too)
-      if(nrecv && !self_swap) hipLaunchKernelGGL(k_ghost_types, dim3(div_up(nrecv, 256)), dim3(256), 0, h->stream, h->x.p, nall, nrecv, h->type.p);
+      const bool self0 = sw[0]->sendproc == h->me && !h->opt_force_transport, self1 = sw[1]->sendproc == h->me && !h->opt_force_transport;
+      if(self0 && self1) {
+        for(int q = 0; q < 2; q++) {
+          Swap& s = *sw[q];
+          const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
+          const int nall = h->nlocal + h->nghost, nrecv = nsend[q];
+          MMD_TRY(mmd_ensure_atoms(h, nall + nrecv + 1, true));
+          MMD_TRY(h->ghost_image.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
+          MMD_TRY(h->ghost_root.ensure((size_t)h->nghost + nrecv + 8, true, h->stream, (size_t)h->nghost));
+          if(nsend[q])                                   // (the pack kernel of a self swap writes the ghost types too)
+            hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend[q], 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->ghost_root.p,
+                               h->nlocal, s.sendlist.p, nsend[q], sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], h->x.p + nall,
+                               h->ghost_image.p + h->nghost, h->ghost_root.p + h->nghost, h->type.p + nall);
+          HIP_TRY(hipGetLastError());
+          s.sendnum = nsend[q]; s.recvnum = nrecv; s.firstrecv = nall;
+          h->nghost += nrecv;
+        }
+        continue;
+      }
+      // ---- remote partners (a dimension is either all-self or all-remote): message = n real4 followed by n image codes
+      h->ghost_chain_ok = false;
+      const size_t rec = sizeof(real4) + sizeof(int);
+      const size_t bytes_s[2] = {(size_t)nsend[0] * rec, (size_t)nsend[1] * rec};
+      const size_t off_s1 = (bytes_s[0] + 63) & ~(size_t)63;                  // second message starts 64-byte aligned
+      MMD_TRY(h->buf_send.ensure((off_s1 + bytes_s[1]) / sizeof(real) + 16, false, h->stream));
+      unsigned char* sbase = (unsigned char*)h->buf_send.p;
+      const void* dsend[2] = {sbase, sbase + off_s1};
+      for(int q = 0; q < 2; q++) {
+        Swap& s = *sw[q];
+        const real sx = s.pbc[0] * h->prd[0], sy = s.pbc[1] * h->prd[1], sz = s.pbc[2] * h->prd[2];
+        real4* dst = (real4*)dsend[q];
+        if(nsend[q])
+          hipLaunchKernelGGL(k_pack_border, dim3(div_up(nsend[q], 256)), dim3(256), 0, h->stream, h->x.p, h->ghost_image.p, h->ghost_root.p,
+                             h->nlocal, s.sendlist.p, nsend[q], sx, sy, sz, s.pbc_any, s.pbc[0], s.pbc[1], s.pbc[2], dst, (int*)(dst + nsend[q]),
+                             (int*)nullptr, (int*)nullptr);
+      }
       HIP_TRY(hipGetLastError());
-      s.sendnum = nsend;
-      s.recvnum = nrecv;
-      s.firstrecv = nall;
-      h->nghost += nrecv;
+      const int dest[2] = {sw[0]->sendproc, sw[1]->sendproc}, src[2] = {sw[0]->recvproc, sw[1]->recvproc};
+      int nrecv[2] = {0, 0};
+      MMD_TRY(mmd_transport_sendrecv_counts_pair(h, nsend, dest, nrecv, src));
+      const size_t bytes_r[2] = {(size_t)nrecv[0] * rec, (size_t)nrecv[1] * rec};
+      const size_t off_r1 = (bytes_r[0] + 63) & ~(size_t)63;
+      MMD_TRY(h->buf_recv.ensure((off_r1 + bytes_r[1]) / sizeof(real) + 16, false, h->stream));
+      unsigned char* rbase = (unsigned char*)h->buf_recv.p;
+      void* drecv[2] = {rbase, rbase + off_r1};
+      MMD_TRY(mmd_transport_sendrecv_pair(h, dsend, bytes_s, dest, drecv, bytes_r, src));
+      const int nall0 = h->nlocal + h->nghost;
+      MMD_TRY(mmd_ensure_atoms(h, nall0 + nrecv[0] + nrecv[1] + 1, true));
+      MMD_TRY(h->ghost_image.ensure((size_t)h->nghost + nrecv[0] + nrecv[1] + 8, true, h->stream, (size_t)h->nghost));
+      for(int q = 0; q < 2; q++) {
+        Swap& s = *sw[q];
+        const int nall = h->nlocal + h->nghost;
+        if(nrecv[q]) {
+          HIP_TRY(hipMemcpyAsync(h->x.p + nall, drecv[q], (size_t)nrecv[q] * sizeof(real4), hipMemcpyDeviceToDevice, h->stream));
+          HIP_TRY(hipMemcpyAsync(h->ghost_image.p + h->nghost, (real4*)drecv[q] + nrecv[q], (size_t)nrecv[q] * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+          hipLaunchKernelGGL(k_ghost_types, dim3(div_up(nrecv[q], 256)), dim3(256), 0, h->stream, h->x.p, nall, nrecv[q], h->type.p);
+        }
+        HIP_TRY(hipGetLastError());
+        s.sendnum = nsend[q]; s.recvnum = nrecv[q]; s.firstrecv = nall;
+        h->nghost += nrecv[q];
+      }
     }
   }
   MMD_TRY(mmd_set_dummy(h));

@@ -144,6 +144,7 @@ struct mmd_handle {
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
   DevArr<unsigned short> tile_self;       // half lists: union slot of each tile atom itself (0xffff: not in the union)
+  DevArr<int> tile_rowmax, tile_rowsum;   // per tile: longest row / sum of the row lengths (reduced by k_tile_reduce)
   DevArr<int> tile_ghost, tile_order;     // per tile: references a ghost atom?; tiles ordered interior-first
   int ntiles_interior = 0;
   hipEvent_t ev_x_ready = nullptr, ev_halo_done = nullptr;
@@ -222,6 +223,9 @@ int mmd_order_tiles(mmd_handle* h);
 int mmd_ensure_rows(mmd_handle* h);       // materialise `neigh` from the tile form when a kernel needs it
 int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int dest, void* drecv, size_t nrecv, int src);
 int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv, int src);
+int mmd_transport_sendrecv_counts_pair(mmd_handle* h, const int nsend[2], const int dest[2], int nrecv[2], const int src[2]);
+int mmd_transport_sendrecv_pair(mmd_handle* h, const void* const dsend[2], const size_t nsend[2], const int dest[2], void* const drecv[2],
+                                const size_t nrecv[2], const int src[2]);
 int mmd_transport_allreduce(mmd_handle* h, double* vals, int n);
 double mmd_wall();
 

@@ -679,13 +679,14 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    const int* __restrict__ tile_cnt, int* __restrict__ numneigh,
                                                    unsigned short* __restrict__ nl16, int* __restrict__ tile_cand,
                                                    int* __restrict__ tile_ncand, int* __restrict__ tile_max, int* __restrict__ tile_ghost,
-                                                   unsigned short* __restrict__ tile_self, int* __restrict__ flags,
-                                                   unsigned long long* __restrict__ total_out)
+                                                   unsigned short* __restrict__ tile_self, int* __restrict__ tile_rowmax,
+                                                   int* __restrict__ tile_rowsum, int* __restrict__ flags, int ablate)
 {
   __shared__ int rng_start[128], rng_pref[130];
   __shared__ __align__(16) float s_x[NB2_BUF], s_y[NB2_BUF], s_z[NB2_BUF];      // (PF: relative to the tile's corner)
   __shared__ int s_cj[NB2_BUF];                       // candidate's atom index (| NB2_LEX)
   __shared__ unsigned char s_own[NB2_BUF];            // which tile atom the candidate is (0xff: none)
+  __shared__ unsigned short s_selfpos[64];            // buffer position of each tile atom's own candidate record (0xffff: not in this buffer)
   __shared__ unsigned short s_self[64];               // final slot of each tile atom itself (0xffff: not in the union)
   const int lane = threadIdx.x;
   const int tile = xcd_work_item(ntiles);
@@ -716,6 +717,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   }
   if(lane == 0) rng_pref[nr] = carry;
   s_self[lane] = (unsigned short)0xffff;
+  s_selfpos[lane] = (unsigned short)0xffff;
   __syncthreads();
   const int total = __builtin_amdgcn_readfirstlane(rng_pref[nr]);
   const int rc = g.reach[2] * ny + g.reach[1];                   // the block's own (y,z) row
@@ -727,8 +729,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const unsigned long long own_mask = __builtin_amdgcn_ballot_w64(owned);
   unsigned short* __restrict__ rowp = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
   const size_t cbase = (size_t)tile * cstride;
-  if(own_mask == 0ull) {                                         // (second tile of a block that holds only ghosts)
-    if(lane == 0) { tile_max[tile] = 0; tile_ncand[tile] = 0; tile_cand[cbase] = nall; tile_ghost[tile] = 0; }
+  if(own_mask == 0ull || (ablate & 32)) {                        // (second tile of a block that holds only ghosts)
+    if(lane == 0) { tile_max[tile] = 0; tile_ncand[tile] = 0; tile_cand[cbase] = nall; tile_ghost[tile] = 0; tile_rowmax[tile] = 0; tile_rowsum[tile] = 0; }
     if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = (unsigned short)0xffff;
     return;
   }
@@ -771,7 +773,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       s_own[fill + lane] = (unsigned char)0xff;
     }
     __syncthreads();
-    for(int gq = 0; gq < fill8; gq += 32) {
+    const int selfpos = MODE == 0 ? (int)s_selfpos[lane] : -1;
+    for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0;
       for(int q = 0; q < G; q += 8) {
@@ -827,6 +830,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           }
         }
       }
+      // full lists: the atom itself (rsq = 0) is a hit of its own lane: dropped here
+      if(MODE == 0) { const unsigned sp = (unsigned)(selfpos - gq); if(sp < (unsigned)G) bits &= ~(1u << (G - 1 - sp)); }
       // ---- the candidates some lane keeps form the tile's union: they get the next slots, in candidate order
       const unsigned used = wave_or_u(bits);
       if(lane < G) {
@@ -834,31 +839,30 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         if((used >> bq) & 1u) {
           const int slot = S + __popc(used >> 1 >> bq);           // used candidates before mine
           if(slot < cstride - 1) tile_cand[cbase + slot] = s_cj[gq + lane] & ~NB2_LEX;
-          const unsigned own = s_own[gq + lane];
-          if(own != 0xffu) s_self[own] = (unsigned short)slot;
+          if(MODE != 0) { const unsigned own = s_own[gq + lane]; if(own != 0xffu) s_self[own] = (unsigned short)slot; }
         }
       }
       any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && (s_cj[gq + lane] & ~NB2_LEX) >= nlocal) != 0ull;
-      __syncthreads();
-      const unsigned myslot = s_self[lane];
+      // ---- expansion: every lane turns its set bits into row entries; branch-free, as many rounds as the fullest word holds
+      const int rounds = wave_max_i(__popc(bits));
       unsigned bb = bits;
-      while(bb) {
-        const int bq = __builtin_ctz(bb);
+      for(int it = 0; it < rounds; it++) {
+        const bool v = bb != 0u;
+        const int bq = __builtin_ctz(bb | 0x80000000u);
         bb &= bb - 1;
         const unsigned slot = (unsigned)S + (unsigned)__popc(used >> 1 >> bq);
-        if(MODE != 0 || slot != myslot) {                        // full lists: the atom itself (rsq = 0) is a hit; dropped here
-          if(n < maxneighs) rowp[(unsigned)n * 64u] = (unsigned short)(slot * NB_SLOT_BYTES);
-          n++;
-        }
+        if(v && n < maxneighs && !(ablate & 1)) rowp[(unsigned)n * 64u] = (unsigned short)(slot * NB_SLOT_BYTES);    // (ablate: profiling only)
+        n += v ? 1 : 0;
       }
       S += __popc(used);
     }
+    if(MODE == 0) s_selfpos[lane] = (unsigned short)0xffff;
     __syncthreads();
     fill = 0;
   };
 
   // ---- phase 1: stream the candidates
-  const int nchunks = (total + 63) >> 6;
+  const int nchunks = (ablate & 8) ? 0 : (total + 63) >> 6;
   for(int c0 = 0; c0 < nchunks; c0 += NB2_BATCH) {
     int jj[NB2_BATCH];
     if(fast) {
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     for(int u = 0; u < NB2_BATCH; u++) {
       if(c0 + u < nchunks) {
         const int j = jj[u];
-        bool keep = j >= 0;
+        bool keep = j >= 0 && !(ablate & 16);
         int cjv = j;
         if(MODE != 0) keep = keep && (j >= nlocal || j > imin);            // an owned j <= every tile atom is nobody's j > i
         if(MODE == 2 && j >= nlocal) {
@@ -914,6 +918,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             s_cj[pos] = cjv;
             const unsigned own = (unsigned)((c0 + u) * 64 + lane - selfbase);
             s_own[pos] = own < 64u ? (unsigned char)own : (unsigned char)0xff;
+            if(MODE == 0 && own < 64u) s_selfpos[own] = (unsigned short)pos;
           }
           fill += __popcll(m);
         }
@@ -928,19 +933,39 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   if(kmax > maxneighs) kmax = maxneighs;
   const unsigned short dummy = (unsigned short)(S * NB_SLOT_BYTES);
   const int nmin = min(-wave_max_i(-n), kmax);
-  for(int k = nmin; k < kmax; k++) if(k >= n) rowp[(unsigned)k * 64u] = dummy;
+  for(int k = nmin; k < kmax && !(ablate & 4); k++) if(k >= n) rowp[(unsigned)k * 64u] = dummy;
   if(owned) numneigh[ii] = n;
   if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = owned ? s_self[lane] : (unsigned short)0xffff;
-  const long long tsum = wave_sum((long long)n);
+  const int tsum = wave_sum(n);
   if(lane == 0) {
     tile_max[tile] = kmax;
     tile_ncand[tile] = S;
     tile_cand[cbase + min(S, cstride - 1)] = nall;          // the dummy atom closes the list
     tile_ghost[tile] = any_ghost ? 1 : 0;
-    atomicMax(&flags[0], maxn);
-    atomicMax(&flags[2], S);
-    if(S > cstride - 2 || (S + 1) * NB_SLOT_BYTES > 65535) atomicMax(&flags[3], 1);   // union does not fit the 16-bit slot offsets
-    atomicAdd(total_out, (unsigned long long)tsum);
+    // per-tile results, reduced by k_tile_reduce: 36 k workgroups hammering three global words with atomics cost
+    // 0.8 ms at -s 80 (same-address atomics retire one at a time, ~10 ns each)
+    tile_rowmax[tile] = maxn;
+    tile_rowsum[tile] = tsum;
+    if(S > cstride - 2 || (S + 1) * NB_SLOT_BYTES > 65535) atomicMax(&flags[3], 1);   // (rare) union does not fit the 16-bit slot offsets
+  }
+}
+
+// flags[0] = longest row, flags[2] = largest union, *total_out = sum of the row lengths
+__global__ __launch_bounds__(1024) void k_tile_reduce(const int* __restrict__ tile_rowmax, const int* __restrict__ tile_rowsum,
+                                                      const int* __restrict__ tile_ncand, int ntiles, int* __restrict__ flags,
+                                                      unsigned long long* __restrict__ total_out)
+{
+  __shared__ int s_a[16], s_b[16];
+  __shared__ long long s_c[16];
+  int a = 0, b = 0;
+  long long c = 0;
+  for(int t = threadIdx.x; t < ntiles; t += blockDim.x) { a = max(a, tile_rowmax[t]); b = max(b, tile_ncand[t]); c += tile_rowsum[t]; }
+  a = wave_max_i(a); b = wave_max_i(b); c = wave_sum(c);
+  if((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; s_c[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    for(int w = 1; w < (int)(blockDim.x >> 6); w++) { a = max(a, s_a[w]); b = max(b, s_b[w]); c += s_c[w]; }
+    flags[0] = a; flags[2] = b; *total_out = (unsigned long long)c;
   }
 }
 
@@ -1045,6 +1070,8 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     MMD_TRY(h->tile_ncand.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_cnt.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_ghost.ensure((size_t)nt + 2, false, h->stream));
+    MMD_TRY(h->tile_rowmax.ensure((size_t)nt + 2, false, h->stream));
+    MMD_TRY(h->tile_rowsum.ensure((size_t)nt + 2, false, h->stream));
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
@@ -1066,9 +1093,11 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   hipLaunchKernelGGL(k_build_rows<M>, dim3(xcd_grid(h->ntiles)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,           \
                      h->ghost_image.p, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
                      h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
-                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->d_flags, (unsigned long long*)h->d_result)
+                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->d_flags, h->opt_ablate)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
+        hipLaunchKernelGGL(k_tile_reduce, dim3(1), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
+                           h->d_flags, (unsigned long long*)h->d_result);
       } else if(lds > 64 * 1024) {        // the candidate-per-lane form keeps maxneighs x 64 raw slots in LDS
         want_tiles = false;
         break;

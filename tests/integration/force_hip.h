@@ -1,0 +1,72 @@
+// tests/integration/force_hip.h — the binding INTEGRATION.md §2 documents: a Force plugin for the reference's ref/ tree
+// (abstract class Force, ref/force.h:40-69; selected where ref/ljs.cpp:274-285 picks ForceLJ / ForceEAM) that forwards
+// Force::setup / Force::compute to the C-ABI of include/mmd.h. It is NOT part of the product: __graft_entry__.build()
+// compiles it against the reference's own headers (-fsyntax-only) whenever /root/reference is present, so the code shown
+// in INTEGRATION.md is known to compile against ref/force.h, ref/atom.h, ref/neighbor.h and ref/comm.h.
+#ifndef FORCE_HIP_H_
+#define FORCE_HIP_H_
+
+#include "force.h"                      // the reference's header (ref/force.h)
+
+#ifndef MMD_PRECISION
+#define MMD_PRECISION PRECISION         // ref/types.h:61-72: PRECISION 1 = float, 2 = double — same convention
+#endif
+extern "C" {
+#include "mmd.h"
+}
+
+class ForceHIP : public Force
+{
+  public:
+    mmd_handle* h;
+
+    explicit ForceHIP(int ntypes_) : h(0)
+    {
+      // members as ForceLJ::ForceLJ sets them (ref/force_lj.cpp:41-57)
+      cutforce = 0.0;
+      use_oldcompute = 0;
+      reneigh = 1;
+      style = FORCELJ;
+      ntypes = ntypes_;
+      cutforcesq = new MMD_float[ntypes * ntypes];
+      epsilon = new MMD_float[ntypes * ntypes];
+      sigma6 = new MMD_float[ntypes * ntypes];
+      sigma = new MMD_float[ntypes * ntypes];
+      for(int i = 0; i < ntypes * ntypes; i++) { cutforcesq[i] = 0.0; epsilon[i] = 1.0; sigma6[i] = 1.0; sigma[i] = 1.0; }
+      if(mmd_create(-1, &h) != 0) h = 0;           // no GPU => every later call fails loudly (no CPU fallback)
+    }
+    virtual ~ForceHIP()
+    {
+      mmd_destroy(h);
+      delete[] cutforcesq; delete[] epsilon; delete[] sigma6; delete[] sigma;
+    }
+
+    void setup()                                     // ForceLJ::setup, ref/force_lj.cpp:65-69
+    {
+      for(int i = 0; i < ntypes * ntypes; i++) cutforcesq[i] = cutforce * cutforce;
+      mmd_force_lj_setup(h, ntypes, cutforcesq, sigma6, epsilon);
+    }
+
+    // Force::compute(Atom&, Neighbor&, Comm&, int): called by every OpenMP thread from Integrate::run
+    // (ref/integrate.cpp:183, inside the parallel region opened at :90) and once outside it (ref/ljs.cpp:455,478)
+    void compute(Atom &atom, Neighbor &neighbor, Comm &, int)
+    {
+      #pragma omp master
+      {
+        MMD_float prd[3] = {atom.box.xprd, atom.box.yprd, atom.box.zprd};
+        MMD_float lo[3] = {atom.box.xlo, atom.box.ylo, atom.box.zlo}, hi[3] = {atom.box.xhi, atom.box.yhi, atom.box.zhi};
+        mmd_atom_set_box(h, prd, lo, hi);
+        mmd_atom_upload(h, atom.x, atom.v, atom.type, 0, atom.nlocal, atom.nghost);          // PAD=3 arrays as they are
+        const int nbin[3] = {neighbor.nbinx, neighbor.nbiny, neighbor.nbinz};
+        mmd_neighbor_setup(h, nbin, neighbor.cutneigh, neighbor.halfneigh, neighbor.ghost_newton, ntypes);
+        mmd_neighbor_upload(h, neighbor.neighbors, neighbor.maxneighs, neighbor.numneigh, atom.nlocal);   // ref rows as they are
+        double e = 0, v = 0;
+        if(mmd_force_compute(h, evflag, &e, &v) != 0) fprintf(stderr, "ForceHIP: %s\n", mmd_last_error());
+        mmd_atom_download(h, 0, 0, atom.f, 0, 0);
+        if(evflag) { eng_vdwl = e; virial = v; }      // same conventions as ref/force_lj.cpp:441-447
+      }
+      #pragma omp barrier
+    }
+};
+
+#endif

@@ -4,6 +4,7 @@
                   exactly that swap pattern (sendrecv + allreduce semantics of the library's transport).
   mode sim      : GPU — every rank runs the product (ranks share GPU 0 when only one is visible) with the
                   gloo host transport; rank 0 writes the thermo rows + per-rank counts to <out>.
+  mode simrccl  : the same over the library's RCCL communicator (one GPU per rank; needs as many GPUs as ranks).
 """
 import json
 import os
@@ -63,10 +64,22 @@ def geometry(out):
         json.dump({"errors": sum(allerr, []), "procgrid": mine["procgrid"], "world": world}, open(out, "w"))
 
 
-def sim(out, args, precision):
+def sim(out, args, precision, rccl=False):
     rank, world = dist.get_rank(), dist.get_world_size()
-    tr = GlooTransport()
-    api.sim_set_host_transport(tr.sendrecv, tr.allreduce, precision)
+    if rccl:
+        # production transport: the library's own RCCL communicator, one GPU per rank (LOCAL_RANK picks the device)
+        import ctypes
+        L = api.load_library(precision)
+        obj = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            assert L.mmd_comm_unique_id(buf) == 0, L.mmd_last_error()
+            obj = [buf.raw]
+        dist.broadcast_object_list(obj, src=0)
+        L.mmd_sim_set_unique_id(obj[0])
+    else:
+        tr = GlooTransport()
+        api.sim_set_host_transport(tr.sendrecv, tr.allreduce, precision)
     s = minimd_amd.Sim(args, precision=precision)
     s.initial()
     s.run()
@@ -85,7 +98,7 @@ if __name__ == "__main__":
         if mode == "geometry":
             geometry(out)
         else:
-            sim(out, sys.argv[4:], sys.argv[3])
+            sim(out, sys.argv[4:], sys.argv[3], rccl=(mode == "simrccl"))
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -678,13 +678,15 @@ def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
 
 
 @pytest.mark.gpu
-def test_bench_contract_two_ranks_sharing_the_gpu(tmp_path):
-    """bench.py's N>1 plumbing (torch.distributed.run, gloo control plane, barrier + max-over-ranks timing, one JSON line from
-    rank 0) with the halo on the host-staged debug transport, since two RCCL ranks cannot share one GPU"""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MMD_BENCH_TRANSPORT="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29661", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20", "--size", "16"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+def test_bench_launches_itself_for_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` as a PLAIN process (the way the driver starts it): bench.py re-launches itself through
+    torch.distributed.run on a free loop-back port; with one visible GPU the two ranks share it and the halos take the
+    host-staged transport (the JSON line says so), with two GPUs they use RCCL. One JSON line from rank 0."""
+    import torch
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("MMD_BENCH_TRANSPORT", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20", "--size", "16", "--equil", "20"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -695,6 +697,40 @@ def test_bench_contract_two_ranks_sharing_the_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 20 and d["scaling"] == "weak" and d["value"] > 0
     assert "32x16x16" in d["config"]["workload"] and d["cpu_baseline"] is None      # (CPU baseline only at N=1)
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["config"]["transport"] == ("rccl" if torch.cuda.device_count() >= 2 else "host") and d["config"]["transport_ranks"] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,port", [(["-s", "12", "-n", "100", "--half_neigh", "0"], 29681), (["-s", "12", "-n", "100", "--half_neigh", "1"], 29682),
+                                       (["-i", "in.eam.miniMD", "-s", "8", "-n", "60", "--half_neigh", "0"], 29683)])
+def test_rccl_two_gpus_match_one_rank(args, port, tmp_path):
+    """the PRODUCTION transport between two real GPUs (skipped on a one-GPU box): RCCL count handshakes and payloads of
+    exchange / borders (both swaps of a ghost layer in one group), the per-step halo pair of a 2-wide dimension (two sends to
+    and two receives from the same peer in one group, comm.hip mmd_comm_communicate), the reverse halo (half lists), the EAM
+    fp halo and the thermo all-reduce. Rows equal the one-rank run to summation order; per-rank counts equal the oracle's."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    cwd = os.path.join(REPO, "data")
+    base = sim_rows(args)
+    out = str(tmp_path / "mp.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "simrccl", out, "dp"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=cwd)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert sum(c[0] for c in res["counts"]) == res["natoms"]
+    rows = [tuple(x) for x in res["rows"]]
+    assert [r_[0] for r_ in rows] == [b[0] for b in base]
+    for a, b in zip(rows, base):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+    o = Oracle(args, nprocs=2)
+    o.initial(); o.run()
+    assert [o.nlocal(0), o.nlocal(1)] == [c[0] for c in res["counts"]]
+    assert [o.nghost(0), o.nghost(1)] == [c[1] for c in res["counts"]]
+    o.close()
 
 
 @pytest.mark.gpu

@@ -182,3 +182,13 @@ def test_neighbor_geometry_equals_oracle(args):
         assert g["reach"][d] * 2 * binsize >= o.param("cutneigh") - 1e-12 or (2 * g["reach"][d] - 1) * binsize >= o.param("cutneigh")
         assert (2 * g["reach"][d] - 1) * binsize + binsize >= o.param("cutneigh")
     h.close(); o.close()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ref"), reason="needs the reference headers (build container only)")
+def test_documented_force_plugin_compiles_against_the_reference_headers():
+    """tests/integration/force_hip.h (class ForceHIP : public Force) against ref/force.h:40-69, both precisions"""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(REPO, "tests", "integration"), "check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    assert "tests/integration/force_hip.h" in text
