@@ -671,6 +671,8 @@ __device__ __forceinline__ unsigned nb2_shift_in(unsigned bits, unsigned long lo
   return bits;
 }
 
+typedef float nb2_f2 __attribute__((ext_vector_type(2)));
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, const int* __restrict__ binned,
                                                    const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    unsigned short* __restrict__ tile_self, int* __restrict__ tile_rowmax,
                                                    int* __restrict__ tile_rowsum, int* __restrict__ flags, int ablate)
 {
-  __shared__ int rng_start[128], rng_pref[130];
+  __shared__ int rng_start[128], rng_len[128];
   __shared__ __align__(16) float s_x[NB2_BUF], s_y[NB2_BUF], s_z[NB2_BUF];      // (PF: relative to the tile's corner)
   __shared__ int s_cj[NB2_BUF];                       // candidate's atom index (| NB2_LEX)
   __shared__ unsigned char s_own[NB2_BUF];            // which tile atom the candidate is (0xff: none)
@@ -693,12 +695,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   if(tile < 0) return;
   const int b = tile_block[tile];
   const int ta = tile_first[tile], tcn = tile_cnt[tile];
-  const int a0 = bin_start[b * 8];
   const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
   // ---- candidate slices: for every (dz,dy) one contiguous run of blocks [bx-R, bx+R] in binned[]
   const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
   const int nr = min(ny * nz, 128);
-  int carry = 0;
   for(int r0 = 0; r0 < nr; r0 += 64) {
     const int r = r0 + lane;
     int len = 0, start = 0;
@@ -710,18 +710,12 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         start = bin_start[(row + x0) * 8];
         len = bin_start[(row + x1) * 8 + 8] - start;
       }
+      rng_start[r] = start; rng_len[r] = len;
     }
-    const int incl = wave_incl_scan(len);
-    if(r < nr) { rng_start[r] = start; rng_pref[r] = carry + incl - len; }
-    carry += __shfl(incl, 63, 64);
   }
-  if(lane == 0) rng_pref[nr] = carry;
   s_self[lane] = (unsigned short)0xffff;
   s_selfpos[lane] = (unsigned short)0xffff;
   __syncthreads();
-  const int total = __builtin_amdgcn_readfirstlane(rng_pref[nr]);
-  const int rc = g.reach[2] * ny + g.reach[1];                   // the block's own (y,z) row
-  const int selfbase = __builtin_amdgcn_readfirstlane((rc < nr ? rng_pref[rc] + (a0 - rng_start[rc]) : -(1 << 30)) + (ta - a0));   // sequence position of tile atom 0
   // ---- my atom
   const int ii = lane < tcn ? binned[ta + lane] : -1;
   const bool owned = ii >= 0 && ii < nlocal;
@@ -749,17 +743,6 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float cut_lo = (float)cutneighsq - eps, cut_hi = (float)cutneighsq + eps;
   // lanes without an owned atom sit far away on the other side of the padding candidates: never a hit
   const float fxi = owned ? (float)(pme.x - ox) : -1.0e15f, fyi = owned ? (float)(pme.y - oy) : -1.0e15f, fzi = owned ? (float)(pme.z - oz) : -1.0e15f;
-  // branch-free slice addressing (<= NB_FASTR slices): sequence position t lives at binned[t + D(slice of t)]
-  int pq[NB_FASTR], dq[NB_FASTR];
-#pragma unroll
-  for(int q = 0; q < NB_FASTR; q++) {
-    const int d_here = q < nr ? rng_start[q] - rng_pref[q] : 0;
-    const int d_prev = (q > 0 && q < nr) ? rng_start[q - 1] - rng_pref[q - 1] : 0;
-    pq[q] = __builtin_amdgcn_readfirstlane(q < nr ? rng_pref[q] : 0x7fffffff);
-    dq[q] = __builtin_amdgcn_readfirstlane(q < nr ? d_here - d_prev : 0);
-  }
-  const bool fast = nr <= NB_FASTR;
-
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int n = 0;                               // my row length
   bool any_ghost = false;
@@ -778,42 +761,51 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0;
       for(int q = 0; q < G; q += 8) {
-        float cx[8], cy[8], cz[8];
+        // 8 buffered candidates per trip: 6 ds_read_b128 (uniform addresses). On this part a VALU instruction costs a
+        // wavefront the same issue slot whether it is 32 or 64 bits wide, but v_pk_*_f32 handles TWO floats per lane: the
+        // pre-test's rsq of two candidates takes 6 packed instructions (DP: a conservative filter, so fma is welcome).
         const float4* vx = (const float4*)&s_x[gq + q];
         const float4* vy = (const float4*)&s_y[gq + q];
         const float4* vz = (const float4*)&s_z[gq + q];
+        nb2_f2 cx2[4], cy2[4], cz2[4];
 #pragma unroll
         for(int u = 0; u < 2; u++) {
           const float4 tx = vx[u], ty = vy[u], tz = vz[u];
-          cx[4 * u] = tx.x; cx[4 * u + 1] = tx.y; cx[4 * u + 2] = tx.z; cx[4 * u + 3] = tx.w;
-          cy[4 * u] = ty.x; cy[4 * u + 1] = ty.y; cy[4 * u + 2] = ty.z; cy[4 * u + 3] = ty.w;
-          cz[4 * u] = tz.x; cz[4 * u + 1] = tz.y; cz[4 * u + 2] = tz.z; cz[4 * u + 3] = tz.w;
+          cx2[2 * u] = nb2_f2{tx.x, tx.y}; cx2[2 * u + 1] = nb2_f2{tx.z, tx.w};
+          cy2[2 * u] = nb2_f2{ty.x, ty.y}; cy2[2 * u + 1] = nb2_f2{ty.z, ty.w};
+          cz2[2 * u] = nb2_f2{tz.x, tz.y}; cz2[2 * u + 1] = nb2_f2{tz.z, tz.w};
         }
+        const nb2_f2 X2 = {fxi, fxi}, Y2 = {fyi, fyi}, Z2 = {fzi, fzi};
 #pragma unroll
-        for(int u = 0; u < 8; u++) {
-          const float dx = fxi - cx[u], dy = fyi - cy[u], dz = fzi - cz[u];
-          unsigned long long m, mh = 0;
-          if(NB2_PF) {
-            const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            m = __builtin_amdgcn_fcmpf(rsq, cut_lo, 5 /* ordered <= */);
-            mh = __builtin_amdgcn_fcmpf(rsq, cut_hi, 5);
-          } else {
-            const float rsq = dx * dx + dy * dy + dz * dz;        // (no contraction in this file: rounds like the reference)
-            m = __builtin_amdgcn_fcmpf(rsq, (float)cutneighsq, 5 /* ordered <= : ref/neighbor.cpp:165,179 */);
-          }
-          if(MODE != 0) {
-            const int cju = __builtin_amdgcn_readfirstlane(s_cj[gq + q + u]);
-            unsigned long long rule;
-            if(MODE == 2 && (cju & NB2_LEX)) {
-              // (z,y,x) order on the exact positions (ref/neighbor.cpp:155-157)
-              const real4 pj = x[cju & ~NB2_LEX];
-              rule = __builtin_amdgcn_ballot_w64(owned && !(pj.z < pme.z || (pj.z == pme.z && pj.y < pme.y) || (pj.z == pme.z && pj.y == pme.y && pj.x < pme.x)));
+        for(int u2 = 0; u2 < 4; u2++) {
+          const nb2_f2 dx = X2 - cx2[u2], dy = Y2 - cy2[u2], dz = Z2 - cz2[u2];
+          nb2_f2 rsq2;
+          if(NB2_PF) rsq2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+          else rsq2 = dx * dx + dy * dy + dz * dz;                 // (no contraction in this file: rounds like the reference)
+#pragma unroll
+          for(int hlf = 0; hlf < 2; hlf++) {
+            const int u = 2 * u2 + hlf;
+            const float rsq = hlf ? rsq2.y : rsq2.x;
+            unsigned long long m, mh = 0;
+            if(NB2_PF) {
+              m = __builtin_amdgcn_fcmpf(rsq, cut_lo, 5 /* ordered <= */);
+              mh = __builtin_amdgcn_fcmpf(rsq, cut_hi, 5);
             } else
-              rule = __builtin_amdgcn_sicmp(cju, ii, 38 /* signed > */);
-            m &= rule; mh &= rule;
+              m = __builtin_amdgcn_fcmpf(rsq, (float)cutneighsq, 5 /* ordered <= : ref/neighbor.cpp:165,179 */);
+            if(MODE != 0) {
+              const int cju = __builtin_amdgcn_readfirstlane(s_cj[gq + q + u]);
+              unsigned long long rule;
+              if(MODE == 2 && (cju & NB2_LEX)) {
+                // (z,y,x) order on the exact positions (ref/neighbor.cpp:155-157)
+                const real4 pj = x[cju & ~NB2_LEX];
+                rule = __builtin_amdgcn_ballot_w64(owned && !(pj.z < pme.z || (pj.z == pme.z && pj.y < pme.y) || (pj.z == pme.z && pj.y == pme.y && pj.x < pme.x)));
+              } else
+                rule = __builtin_amdgcn_sicmp(cju, ii, 38 /* signed > */);
+              m &= rule; mh &= rule;
+            }
+            bits = nb2_shift_in(bits, m);
+            if(NB2_PF) bits_hi = nb2_shift_in(bits_hi, mh);
           }
-          bits = nb2_shift_in(bits, m);
-          if(NB2_PF) bits_hi = nb2_shift_in(bits_hi, mh);
         }
       }
       // pass q of the group sits at bit G-1-q
@@ -844,7 +836,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       }
       any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && (s_cj[gq + lane] & ~NB2_LEX) >= nlocal) != 0ull;
       // ---- expansion: every lane turns its set bits into row entries; branch-free, as many rounds as the fullest word holds
-      const int rounds = wave_max_i(__popc(bits));
+      const int rounds = (int)wave_max_u((unsigned)__popc(bits));
       unsigned bb = bits;
       for(int it = 0; it < rounds; it++) {
         const bool v = bb != 0u;
@@ -861,31 +853,28 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     fill = 0;
   };
 
-  // ---- phase 1: stream the candidates
-  const int nchunks = (ablate & 8) ? 0 : (total + 63) >> 6;
-  for(int c0 = 0; c0 < nchunks; c0 += NB2_BATCH) {
-    int jj[NB2_BATCH];
-    if(fast) {
+  // ---- phase 1: stream the candidates, slice by slice (a slice = one contiguous run of binned[]: no per-element address
+  // search; chunks are the 64-entry pieces of the slices, the last piece of a slice is partly empty)
+  int r = -1, off = 0, len_r = 0, start_r = 0;          // wave-uniform cursor over the slices
+  const int nr_eff = (ablate & 8) ? 0 : nr;
+  for(;;) {
+    int jj[NB2_BATCH], aa[NB2_BATCH];
+    bool more = false;
 #pragma unroll
-      for(int u = 0; u < NB2_BATCH; u++) {
-        const int gt = (c0 + u) * 64 + lane;
-        int addr = gt;
-#pragma unroll
-        for(int q = 0; q < NB_FASTR; q++) addr += gt >= pq[q] ? dq[q] : 0;
-        jj[u] = gt < total ? binned[addr] : -1;
+    for(int u = 0; u < NB2_BATCH; u++) {
+      while(r < nr_eff && off >= len_r) {               // next non-empty slice (scalar unit)
+        r++; off = 0;
+        if(r < nr_eff) { len_r = __builtin_amdgcn_readfirstlane(rng_len[r]); start_r = __builtin_amdgcn_readfirstlane(rng_start[r]); }
+        else len_r = 0;
       }
-    } else {
-      int r = 0;
-#pragma unroll
-      for(int u = 0; u < NB2_BATCH; u++) {
-        const int gt = (c0 + u) * 64 + lane;
-        jj[u] = -1;
-        if(gt < total) {
-          while(r + 1 < nr && rng_pref[r + 1] <= gt) r++;
-          jj[u] = binned[rng_start[r] + (gt - rng_pref[r])];
-        }
+      jj[u] = -1; aa[u] = -1;
+      if(r < nr_eff) {
+        more = true;
+        if(off + lane < len_r) { aa[u] = start_r + off + lane; jj[u] = binned[aa[u]]; }
+        off += 64;
       }
     }
+    if(!more) break;
     real4 pp[NB2_BATCH];
     int code[NB2_BATCH];
 #pragma unroll
@@ -895,44 +884,43 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     }
 #pragma unroll
     for(int u = 0; u < NB2_BATCH; u++) {
-      if(c0 + u < nchunks) {
-        const int j = jj[u];
-        bool keep = j >= 0 && !(ablate & 16);
-        int cjv = j;
-        if(MODE != 0) keep = keep && (j >= nlocal || j > imin);            // an owned j <= every tile atom is nobody's j > i
-        if(MODE == 2 && j >= nlocal) {
-          const int sx = code[u] % 5 - 2, sy = (code[u] / 5) % 5 - 2, sz = code[u] / 25 - 2;
-          if(sx == 0 && sy == 0 && sz == 0) cjv = j | NB2_LEX;
-          else if(!(sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0))))) keep = false;    // the mirrored pair keeps it
+      const int j = jj[u];
+      bool keep = j >= 0 && !(ablate & 16);
+      int cjv = j;
+      if(MODE != 0) keep = keep && (j >= nlocal || j > imin);            // an owned j <= every tile atom is nobody's j > i
+      if(MODE == 2 && j >= nlocal) {
+        const int sx = code[u] % 5 - 2, sy = (code[u] / 5) % 5 - 2, sz = code[u] / 25 - 2;
+        if(sx == 0 && sy == 0 && sz == 0) cjv = j | NB2_LEX;
+        else if(!(sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0))))) keep = false;    // the mirrored pair keeps it
+      }
+      const float fx = (float)pp[u].x, fy = (float)pp[u].y, fz = (float)pp[u].z;
+      const float ddx = fmaxf(fmaxf(bx0 - fx, fx - bx1), 0.0f);
+      const float ddy = fmaxf(fmaxf(by0 - fy, fy - by1), 0.0f);
+      const float ddz = fmaxf(fmaxf(bz0 - fz, fz - bz1), 0.0f);
+      keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+      if(m) {
+        const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if(keep) {
+          s_x[pos] = (float)(pp[u].x - ox); s_y[pos] = (float)(pp[u].y - oy); s_z[pos] = (float)(pp[u].z - oz);
+          s_cj[pos] = cjv;
+          const unsigned own = (unsigned)(aa[u] - ta);                   // the tile's own atoms are binned[ta .. ta+63]
+          if(MODE != 0) s_own[pos] = own < 64u ? (unsigned char)own : (unsigned char)0xff;
+          if(MODE == 0 && own < 64u) s_selfpos[own] = (unsigned short)pos;
         }
-        const float fx = (float)pp[u].x, fy = (float)pp[u].y, fz = (float)pp[u].z;
-        const float ddx = fmaxf(fmaxf(bx0 - fx, fx - bx1), 0.0f);
-        const float ddy = fmaxf(fmaxf(by0 - fy, fy - by1), 0.0f);
-        const float ddz = fmaxf(fmaxf(bz0 - fz, fz - bz1), 0.0f);
-        keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if(m) {
-          const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-          if(keep) {
-            s_x[pos] = (float)(pp[u].x - ox); s_y[pos] = (float)(pp[u].y - oy); s_z[pos] = (float)(pp[u].z - oz);
-            s_cj[pos] = cjv;
-            const unsigned own = (unsigned)((c0 + u) * 64 + lane - selfbase);
-            s_own[pos] = own < 64u ? (unsigned char)own : (unsigned char)0xff;
-            if(MODE == 0 && own < 64u) s_selfpos[own] = (unsigned short)pos;
-          }
-          fill += __popcll(m);
-        }
+        fill += __popcll(m);
       }
     }
-    if(fill > NB2_BUF - 64 * NB2_BATCH || c0 + NB2_BATCH >= nchunks) flush();     // (one copy of the test code: flushed between batches only)
+    if(fill > NB2_BUF - 64 * NB2_BATCH) flush();        // (one copy of the test code: flushed between batches only)
   }
+  flush();
 
   // ---- rows are complete: pad them with the dummy slot (= S, staged by the force kernels behind the candidates)
-  const int maxn = wave_max_i(n);
+  const int maxn = (int)wave_max_u((unsigned)n);
   int kmax = (maxn + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD;
   if(kmax > maxneighs) kmax = maxneighs;
   const unsigned short dummy = (unsigned short)(S * NB_SLOT_BYTES);
-  const int nmin = min(-wave_max_i(-n), kmax);
+  const int nmin = min((int)wave_min_u((unsigned)n), kmax);
   for(int k = nmin; k < kmax && !(ablate & 4); k++) if(k >= n) rowp[(unsigned)k * 64u] = dummy;
   if(owned) numneigh[ii] = n;
   if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = owned ? s_self[lane] : (unsigned short)0xffff;
