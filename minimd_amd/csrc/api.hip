@@ -39,6 +39,7 @@ extern "C" int mmd_create(int device, mmd_handle** out)
   HIP_TRY(hipHostMalloc((void**)&h->h_result, 32 * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&h->d_result, 32 * sizeof(double)));
   HIP_TRY(hipHostMalloc((void**)&h->h_flags, 32 * sizeof(int), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&h->h_flags_big, 64 * sizeof(int), hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&h->d_flags, 32 * sizeof(int)));
   HIP_TRY(hipMemset(h->d_result, 0, 32 * sizeof(double)));
   HIP_TRY(hipMemset(h->d_flags, 0, 32 * sizeof(int)));
@@ -60,13 +61,14 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->tile_cand.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
   for(auto& s : h->swaps) s.sendlist.release();
-  h->buf_send.release(); h->buf_recv.release(); h->flag_tmp.release(); h->bnd_list.release(); h->partials.release();
+  h->buf_send.release(); h->buf_recv.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if(h->ev_x_ready) { (void)hipEventDestroy(h->ev_x_ready); (void)hipEventDestroy(h->ev_halo_done); }
   h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release();
   if(h->h_result) (void)hipHostFree(h->h_result);
   if(h->d_result) (void)hipFree(h->d_result);
   if(h->h_flags) (void)hipHostFree(h->h_flags);
+  if(h->h_flags_big) (void)hipHostFree(h->h_flags_big);
   if(h->d_flags) (void)hipFree(h->d_flags);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   if(h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
@@ -131,17 +133,32 @@ static int ev_end(mmd_handle* h)
   h->ev_used++;
   return 0;
 }
-static int ev_collect(mmd_handle* h)
+// kinds 2 / 3: the Comm (exchange + sort + borders) and Neighbor::build phases of a re-neighboring (TIME_COMM + TIME_TEST / TIME_NEIGH).
+// sync = false collects only the pairs that have already completed (no host wait) and keeps the others in the pool.
+static int ev_collect(mmd_handle* h, bool sync = true)
 {
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  if(h->comm_stream) HIP_TRY(hipStreamSynchronize(h->comm_stream));
+  if(sync) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if(h->comm_stream) HIP_TRY(hipStreamSynchronize(h->comm_stream));
+  }
+  size_t keep = 0;
   for(size_t i = 0; i < h->ev_used; i++) {
+    if(!sync && hipEventQuery(h->ev_pool[i].b) != hipSuccess) {      // still in flight: keep the pair
+      std::swap(h->ev_pool[keep], h->ev_pool[i]);
+      keep++;
+      continue;
+    }
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
-    if(h->ev_pool[i].kind == 0) { h->force_ms += ms; h->force_launches++; }
-    else h->comm_ms += ms;
+    switch(h->ev_pool[i].kind) {
+      case 0: h->force_ms += ms; h->force_launches++; break;
+      case 1: h->comm_ms += ms; break;
+      case 2: h->timer[1] += ms * 1e-3; h->timer[4] += ms * 1e-3; break;     // ref/integrate.cpp:155-166
+      default: h->timer[3] += ms * 1e-3; break;
+    }
   }
-  h->ev_used = 0;
+  h->ev_used = keep;
+  (void)hipGetLastError();                     // (hipEventQuery reports "not ready" through the sticky error too)
   return 0;
 }
 
@@ -176,7 +193,6 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   h->force_ms = 0; h->comm_ms = 0; h->force_launches = 0; h->ev_used = 0;
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double t_start = mmd_wall();
-  double t_prev;
   // host-side phase clocks need the device drained at phase boundaries only when a phase is to be
   // attributed; kernels are enqueued asynchronously, so the COMM/NEIGH/FORCE buckets are sampled
   // with a stream sync on re-neighbor steps (where the host must read counts anyway) and on thermo steps.
@@ -187,7 +203,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   bool initial_done = false;        // initialIntegrate of this step already ran fused with the previous finalIntegrate
   // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
   const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport) && h->style == 0 && !h->halfneigh;
-  bool halo_pending = false;
+  bool halo_pending = false, collect_pending = false;
   int evflag_pending = 0;
   const bool fuse_force = h->opt_fuse >= 2 && !reverse && !h->halfneigh;
   bool fused_force = false;          // this step's force launch carries finalIntegrate + the next initialIntegrate
@@ -229,7 +245,6 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         if(h->time_force_events) MMD_TRY(ev_end(h));
       }
     } else {
-      MMD_TRY(ev_collect(h));                  // drains the stream; keeps the event pool at <= neigh_every pairs
       if(h->opt_check_exchange && h->xold_n == h->nlocal) {    // ref/integrate.cpp:112-151 (warning text as there)
         double d_max = 0;
         MMD_TRY(mmd_integrate_max_move(h, &d_max));
@@ -239,19 +254,21 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
                  "Increase reneighboring frequency or choose a different processor grid\n"
                  "Maximum move distance: %lf; Subdomain dimensions: %lf %lf %lf\n", d_max, sx, sy, sz);
       }
-      t_prev = mmd_wall();
-      MMD_TRY(mmd_comm_exchange(h));
-      if(first_step + n + 1 >= h->next_sort) { MMD_TRY(mmd_atom_sort(h)); h->next_sort += h->sort_every; }
-      MMD_TRY(mmd_comm_borders(h));
+      // phase clocks are event pairs on the stream (no host synchronisation just to read a clock); the pairs that have
+      // completed are folded into the timers after the build, whose own count read-back has drained the stream anyway
+      h->in_reneighbor = true;
+      int rc = ev_begin(h, 2);
+      if(rc >= 0) rc = mmd_comm_exchange(h);
+      if(rc >= 0 && first_step + n + 1 >= h->next_sort) { rc = mmd_atom_sort(h); h->next_sort += h->sort_every; }
+      if(rc >= 0) rc = mmd_comm_borders(h);
+      h->in_reneighbor = false;
+      MMD_TRY(rc);
       if(h->opt_check_exchange) MMD_TRY(mmd_integrate_mark_positions(h));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      double t = mmd_wall();
-      h->timer[4] += t - t_prev; h->timer[1] += t - t_prev;     // TIME_TEST and TIME_COMM (ref :155-166)
-      t_prev = t;
+      MMD_TRY(ev_end(h));
+      MMD_TRY(ev_begin(h, 3));
       MMD_TRY(mmd_neighbor_build(h));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      t = mmd_wall();
-      h->timer[3] += t - t_prev;
+      MMD_TRY(ev_end(h));
+      collect_pending = true;                  // (folded into the timers once this step's force kernel is in flight)
     }
     const int step = first_step + n + 1;
     const int evflag = thermo_nstat > 0 && (step % thermo_nstat == 0);
@@ -285,6 +302,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       MMD_TRY(mmd_integrate_final_initial(h));
       initial_done = true;
     } else MMD_TRY(mmd_integrate_final(h));
+    if(collect_pending) { MMD_TRY(ev_collect(h, false)); collect_pending = false; }      // host work under the force kernel
     if(evflag) {
       MMD_TRY(mmd_temperature_async(h, 2));
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -171,9 +171,11 @@ extern "C" int mmd_atom_sort(mmd_handle* h)
   hipLaunchKernelGGL(k_sort_permute, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->binned.p, n, h->x.p, h->v.p, h->type.p,
                      h->tag.p, h->x_alt.p, h->v_alt.p, h->type_alt.p, h->tag_alt.p);
   HIP_TRY(hipGetLastError());
-  // ghosts (+ dummy slot) ride along unchanged; Comm::borders normally rebuilds them right after
-  HIP_TRY(hipMemcpyAsync(h->x_alt.p + n, h->x.p + n, ((size_t)h->nghost + 1) * sizeof(real4), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->type_alt.p + n, h->type.p + n, (size_t)h->nghost * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  // ghosts (+ dummy slot) ride along unchanged — except inside Integrate::run, where Comm::borders rebuilds them right after
+  if(!h->in_reneighbor) {
+    HIP_TRY(hipMemcpyAsync(h->x_alt.p + n, h->x.p + n, ((size_t)h->nghost + 1) * sizeof(real4), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->type_alt.p + n, h->type.p + n, (size_t)h->nghost * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  }
   std::swap(h->x, h->x_alt);
   std::swap(h->v, h->v_alt);
   std::swap(h->type, h->type_alt);

@@ -594,7 +594,7 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
       h->nlocal += nkeep;
     }
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if(h->nprocs > 1) HIP_TRY(hipStreamSynchronize(h->stream));     // (the scratch arrays below are only allocated when a dimension is split)
   leavers.release(); fillers.release(); keep.release();
   return 0;
 }
@@ -654,11 +654,232 @@ __global__ __launch_bounds__(256) void k_ghost_types(const real4* __restrict__ x
   type[first + k] = (int)x[first + k].w;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One-rank fast path of Comm::borders: every swap is a periodic self swap, so nothing but the final counts has to reach the
+// host. The six swaps run as count / scatter kernel pairs whose ranges, offsets and running ghost count live in device
+// memory (`bst`), sized by the previous re-neighboring's counts (+50 %); ONE synchronisation at the end reads the counts and an
+// overflow flag (then the general path below redoes the work with grown arrays). Same selections in the same order as
+// the general path => identical send lists and ghosts. bst layout (ints):
+//   [0] nb = owned atoms inside any send slab   [1] overflow flag   [4+s] sendnum of swap s   [30+s] ghosts before swap s
+// ---------------------------------------------------------------------------------------------------
+#define BST_NB 0
+#define BST_OVF 1
+#define BST_SEND 4
+#define BST_GHOSTS 30
+struct SlabSet { real lo[6], hi[6]; int dim[6]; int n; };
+
+__device__ __forceinline__ bool in_any_slab(const real4 p, const SlabSet& S)
+{
+  bool in = false;
+  for(int s = 0; s < S.n; s++) { const real c = S.dim[s] == 0 ? p.x : (S.dim[s] == 1 ? p.y : p.z); in = in || (c >= S.lo[s] && c <= S.hi[s]); }
+  return in;
+}
+// sum of cnt[0..upto) by the whole workgroup (256 threads); every thread gets the result
+__device__ __forceinline__ int block_prefix_total(const int* __restrict__ cnt, int upto, int* lds /* >= 17 */)
+{
+  int v = 0;
+  for(int t = threadIdx.x; t < upto; t += 256) v += cnt[t];
+  int tot;
+  block_incl_scan(v, lds, &tot);
+  return tot;
+}
+
+__global__ __launch_bounds__(256) void k_bnd_count(const real4* __restrict__ x, int nlocal, SlabSet S, int* __restrict__ cnt)
+{
+  __shared__ int lds[17];
+  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) if(base + k < nlocal) c += in_any_slab(x[base + k], S) ? 1 : 0;
+  int tot;
+  block_incl_scan(c, lds, &tot);
+  if(threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_bnd_scatter(const real4* __restrict__ x, int nlocal, SlabSet S, const int* __restrict__ cnt,
+                                                     int* __restrict__ bnd, int* __restrict__ bst)
+{
+  __shared__ int lds[17];
+  const int off = block_prefix_total(cnt, blockIdx.x, lds);
+  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  bool fl[4];
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) { fl[k] = base + k < nlocal && in_any_slab(x[base + k], S); c += fl[k] ? 1 : 0; }
+  int tot;
+  const int inc = block_incl_scan(c, lds, &tot);
+  int pos = off + inc - c;
+#pragma unroll
+  for(int k = 0; k < 4; k++) if(fl[k]) bnd[pos++] = base + k;
+  if(blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bst[BST_NB] = off + tot;
+}
+// The two swaps of a dimension (sw0 towards -1, sw0+1 towards +1) select from the same atoms — owned boundary atoms and the
+// ghosts of the EARLIER dimensions — so one launch serves both (blockIdx.y = which of the two).
+struct SwapPair { real lo[2], hi[2], sx[2], sy[2], sz[2]; int pbc_any[2], px[2], py[2], pz[2]; int cap_list[2]; int* sendlist[2]; };
+
+__global__ __launch_bounds__(256) void k_swap_count(const real4* __restrict__ x, const int* __restrict__ bnd, const int* __restrict__ bst,
+                                                    int nlocal, int sw0, int dim, SwapPair P, int* __restrict__ cnt, int ncnt)
+{
+  __shared__ int lds[17];
+  const int y = blockIdx.y;
+  const real lo = P.lo[y], hi = P.hi[y];
+  const int nb = bst[BST_NB], n = nb + bst[BST_GHOSTS + sw0];
+  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) {
+    const int q = base + k;
+    if(q < n) {
+      const real4 p = x[q < nb ? bnd[q] : nlocal + (q - nb)];
+      const real v = dim == 0 ? p.x : (dim == 1 ? p.y : p.z);
+      c += (v >= lo && v <= hi) ? 1 : 0;
+    }
+  }
+  int tot;
+  block_incl_scan(c, lds, &tot);
+  if(threadIdx.x == 0) cnt[y * ncnt + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, const int* __restrict__ bnd, int* __restrict__ bst, int nlocal,
+                                                      int sw0, int dim, SwapPair P, const int* __restrict__ cnt, int ncnt,
+                                                      int cap_atoms, int cap_ghost, int* __restrict__ ghost_image, int* __restrict__ ghost_root,
+                                                      int* __restrict__ type)
+{
+  __shared__ int lds[17];
+  const int y = blockIdx.y;
+  const real lo = P.lo[y], hi = P.hi[y];
+  const int nb = bst[BST_NB], n = nb + bst[BST_GHOSTS + sw0];
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if((long long)blockIdx.x * CP_TILE >= n && !last) return;
+  // ghosts in front of this swap's: those of the earlier dimensions, plus ALL of the pair's first swap for the second
+  int nghost = bst[BST_GHOSTS + sw0];
+  if(y == 1) nghost += block_prefix_total(cnt, ncnt, lds);
+  const int nall = nlocal + nghost;
+  const int off = block_prefix_total(cnt + y * ncnt, blockIdx.x, lds);
+  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  bool fl[4];
+  int idx[4];
+  real4 pp[4];
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) {
+    const int q = base + k;
+    fl[k] = false; idx[k] = 0;
+    if(q < n) {
+      idx[k] = q < nb ? bnd[q] : nlocal + (q - nb);
+      pp[k] = x[idx[k]];
+      const real v = dim == 0 ? pp[k].x : (dim == 1 ? pp[k].y : pp[k].z);
+      fl[k] = v >= lo && v <= hi;
+    }
+    c += fl[k] ? 1 : 0;
+  }
+  int tot;
+  const int inc = block_incl_scan(c, lds, &tot);
+  int pos = off + inc - c;
+  bool ovf = false;
+  int* __restrict__ sendlist = P.sendlist[y];
+#pragma unroll
+  for(int k = 0; k < 4; k++) {
+    if(fl[k]) {
+      if(pos < P.cap_list[y] && nall + pos < cap_atoms && nghost + pos < cap_ghost) {
+        const int i = idx[k];
+        real4 p = pp[k];
+        if(P.pbc_any[y]) { p.x += P.sx[y]; p.y += P.sy[y]; p.z += P.sz[y]; }
+        sendlist[pos] = i;
+        x[nall + pos] = p;
+        const int code = i < nlocal ? IMAGE_NONE : ghost_image[i - nlocal];
+        ghost_image[nghost + pos] = image_add(code, P.px[y], P.py[y], P.pz[y]);
+        ghost_root[nghost + pos] = i < nlocal ? i : ghost_root[i - nlocal];
+        type[nall + pos] = (int)p.w;
+      } else ovf = true;
+      pos++;
+    }
+  }
+  if(ovf) bst[BST_OVF] = 1;
+  if(last) {                                  // (its prefix covers every other tile: off + tot is the swap's total)
+    if((long long)gridDim.x * CP_TILE < n) bst[BST_OVF] = 1;        // the launch was sized for fewer candidates than there are
+    if(threadIdx.x == 0) { bst[BST_SEND + sw0 + y] = off + tot; if(y == 1) bst[BST_GHOSTS + sw0 + 2] = nghost + off + tot; }
+  }
+}
+
+// returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
+static int borders_one_rank_fast(mmd_handle* h)
+{
+  if(h->nprocs != 1 || h->opt_force_transport || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0 || h->nlocal <= 4096) return 0;
+  for(auto& s : h->swaps) if(s.sendproc != h->me) return 0;
+  const int nlocal = h->nlocal;
+  const int est_ghost = h->prev_nghost + h->prev_nghost / 2 + 4096, est_nb = h->prev_nb + h->prev_nb / 2 + 4096;
+  MMD_TRY(mmd_ensure_atoms(h, nlocal + est_ghost + 1, true));
+  MMD_TRY(h->ghost_image.ensure((size_t)est_ghost + 8, false, h->stream));
+  MMD_TRY(h->ghost_root.ensure((size_t)est_ghost + 8, false, h->stream));
+  MMD_TRY(h->bnd_list.ensure((size_t)nlocal + 8, false, h->stream));
+  int cap_list[6];
+  for(int q = 0; q < 6; q++) {
+    const int est = h->swaps[q].sendnum + h->swaps[q].sendnum / 2 + 4096;
+    MMD_TRY(h->swaps[q].sendlist.ensure((size_t)est, false, h->stream));
+    cap_list[q] = (int)std::min<size_t>(h->swaps[q].sendlist.cap, 0x7fffffff);
+  }
+  const int cap_atoms = h->nmax, cap_ghost = (int)std::min<size_t>(std::min(h->ghost_image.cap, h->ghost_root.cap), 0x7fffffff);
+  const int nt_own = div_up(nlocal, CP_TILE), nt_sw = div_up(est_nb + est_ghost, CP_TILE);
+  MMD_TRY(h->flag_tmp.ensure((size_t)std::max(nt_own, 2 * nt_sw) + 8, false, h->stream));
+  MMD_TRY(h->bstate.ensure(64, false, h->stream));
+  HIP_TRY(hipMemsetAsync(h->bstate.p, 0, 64 * sizeof(int), h->stream));
+  SlabSet S;
+  S.n = 6;
+  for(int q = 0; q < 6; q++) { S.lo[q] = h->swaps[q].slablo; S.hi[q] = h->swaps[q].slabhi; S.dim[q] = h->swaps[q].dim; }
+  hipLaunchKernelGGL(k_bnd_count, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p);
+  hipLaunchKernelGGL(k_bnd_scatter, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bnd_list.p, h->bstate.p);
+  for(int q = 0; q < 6; q += 2) {
+    SwapPair P;
+    for(int y = 0; y < 2; y++) {
+      Swap& sw = h->swaps[q + y];
+      P.lo[y] = sw.slablo; P.hi[y] = sw.slabhi;
+      P.sx[y] = sw.pbc[0] * h->prd[0]; P.sy[y] = sw.pbc[1] * h->prd[1]; P.sz[y] = sw.pbc[2] * h->prd[2];
+      P.pbc_any[y] = sw.pbc_any; P.px[y] = sw.pbc[0]; P.py[y] = sw.pbc[1]; P.pz[y] = sw.pbc[2];
+      P.cap_list[y] = cap_list[q + y]; P.sendlist[y] = sw.sendlist.p;
+    }
+    const int dim = h->swaps[q].dim;
+    hipLaunchKernelGGL(k_swap_count, dim3(nt_sw, 2), dim3(256), 0, h->stream, h->x.p, h->bnd_list.p, h->bstate.p, nlocal, q, dim, P, h->flag_tmp.p, nt_sw);
+    hipLaunchKernelGGL(k_swap_scatter, dim3(nt_sw, 2), dim3(256), 0, h->stream, h->x.p, h->bnd_list.p, h->bstate.p, nlocal, q, dim, P,
+                       h->flag_tmp.p, nt_sw, cap_atoms, cap_ghost, h->ghost_image.p, h->ghost_root.p, h->type.p);
+  }
+  HIP_TRY(hipGetLastError());
+  static_assert(BST_GHOSTS + 6 < 40, "bst read-back window");
+  std::vector<int>& hb = h->h_bstate;
+  hb.resize(40);
+  HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));      // nb, ovf, sendnum[6], ghost prefix
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int* hf = h->h_flags_big;
+  if(hf[BST_OVF] || hf[BST_NB] > est_nb) return 0;              // estimates too small: general path (it grows the arrays)
+  int nall = nlocal;
+  for(int q = 0; q < 6; q++) {
+    Swap& s = h->swaps[q];
+    s.sendnum = s.recvnum = hf[BST_SEND + q];
+    s.firstrecv = nall;
+    nall += s.sendnum;
+  }
+  h->nghost = hf[BST_GHOSTS + 6];
+  if(nall != nlocal + h->nghost) { mmd_set_error("borders fast path: inconsistent ghost counts"); return -1; }
+  h->prev_nb = hf[BST_NB];
+  h->prev_nghost = h->nghost;
+  h->ghost_chain_ok = true;
+  return 1;
+}
+
 extern "C" int mmd_comm_borders(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
   h->nghost = 0;
+  {
+    const int rc = borders_one_rank_fast(h);
+    if(rc < 0) return rc;
+    if(rc == 1) {
+      MMD_TRY(mmd_set_dummy(h));
+      h->neigh_nlocal = 0;
+      h->tiles_ready = false;
+      return 0;
+    }
+    h->nghost = 0;
+  }
   int iswap = 0;
   MMD_TRY(h->ghost_image.ensure(1024, false, h->stream));
   MMD_TRY(h->ghost_root.ensure(1024, false, h->stream));
@@ -671,6 +892,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
     ap.x = h->x.p; ap.n = (int)h->swaps.size();
     for(int q = 0; q < ap.n; q++) { ap.lo[q] = h->swaps[q].slablo; ap.hi[q] = h->swaps[q].slabhi; ap.dim[q] = h->swaps[q].dim; }
     MMD_TRY(compact(h, ap, 0, h->nlocal, h->bnd_list, &nb));
+    h->prev_nb = nb;
   }
   for(int d = 0; d < 3; d++) {
     int nfirst = 0, nlast = 0;
@@ -751,6 +973,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
     }
   }
   MMD_TRY(mmd_set_dummy(h));
+  h->prev_nghost = h->nghost;
   h->neigh_nlocal = 0;                 // any existing neighbor list is stale now
   h->tiles_ready = false;
   return 0;

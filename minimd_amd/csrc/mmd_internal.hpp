@@ -183,7 +183,10 @@ struct mmd_handle {
   mmd_allreduce_fn host_ar = nullptr;
   void* host_ctx = nullptr;
   std::vector<char> stage_send, stage_recv;
-  DevArr<int> flag_tmp, bnd_list;
+  DevArr<int> flag_tmp, bnd_list, bstate;
+  bool big_bins = false;       // some bin holds more than NB_BIGBIN atoms: binning runs the grid-wide rank sort too
+  bool in_reneighbor = false;  // inside Integrate::run's re-neighboring: Comm::borders follows Atom::sort, ghosts need not ride along
+  int prev_nb = 0, prev_nghost = 0;   // counts of the last Comm::borders (size the device-resident one-rank path of the next one)
   // ---- Integrate
   real dt = 0, dtforce = 0;
   int neigh_every = 20, sort_every = 20;
@@ -193,6 +196,8 @@ struct mmd_handle {
   double* h_result = nullptr;  // pinned host: [0..7]
   double* d_result = nullptr;
   int* h_flags = nullptr;      // pinned host ints
+  int* h_flags_big = nullptr;  // pinned host ints (64): read-back of the device-resident borders state
+  std::vector<int> h_bstate;
   int* d_flags = nullptr;
   // ---- timers (ref/timer.h:35-40) + GPU events around the force kernel
   double timer[5] = {0, 0, 0, 0, 0};
@@ -210,6 +215,7 @@ struct mmd_handle {
 int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve);
 int mmd_set_dummy(mmd_handle* h);
 int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host);   // in-place, returns total
+int mmd_exclusive_scan_from(mmd_handle* h, const int* src, int* data, int n, int* total_host);   // src -> data (may alias)
 int mmd_bin_atoms(mmd_handle* h, int count);
 int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir);

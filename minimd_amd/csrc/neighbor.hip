@@ -121,9 +121,10 @@ __global__ __launch_bounds__(256) void k_bin_count(const real4* __restrict__ x, 
 }
 
 __global__ void k_bin_fill(const int* __restrict__ atom_bin, const int* __restrict__ atom_rank, int n, const int* __restrict__ bin_start,
-                           int* __restrict__ binned)
+                           int* __restrict__ binned, int* __restrict__ big_flag)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i == 0) *big_flag = 0;                                    // (set by k_bin_sort, the next kernel on the stream)
   if(i >= n) return;
   binned[bin_start[atom_bin[i]] + atom_rank[i]] = i;
 }
@@ -184,14 +185,16 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   MMD_TRY(h->binned.ensure((size_t)n + 1, false, h->stream));
   HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
   if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p);
-  HIP_TRY(hipMemcpyAsync(h->bin_start.p, h->bin_count.p, ((size_t)g.mbins + 1) * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-  MMD_TRY(mmd_exclusive_scan(h, h->bin_start.p, g.mbins, nullptr));
-  if(n) hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p);
-  HIP_TRY(hipMemsetAsync(h->d_flags + 12, 0, sizeof(int), h->stream));
+  MMD_TRY(mmd_exclusive_scan_from(h, h->bin_count.p, h->bin_start.p, g.mbins, nullptr));
+  hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n > 0 ? n : 1, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p, h->d_flags + 12);
   hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->d_flags + 12);
-  // (atom_bin is free again after the fill: scratch of the long-bin sort)
-  hipLaunchKernelGGL(k_bin_rank_big, dim3(128), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
-  hipLaunchKernelGGL(k_bin_copy_big, dim3(128), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
+  // bins longer than NB_BIGBIN are ordered by the grid-wide rank count (atom_bin is free again after the fill: its scratch).
+  // The two launches are skipped while no such bin has been seen: the neighbor build reads the flag k_bin_sort raises
+  // (with its own result flags) and then switches them on and bins again.
+  if(h->big_bins) {
+    hipLaunchKernelGGL(k_bin_rank_big, dim3(128), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
+    hipLaunchKernelGGL(k_bin_copy_big, dim3(128), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -359,9 +362,10 @@ __global__ void k_tile_count(const int* __restrict__ binned, const int* __restri
   ntile_of_block[b] = owned ? (a1 - a0 + 63) >> 6 : 0;
 }
 __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, const int* __restrict__ tile_of_block,
-                            int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt)
+                            int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b == 0) { flags[1] = 0; flags[3] = 0; }                   // (result flags of the build kernel that follows on the stream)
   if(b >= nblocks) return;
   const int t0 = tile_of_block[b], t1 = tile_of_block[b + 1];
   const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
@@ -1063,12 +1067,14 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
-    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p);
+    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags);
     HIP_TRY(hipGetLastError());
     for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
       MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 16 * 64, false, h->stream));   // (+ prefetch overrun of the last tile)
-      HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
-      HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
+      if(h->opt_build != 1) {             // (the production kernel needs no zeroing: k_tile_fill / k_tile_reduce write every flag)
+        HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
+      }
       const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
       const int tmode = !h->halfneigh ? 0 : (h->ghost_newton ? 2 : 1);
 #define LAUNCH_TILES(M)                                                                                                                 \
@@ -1085,7 +1091,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         hipLaunchKernelGGL(k_tile_reduce, dim3(1), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
-                           h->d_flags, (unsigned long long*)h->d_result);
+                           h->d_flags, (unsigned long long*)(h->d_flags + 4));
       } else if(lds > 64 * 1024) {        // the candidate-per-lane form keeps maxneighs x 64 raw slots in LDS
         want_tiles = false;
         break;
@@ -1095,9 +1101,14 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #undef LAUNCH_ROWS
 #undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, h->stream));     // [0..3] results, [4..5] total, [12] long-bin flag
+      if(h->opt_build != 1) HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
+      if(h->opt_build == 1) memcpy(h->h_result, h->h_flags + 4, sizeof(double));
+      if(h->h_flags[12] && !h->big_bins) {                       // a bin longer than NB_BIGBIN showed up: bin again with the rank sort on
+        h->big_bins = true;
+        return mmd_neighbor_build(h);
+      }
       if(h->h_flags[3]) { want_tiles = false; break; }           // a block has too many candidates: global-row build below
       const int maxn = h->h_flags[0];
       h->max_row = maxn;
@@ -1133,8 +1144,9 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     }
 #undef LAUNCH_BUILD
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if(h->h_flags[12] && !h->big_bins) { h->big_bins = true; return mmd_neighbor_build(h); }
     const int maxn = h->h_flags[0];
     h->max_row = maxn;
     if(maxn >= h->maxneighs) {                      // ref/neighbor.cpp:186-208

@@ -39,29 +39,29 @@ __global__ __launch_bounds__(256) void k_scan_tile_sums(const int* __restrict__ 
   if(threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ sums, int ntiles, int* __restrict__ total)
+__global__ __launch_bounds__(1024) void k_scan_sums(const int* src, int* dst, int ntiles, int* total)      // (src may be dst)
 {
   __shared__ int lds[17];
   int carry = 0;
   for(int b = 0; b < ntiles; b += 1024) {
     const int i = b + threadIdx.x;
-    const int v = i < ntiles ? sums[i] : 0;
+    const int v = i < ntiles ? src[i] : 0;
     int tot;
     const int inc = block_incl_scan(v, lds, &tot);
-    if(i < ntiles) sums[i] = carry + inc - v;
+    if(i < ntiles) dst[i] = carry + inc - v;
     carry += tot;
   }
   if(threadIdx.x == 0) *total = carry;
 }
 
-__global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ d, int n, const int* __restrict__ sums)
+__global__ __launch_bounds__(256) void k_scan_apply(const int* src, int* d, int n, const int* __restrict__ sums)   // (src may be d)
 {
   __shared__ int lds[17];
   const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
   int v[4];
   int s = 0;
 #pragma unroll
-  for(int k = 0; k < 4; k++) { v[k] = base + k < n ? d[base + k] : 0; s += v[k]; }
+  for(int k = 0; k < 4; k++) { v[k] = base + k < n ? src[base + k] : 0; s += v[k]; }
   int tot;
   const int inc = block_incl_scan(s, lds, &tot);
   int run = sums[blockIdx.x] + inc - s;
@@ -72,17 +72,18 @@ __global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ d, int n, 
   }
 }
 
-// d[n] must be writable: the grand total is also stored there (bin_start[mbins] convention)
-int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host)
+// exclusive scan of src[n] into data[n] (src == data: in place). data[n] must be writable: the grand total is also stored there
+// (bin_start[mbins] convention)
+int mmd_exclusive_scan_from(mmd_handle* h, const int* src, int* data, int n, int* total_host)
 {
-  if(n <= 16384) {            // short arrays (per-tile counts of the compactions): one workgroup scans in place
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, data, n, data + n);
+  if(n <= 32768) {            // short arrays (per-tile counts of the compactions, bins of small boxes): one workgroup
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, src, data, n, data + n);
   } else {
     const int ntiles = div_up(n, SCAN_TILE);
     MMD_TRY(h->scan_tmp.ensure((size_t)ntiles + 8, false, h->stream));
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, h->stream, data, n, h->scan_tmp.p);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, h->scan_tmp.p, ntiles, data + n);
-    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, h->stream, data, n, h->scan_tmp.p);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, h->stream, src, n, h->scan_tmp.p);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, (const int*)h->scan_tmp.p, h->scan_tmp.p, ntiles, data + n);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, h->stream, src, data, n, h->scan_tmp.p);
   }
   HIP_TRY(hipGetLastError());
   if(total_host) {
@@ -92,6 +93,7 @@ int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host)
   }
   return 0;
 }
+int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host) { return mmd_exclusive_scan_from(h, data, data, n, total_host); }
 
 // ---------------------------------------------------------------------------------------------------
 // per-atom capacity (Atom::growarray, ref/atom.cpp:71-84) — +1 slot for the dummy atom
