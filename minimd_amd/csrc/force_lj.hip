@@ -233,28 +233,53 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     constexpr int U = decltype(nu)::value;
     real xj[U], yj[U], zj[U];
 #pragma unroll
-    for(int u = 0; u < U; u++) lds_read3<RD>((unsigned)s[u], xj[u], yj[u], zj[u]);
+    for(int u = 0; u < U; u++) lds_read3<(RD == 1 ? 1 : 0)>((unsigned)s[u], xj[u], yj[u], zj[u]);
     np += U * 64;
     if(k + U < k1) {
 #pragma unroll
       for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
     }
+    // every multiply-add is written as an explicit fma: with -ffp-contract=fast the compiler would otherwise be
+    // free to pick WHICH product of a sum it fuses, and the instantiations of this template must round alike
+    // pairs are worked off in groups of four (register pressure: the second group's positions wait in their LDS-read registers)
+    constexpr bool BATCH = RD == 2 && !EXACT && (U % 4) == 0 && sizeof(real) == 8;
+    constexpr int GRP = BATCH ? 4 : 1;
 #pragma unroll
-    for(int u = 0; u < U; u++) {
-      // every multiply-add is written as an explicit fma: with -ffp-contract=fast the compiler would otherwise be
-      // free to pick WHICH product of a sum it fuses, and the instantiations of this template must round alike
-      const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
-      const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));
-      const bool in = rsq < P.cutforcesq;
-      const real sr2 = keep_if(in, EXACT ? recip<true>(rsq) : recip_fast(rsq));   // out of range => everything below is 0
-      const real A = (sr2 * sr2) * sr2;
-      const real t = fma_r(A, P.sigma6, (real)-0.5);
-      const real fs = (A * sr2) * t;               // force / c_out
-      fx = fma_r(dx, fs, fx); fy = fma_r(dy, fs, fy); fz = fma_r(dz, fs, fz);
-      if(EV) {
-        const real sr6 = A * P.sigma6;
-        e_acc = __builtin_fma((double)(sr6 * (sr6 - (real)1.0)), (double)P.epsilon, e_acc);
-        v_acc = __builtin_fma((double)rsq, (double)fs, v_acc);
+    for(int g0 = 0; g0 < U; g0 += GRP) {
+      real dx[GRP], dy[GRP], dz[GRP], rsq[GRP], sr2[GRP];
+#pragma unroll
+      for(int q = 0; q < GRP; q++) {
+        const int u = g0 + q;
+        dx[q] = xi.x - xj[u]; dy[q] = xi.y - yj[u]; dz[q] = xi.z - zj[u];
+        rsq[q] = fma_r(dz[q], dz[q], fma_r(dy[q], dy[q], dx[q] * dx[q]));
+      }
+      if(BATCH) {
+        // ONE reciprocal per FOUR pairs (the quarter-rate v_rcp_f64 and its Newton step are the costliest part of a pair):
+        // r = 1/(abcd) refined once, then 1/a = b (cd r), 1/b = a (cd r), 1/c = d (ab r), 1/d = c (ab r). The product stays far
+        // inside the double range even when all four entries are the dummy atom (rsq 3e30); not so in float, which keeps
+        // one reciprocal per pair.
+        const real p = rsq[0] * rsq[GRP > 1 ? 1 : 0], q = rsq[GRP > 2 ? 2 : 0] * rsq[GRP > 3 ? 3 : 0];
+        const real r = recip_fast(p * q);
+        const real rp = q * r, rq = p * r;                 // 1/(ab), 1/(cd)
+        sr2[0] = rsq[GRP > 1 ? 1 : 0] * rp; sr2[GRP > 1 ? 1 : 0] = rsq[0] * rp;
+        sr2[GRP > 2 ? 2 : 0] = rsq[GRP > 3 ? 3 : 0] * rq; sr2[GRP > 3 ? 3 : 0] = rsq[GRP > 2 ? 2 : 0] * rq;
+      } else {
+#pragma unroll
+        for(int q = 0; q < GRP; q++) sr2[q] = EXACT ? recip<true>(rsq[q]) : recip_fast(rsq[q]);
+      }
+#pragma unroll
+      for(int q = 0; q < GRP; q++) {
+        const bool in = rsq[q] < P.cutforcesq;
+        const real s2 = keep_if(in, sr2[q]);         // out of range => everything below is 0
+        const real A = (s2 * s2) * s2;
+        const real t = fma_r(A, P.sigma6, (real)-0.5);
+        const real fs = (A * s2) * t;               // force / c_out
+        fx = fma_r(dx[q], fs, fx); fy = fma_r(dy[q], fs, fy); fz = fma_r(dz[q], fs, fz);
+        if(EV) {
+          const real sr6 = A * P.sigma6;
+          e_acc = __builtin_fma((double)(sr6 * (sr6 - (real)1.0)), (double)P.epsilon, e_acc);
+          v_acc = __builtin_fma((double)rsq[q], (double)fs, v_acc);
+        }
       }
     }
   };
@@ -562,7 +587,7 @@ int mmd_lj_tiles_available(mmd_handle* h)
 // the production tile kernel can carry finalIntegrate(n) + initialIntegrate(n+1) (no energy/virial on that step)
 int mmd_lj_can_fuse_integrate(mmd_handle* h)
 {
-  return mmd_lj_tiles_available(h) && h->opt_tile_waves == 2 && h->opt_tile_unroll == 8 && h->opt_tile_read == 0 && !h->opt_exact_div;
+  return mmd_lj_tiles_available(h) && h->opt_tile_waves == 2 && h->opt_tile_unroll == 8 && (h->opt_tile_read == 0 || h->opt_tile_read == 2) && !h->opt_exact_div;
 }
 
 // launch the tile kernel over `count` tiles: tile ids from `list` (device) or 0..count-1
@@ -581,6 +606,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
                        count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,              \
                        h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce); }
   const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = h->opt_tile_read;
+  TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
   TK(0, 0, 2, 8, 0, 1);                                                                          // production, integrator fused
   TK(0, 0, 2, 8, 0, 0); TK(1, 0, 2, 8, 0, 0); TK(0, 1, 2, 8, 0, 0); TK(1, 1, 2, 8, 0, 0);        // production shape (+ exact-division check)
   TK(0, 0, 2, 8, 1, 0); TK(1, 0, 2, 8, 1, 0);

@@ -156,7 +156,7 @@ struct mmd_handle {
   int opt_force_transport = 0;   // testing: route self-swaps through the transport too (RCCL loop-back on one GPU)
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
   int opt_check_exchange = 0;                     // --check_exchange: warn when an atom moved further than a sub-domain
-  int opt_tile_read = 0;                          // 1: three separate 8-byte LDS reads per pair (A/B knob)
+  int opt_tile_read = 2;                          // 2: one reciprocal per four pairs (default); 0: one per pair; 1: + three separate 8-byte LDS reads per pair (A/B knobs)
   int opt_fuse = 2;          // >=1: fused final+initial integrate, single-kernel ghost update on one rank; 2: integrator inside the LJ tile kernel
   int fuse_now = 0;          // transient: the next tile launch carries the integrator
   const void* xalt_dummy_ptr[2] = {nullptr, nullptr}; int xalt_dummy_slot[2] = {-1, -1}; int xalt_dummy_next = 0;

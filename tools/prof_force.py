@@ -36,6 +36,12 @@ if a.ab:
         for v in (1, 0):
             h.set_option(a.ab, v)
             print("round %d  %s=%d  force %.4f ms" % (rnd, a.ab, v, h.profile_kernel(0, a.reps)))
+if os.environ.get("TILEREAD"):
+    for rnd in range(3):
+        for v in (0, 2):
+            h.set_option("tile_read", v)
+            print("round %d  tile_read=%d  force %.4f ms" % (rnd, v, h.profile_kernel(0, a.reps)))
+    h.set_option("tile_read", 0)
 if os.environ.get("BUILDKERNELS"):
     # A/B of the two tile-build kernels (build=1: one owned atom per lane, build=0: one candidate per lane)
     for rnd in range(2):
