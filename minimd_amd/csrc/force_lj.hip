@@ -463,25 +463,47 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
 #pragma unroll
       for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
     }
+    // groups of four pairs share ONE reciprocal in double precision (see k_lj_full_tile)
+    constexpr bool BATCH = sizeof(real) == 8;
+    constexpr int GRP = BATCH ? 4 : 1;
 #pragma unroll
-    for(int u = 0; u < U; u++) {
-      const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
-      const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));
-      if(rsq < P.cutforcesq) {                             // (also keeps the padded lanes off the dummy slot's accumulator)
-        const real sr2 = recip_fast(rsq);
-        const real A = (sr2 * sr2) * sr2;
-        const real fs = (A * sr2) * fma_r(A, P.sigma6, (real)-0.5);          // force / c_out
-        const real px = dx * fs, py = dy * fs, pz = dz * fs;
-        fx += px; fy += py; fz += pz;
-        // the partner's accumulator collects +p, negated at the flush (sc = slot * 3 reals in bytes -> slot * 3 doubles)
-        double* a = (double*)((unsigned char*)s_acc + sc[u] * (int)(sizeof(double) / sizeof(real)));
-        if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, (double)px); unsafeAtomicAdd(a + 1, (double)py); unsafeAtomicAdd(a + 2, (double)pz); }   // (ablate: profiling only)
-        if(EV) {
-          real scale = (real)1.0;
-          if(!GN) scale = s_ghost[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))] ? (real)0.5 : (real)1.0;
-          const real sr6 = A * P.sigma6;
-          e_acc += (double)(scale * ((real)4.0 * sr6 * (sr6 - (real)1.0)) * P.epsilon);
-          v_acc += (double)(scale * rsq * fs);
+    for(int g0 = 0; g0 < U; g0 += GRP) {
+      real dx[GRP], dy[GRP], dz[GRP], rsq[GRP], sr2v[GRP];
+#pragma unroll
+      for(int q = 0; q < GRP; q++) {
+        const int u = g0 + q;
+        dx[q] = xi.x - xj[u]; dy[q] = xi.y - yj[u]; dz[q] = xi.z - zj[u];
+        rsq[q] = fma_r(dz[q], dz[q], fma_r(dy[q], dy[q], dx[q] * dx[q]));
+      }
+      if(BATCH) {
+        const real p = rsq[0] * rsq[GRP > 1 ? 1 : 0], q2 = rsq[GRP > 2 ? 2 : 0] * rsq[GRP > 3 ? 3 : 0];
+        const real r = recip_fast(p * q2);
+        const real rp = q2 * r, rq = p * r;
+        sr2v[0] = rsq[GRP > 1 ? 1 : 0] * rp; sr2v[GRP > 1 ? 1 : 0] = rsq[0] * rp;
+        sr2v[GRP > 2 ? 2 : 0] = rsq[GRP > 3 ? 3 : 0] * rq; sr2v[GRP > 3 ? 3 : 0] = rsq[GRP > 2 ? 2 : 0] * rq;
+      } else {
+#pragma unroll
+        for(int q = 0; q < GRP; q++) sr2v[q] = recip_fast(rsq[q]);
+      }
+#pragma unroll
+      for(int q = 0; q < GRP; q++) {
+        const int u = g0 + q;
+        if(rsq[q] < P.cutforcesq) {                           // (also keeps the padded lanes off the dummy slot's accumulator)
+          const real sr2 = sr2v[q];
+          const real A = (sr2 * sr2) * sr2;
+          const real fs = (A * sr2) * fma_r(A, P.sigma6, (real)-0.5);          // force / c_out
+          const real px = dx[q] * fs, py = dy[q] * fs, pz = dz[q] * fs;
+          fx += px; fy += py; fz += pz;
+          // the partner's accumulator collects +p, negated at the flush (sc = slot * 3 reals in bytes -> slot * 3 doubles)
+          double* a = (double*)((unsigned char*)s_acc + sc[u] * (int)(sizeof(double) / sizeof(real)));
+          if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, (double)px); unsafeAtomicAdd(a + 1, (double)py); unsafeAtomicAdd(a + 2, (double)pz); }   // (ablate: profiling only)
+          if(EV) {
+            real scale = (real)1.0;
+            if(!GN) scale = s_ghost[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))] ? (real)0.5 : (real)1.0;
+            const real sr6 = A * P.sigma6;
+            e_acc += (double)(scale * ((real)4.0 * sr6 * (sr6 - (real)1.0)) * P.epsilon);
+            v_acc += (double)(scale * rsq[q] * fs);
+          }
         }
       }
     }
