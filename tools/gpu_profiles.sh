@@ -1,0 +1,29 @@
+#!/bin/bash
+# One gpurun call that produces the evidence kept under profiles/ (round tag = $1, default r02):
+#   bench line, kernel statistics of every BASELINE configuration, PMC passes of the hot kernels, configuration runs.
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+R=${1:-r02}
+O=gpurun_out/prof_$R
+mkdir -p $O
+python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+tail -c 600 $O/bench_n1.json
+python tools/run_configs.py > $O/configs.txt 2>&1
+cat $O/configs.txt
+stats() {   # name, command...
+  name=$1; shift
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/kt_$name -o t -- "$@" > $GRAFT_REPO_ROOT/$O/kt_$name.log 2>&1)
+  python tools/rocpd_stats.py $(find $O/kt_$name -name "*.db" | head -1) $O/kernel_stats_$name.md > /dev/null
+  head -8 $O/kernel_stats_$name.md
+}
+stats bench python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline
+for c in A Bh C Ch E; do stats $c python $GRAFT_REPO_ROOT/tools/run_one.py $c; done
+# PMC passes (each counter group its own rocprofv3 run, --kernel-trace only)
+bash tools/pmc_force.sh $O/pmc_lj_full  k_lj_full_tile   tools/prof_force.py --kernels 0 --reps 5 > $O/pmc_lj_full.txt 2>&1
+bash tools/pmc_force.sh $O/pmc_lj_half  k_lj_half_tile   tools/prof_force.py --half 1 --kernels 0 --reps 5 > $O/pmc_lj_half.txt 2>&1
+bash tools/pmc_force.sh $O/pmc_eam      "k_eam_.*_tile"  tools/prof_force.py --deck in.eam.miniMD --size 64 --kernels 0 --reps 5 > $O/pmc_eam.txt 2>&1
+bash tools/pmc_force.sh $O/pmc_build    k_build_rows     tools/prof_force.py --steps 20 --kernels 1 > $O/pmc_build.txt 2>&1
+tail -30 $O/pmc_lj_full.txt
+# keep the merge small: drop the raw rocprof trees, keep logs + summaries
+find $O -name "*.db" -delete; find $O -type d -name "kt_*" -exec rm -rf {} + 2>/dev/null; find $O -mindepth 1 -maxdepth 1 -type d -name "pmc_*" -exec rm -rf {} + 2>/dev/null
+ls -la $O
