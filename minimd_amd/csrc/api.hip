@@ -64,7 +64,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->buf_send.release(); h->buf_recv.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if(h->ev_x_ready) { (void)hipEventDestroy(h->ev_x_ready); (void)hipEventDestroy(h->ev_halo_done); }
-  h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release();
+  h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release(); h->tile_words.release();
   if(h->h_result) (void)hipHostFree(h->h_result);
   if(h->d_result) (void)hipFree(h->d_result);
   if(h->h_flags) (void)hipHostFree(h->h_flags);

@@ -144,6 +144,7 @@ struct mmd_handle {
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
   DevArr<unsigned short> tile_self;       // half lists: union slot of each tile atom itself (0xffff: not in the union)
+  DevArr<unsigned> tile_words;            // scratch of k_build_rows: per tile the hit words of its candidate groups [group][lane]
   DevArr<int> tile_rowmax, tile_rowsum;   // per tile: longest row / sum of the row lengths (reduced by k_tile_reduce)
   DevArr<int> tile_ghost, tile_order;     // per tile: references a ghost atom?; tiles ordered interior-first
   int ntiles_interior = 0;

@@ -665,6 +665,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
 #define NB2_BATCH 4            // chunks of 64 candidates in flight per batch of loads
 #define NB2_BUF 448            // LDS candidate buffer (slots); flushed between batches when fewer than 64*NB2_BATCH are free
 #define NB2_LEX 0x40000000     // MODE 2: candidate is an unshifted ghost (another rank's atom): (z,y,x) order decides
+#define NB2_NG 40              // groups of 32 tested candidates a tile may produce (more: the global-row build takes over)
 #define NB2_PF (MMD_PRECISION == 2)
 
 // bits = (bits << 1) | (my bit of m): one VALU instruction (carry-in = the compare mask)
@@ -686,13 +687,14 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    unsigned short* __restrict__ nl16, int* __restrict__ tile_cand,
                                                    int* __restrict__ tile_ncand, int* __restrict__ tile_max, int* __restrict__ tile_ghost,
                                                    unsigned short* __restrict__ tile_self, int* __restrict__ tile_rowmax,
-                                                   int* __restrict__ tile_rowsum, int* __restrict__ flags, int ablate)
+                                                   int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate)
 {
   __shared__ int rng_start[128], rng_len[128];
   __shared__ __align__(16) float s_x[NB2_BUF], s_y[NB2_BUF], s_z[NB2_BUF];      // (PF: relative to the tile's corner)
   __shared__ int s_cj[NB2_BUF];                       // candidate's atom index (| NB2_LEX)
   __shared__ unsigned char s_own[NB2_BUF];            // which tile atom the candidate is (0xff: none)
   __shared__ unsigned short s_selfpos[64];            // buffer position of each tile atom's own candidate record (0xffff: not in this buffer)
+  __shared__ uint2 s_gSU[NB2_NG];                     // per group of 32 buffered candidates: {first slot of its union members, which of the 32 are in the union}
   __shared__ unsigned short s_self[64];               // final slot of each tile atom itself (0xffff: not in the union)
   const int lane = threadIdx.x;
   const int tile = xcd_work_item(ntiles);
@@ -748,6 +750,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // lanes without an owned atom sit far away on the other side of the padding candidates: never a hit
   const float fxi = owned ? (float)(pme.x - ox) : -1.0e15f, fyi = owned ? (float)(pme.y - oy) : -1.0e15f, fzi = owned ? (float)(pme.z - oz) : -1.0e15f;
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
+  int gcount = 0;                          // groups tested so far
+  int cnt = 0;                             // my non-empty hit words so far
+  // scratch of this tile: NB2_NG x 64 words followed by NB2_NG x 64 group numbers (bytes)
+  unsigned* __restrict__ ent_w = tile_words + (size_t)tile * (NB2_NG * 80) + lane;
+  unsigned char* __restrict__ ent_g = (unsigned char*)(tile_words + (size_t)tile * (NB2_NG * 80) + NB2_NG * 64) + lane;
   int n = 0;                               // my row length
   bool any_ghost = false;
 
@@ -839,17 +846,14 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         }
       }
       any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && (s_cj[gq + lane] & ~NB2_LEX) >= nlocal) != 0ull;
-      // ---- expansion: every lane turns its set bits into row entries; branch-free, as many rounds as the fullest word holds
-      const int rounds = (int)wave_max_u((unsigned)__popc(bits));
-      unsigned bb = bits;
-      for(int it = 0; it < rounds; it++) {
-        const bool v = bb != 0u;
-        const int bq = __builtin_ctz(bb | 0x80000000u);
-        bb &= bb - 1;
-        const unsigned slot = (unsigned)S + (unsigned)__popc(used >> 1 >> bq);
-        if(v && n < maxneighs && !(ablate & 1)) rowp[(unsigned)n * 64u] = (unsigned short)(slot * NB_SLOT_BYTES);    // (ablate: profiling only)
-        n += v ? 1 : 0;
+      // ---- a lane's NON-EMPTY hit words wait, with their group numbers, in a scratch list (lane-interleaved, read back by
+      // the same lane) for the lock-step expansion at the end of the tile
+      if(gcount < NB2_NG) {
+        if(bits != 0u) { ent_w[(unsigned)cnt * 64u] = bits; ent_g[(unsigned)cnt * 64u] = (unsigned char)gcount; cnt++; }
+        if(lane == 0) s_gSU[gcount] = uint2{(unsigned)S, used};
       }
+      gcount++;
+      n += __popc(bits);
       S += __popc(used);
     }
     if(MODE == 0) s_selfpos[lane] = (unsigned short)0xffff;
@@ -919,13 +923,37 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   }
   flush();
 
-  // ---- rows are complete: pad them with the dummy slot (= S, staged by the force kernels behind the candidates)
+  // ---- lock-step expansion: in round k every lane emits the k-th entry of its row (the slot of its next set bit, or the
+  // dummy slot = S, staged by the force kernels behind the candidates, once its bits are used up), so every store is one whole
+  // 128-byte line of nl16 and the padding comes for free. A lane's words are walked in group order; s_gS / s_gU give the slot
+  // base and the union mask of a group.
   const int maxn = (int)wave_max_u((unsigned)n);
   int kmax = (maxn + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD;
   if(kmax > maxneighs) kmax = maxneighs;
   const unsigned short dummy = (unsigned short)(S * NB_SLOT_BYTES);
-  const int nmin = min((int)wave_min_u((unsigned)n), kmax);
-  for(int k = nmin; k < kmax && !(ablate & 4); k++) if(k >= n) rowp[(unsigned)k * 64u] = dummy;
+  __syncthreads();
+  {
+    // the next list entry is read one hop ahead of its use (a scratch round trip in the dependent chain of every round
+    // would be the whole kernel); s_gSU[g] = {first slot, union mask} of group g
+    unsigned w0 = 0, w1 = 0, g1 = 0, b0 = 0, u0 = 0;
+    int e = 0;                                   // list entry of w0
+    if(cnt > 0) { w0 = ent_w[0]; const uint2 su = s_gSU[ent_g[0]]; b0 = su.x; u0 = su.y; }
+    if(cnt > 1) { w1 = ent_w[64]; g1 = ent_g[64]; }
+    for(int k = 0; k < kmax && !(ablate & 1); k++) {
+      if(w0 == 0u && e + 1 < cnt) {              // (entries are non-empty: one hop always lands on a set bit)
+        e++;
+        w0 = w1;
+        const uint2 su = s_gSU[g1];
+        b0 = su.x; u0 = su.y;
+        if(e + 1 < cnt) { w1 = ent_w[(unsigned)(e + 1) * 64u]; g1 = ent_g[(unsigned)(e + 1) * 64u]; }
+      }
+      const bool v = w0 != 0u;
+      const int bq = __builtin_ctz(w0 | 0x80000000u);
+      w0 &= w0 - 1;
+      const unsigned slot = b0 + (unsigned)__popc(u0 >> 1 >> bq);
+      rowp[(unsigned)k * 64u] = v ? (unsigned short)(slot * NB_SLOT_BYTES) : dummy;
+    }
+  }
   if(owned) numneigh[ii] = n;
   if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = owned ? s_self[lane] : (unsigned short)0xffff;
   const int tsum = wave_sum(n);
@@ -938,7 +966,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     // 0.8 ms at -s 80 (same-address atomics retire one at a time, ~10 ns each)
     tile_rowmax[tile] = maxn;
     tile_rowsum[tile] = tsum;
-    if(S > cstride - 2 || (S + 1) * NB_SLOT_BYTES > 65535) atomicMax(&flags[3], 1);   // (rare) union does not fit the 16-bit slot offsets
+    if(S > cstride - 2 || (S + 1) * NB_SLOT_BYTES > 65535 || gcount > NB2_NG) atomicMax(&flags[3], 1);   // (rare) union does not fit the 16-bit slot offsets / the word scratch
   }
 }
 
@@ -1064,6 +1092,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     MMD_TRY(h->tile_ghost.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_rowmax.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_rowsum.ensure((size_t)nt + 2, false, h->stream));
+    if(h->opt_build == 1) MMD_TRY(h->tile_words.ensure((size_t)nt * NB2_NG * 80 + 64, false, h->stream));
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
@@ -1087,7 +1116,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   hipLaunchKernelGGL(k_build_rows<M>, dim3(xcd_grid(h->ntiles)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,           \
                      h->ghost_image.p, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
                      h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
-                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->d_flags, h->opt_ablate)
+                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         hipLaunchKernelGGL(k_tile_reduce, dim3(1), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,

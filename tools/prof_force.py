@@ -52,7 +52,7 @@ if os.environ.get("BUILDKERNELS"):
                 rnd, v, h.profile_kernel(1, 12), h.neighbor_tile_stats(), h.neighbor_info()["total"]))
     print("force after build=1: %.4f ms" % h.profile_kernel(0, a.reps))
 if os.environ.get("BUILDABLATE"):
-    for ab in (0, 1, 4, 5, 2, 0):
+    for ab in (0, 1, 2, 0):
         h.set_option("ablate", ab)
         print("ablate=%d  k_build_rows path: neighbor build %.4f ms" % (ab, h.profile_kernel(1, 12)))
     h.set_option("ablate", 0)
