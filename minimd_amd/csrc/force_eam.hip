@@ -407,6 +407,7 @@ template <int EV>
 __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
+    const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, int cmax, real rdr, real rdrho, real* __restrict__ fp,
     double* __restrict__ partials)
@@ -424,8 +425,9 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   // (workgroup b runs on XCD b % 8; XCD e owns the contiguous tile range [e*per, (e+1)*per))
   const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;
   for(int tq = blockIdx.x >> 3; tq < per_xcd; tq += wg_per_xcd) {
-  const int tile = (blockIdx.x & 7) * per_xcd + tq;
-  if(tile >= ntiles) break;
+  const int witem = (blockIdx.x & 7) * per_xcd + tq;          // ntiles = length of the work list (all tiles, or one part of them)
+  if(witem >= ntiles) break;
+  const int tile = tile_list ? tile_list[witem] : witem;
   __syncthreads();                                      // previous tile's readers are done with s_pos / s_part
   const int ncand = tile_ncand[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
@@ -506,6 +508,7 @@ template <int EV, int FUSE>
 __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
+    const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
     double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce)
@@ -525,8 +528,9 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   }
   const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;     // persistent workgroups, see k_eam_density_tile
   for(int tq = blockIdx.x >> 3; tq < per_xcd; tq += wg_per_xcd) {
-  const int tile = (blockIdx.x & 7) * per_xcd + tq;
-  if(tile >= ntiles) break;
+  const int witem = (blockIdx.x & 7) * per_xcd + tq;          // ntiles = length of the work list (all tiles, or one part of them)
+  if(witem >= ntiles) break;
+  const int tile = tile_list ? tile_list[witem] : witem;
   __syncthreads();
   const int ncand = tile_ncand[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
@@ -775,18 +779,43 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       h->eam_attr_set = true;
     }
-#define DT(EVv) hipLaunchKernelGGL((k_eam_density_tile<EVv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
-                                   h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \
+#define DT(EVv, LIST, CNT) hipLaunchKernelGGL((k_eam_density_tile<EVv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
+                                   h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
                                    h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p)
-#define FT(EVv, Fv) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv>), dim3(pgrid2), dim3(64 * EAM_TW), tl2, h->stream, h->x.p, h->binned.p,       \
-                                   h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt,   \
+#define FT(EVv, Fv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv>), dim3(pgrid2), dim3(64 * EAM_TW), tl2, h->stream, h->x.p, h->binned.p,       \
+                                   h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
                                    h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce)
-    if(evflag) DT(1); else DT(0);
-    HIP_TRY(hipGetLastError());
-    MMD_TRY(eam_fp_halo(h));
-    if(evflag) FT(1, 0); else if(h->fuse_now) FT(0, 1); else FT(0, 0);
+    auto density = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) DT(1, list, cnt); else DT(0, list, cnt); } };
+    auto force = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) FT(1, 0, list, cnt); else if(h->fuse_now) FT(0, 1, list, cnt); else FT(0, 0, list, cnt); } };
+    if(h->halo_pending) {
+      // overlapped step (several ranks): the position halo of this step is in flight on the communication stream (the caller
+      // recorded ev_halo_done behind it). Interior tiles — no ghost among their candidates — run under it, the boundary tiles
+      // after it; the fp halo (ForceEAM::communicate, ref/force_eam.cpp:851-887) then travels under the interior force sweep.
+      MMD_TRY(mmd_order_tiles(h));
+      const int n_int = h->ntiles_interior, n_bnd = nt - n_int;
+      density(h->tile_order.p, n_int);
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
+      density(h->tile_order.p + n_int, n_bnd);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(h->ev_x_ready, h->stream));                // (reused: "fp of the owned atoms is complete")
+      HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_x_ready, 0));
+      std::swap(h->stream, h->comm_stream);
+      const int rc = eam_fp_halo(h);
+      std::swap(h->stream, h->comm_stream);
+      MMD_TRY(rc);
+      HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
+      force(h->tile_order.p, n_int);
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
+      force(h->tile_order.p + n_int, n_bnd);
+      h->halo_pending = false;
+    } else {
+      density(nullptr, nt);
+      HIP_TRY(hipGetLastError());
+      MMD_TRY(eam_fp_halo(h));
+      force(nullptr, nt);
+    }
 #undef DT
 #undef FT
     HIP_TRY(hipGetLastError());

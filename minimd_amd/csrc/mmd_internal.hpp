@@ -160,6 +160,7 @@ struct mmd_handle {
   int opt_tile_read = 2;                          // 2: one reciprocal per four pairs (default); 0: one per pair; 1: + three separate 8-byte LDS reads per pair (A/B knobs)
   int opt_fuse = 2;          // >=1: fused final+initial integrate, single-kernel ghost update on one rank; 2: integrator inside the LJ tile kernel
   int fuse_now = 0;          // transient: the next tile launch carries the integrator
+  bool halo_pending = false; // transient: this step's position halo is in flight on the communication stream (ev_halo_done behind it)
   const void* xalt_dummy_ptr[2] = {nullptr, nullptr}; int xalt_dummy_slot[2] = {-1, -1}; int xalt_dummy_next = 0;
   int opt_ablate = 0;        // profiling only: 1 = skip LDS staging, 2 = skip the neighbor loop (results invalid)
   // ---- Force

@@ -323,12 +323,15 @@ def test_rccl_loopback_single_rank(lists):
     s.close(); o.close()
 
 
-def test_overlap_split_equals_single_launch():
-    """interior + boundary tile launches (the multi-GPU overlap path) give bit-identical forces to one launch"""
+@pytest.mark.parametrize("deck", ["in.lj.miniMD", "in.eam.miniMD"])
+def test_overlap_split_equals_single_launch(deck):
+    """interior + boundary tile launches (the multi-GPU overlap path) give bit-identical results to one launch. LJ: the
+    position halo runs on the communication stream under the interior tiles. EAM: the position halo under the interior tiles
+    of the density sweep, the fp halo (ForceEAM::communicate) under the interior tiles of the force sweep."""
     m = mm()
     rows = {}
     for ov in (1, 0):
-        s = m.Sim(["-s", 12, "-n", 60, "--half_neigh", 0])
+        s = m.Sim(["-i", deck, "-s", 12 if "lj" in deck else 8, "-n", 60, "--half_neigh", 0])
         h = s.handle
         h.init_rccl(h.unique_id(), 0, 1)
         h.set_option("force_transport", 1)
