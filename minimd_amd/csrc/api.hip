@@ -202,7 +202,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   const bool reverse = h->halfneigh && h->ghost_newton;
   bool initial_done = false;        // initialIntegrate of this step already ran fused with the previous finalIntegrate
   // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
-  const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport) && !h->halfneigh;
+  const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport);
   bool halo_pending = false, collect_pending = false;
   int evflag_pending = 0;
   const bool fuse_force = h->opt_fuse >= 2 && !reverse && !h->halfneigh;
@@ -218,7 +218,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     if((first_step + n + 1) % h->neigh_every) {
       const int step_now = first_step + n + 1;
       const int ev_now = thermo_nstat > 0 && (step_now % thermo_nstat == 0);
-      if(overlap && (h->style == 0 ? mmd_lj_tiles_available(h) : mmd_eam_can_fuse_integrate(h))) {
+      if(overlap && (h->style == 0 ? (mmd_lj_tiles_available(h) || mmd_lj_half_tiles_available(h)) : mmd_eam_can_fuse_integrate(h))) {
         // halo of this step on the communication stream, interior tiles (no ghost among their candidates)
         // concurrently on the compute stream
         HIP_TRY(hipEventRecord(h->ev_x_ready, h->stream));
@@ -230,7 +230,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         std::swap(h->stream, h->comm_stream);
         MMD_TRY(rc);
         HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
-        if(h->style == 0) {
+        if(h->style == 0 && !h->halfneigh) {
           if(h->time_force_events) MMD_TRY(ev_begin(h));
           fused_force = fuse_force && !ev_now && n + 1 < ntimes && mmd_lj_can_fuse_integrate(h);
           if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
@@ -241,7 +241,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
           halo_pending = true;
           evflag_pending = ev_now;
         } else
-          h->halo_pending = true;                // ForceEAM::compute splits both sweeps itself (force_eam.hip)
+          h->halo_pending = true;                // ForceEAM::compute / the half-list LJ dispatch split their launches themselves
       } else {
         if(h->time_force_events) MMD_TRY(ev_begin(h, 1));
         MMD_TRY(mmd_comm_communicate(h));

@@ -399,6 +399,7 @@ template <int EV, int GN>
 __global__ __launch_bounds__(128) void k_lj_half_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
+    const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, const unsigned short* __restrict__ tile_self, int nlocal, int nall, int maxneighs, int pos_bytes,
     LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate)
 {
@@ -414,8 +415,9 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   unsigned char* s_ghost = (unsigned char*)(s_red + 16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_work_item(ntiles);
-  if(tile < 0) return;
+  const int witem = xcd_work_item(ntiles);
+  if(witem < 0) return;
+  const int tile = tile_list ? tile_list[witem] : witem;
   const int ncand = tile_ncand[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
   for(int t0 = 0; t0 <= ncand; t0 += STG * NT) {              // positions in, accumulators cleared
@@ -606,6 +608,13 @@ int mmd_lj_tiles_available(mmd_handle* h)
   return h->style == 0 && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && lj_tile_pos_bytes(h) <= 60 * 1024 && h->neigh_nlocal == h->nlocal;
 }
 
+// half lists in tile form (k_lj_half_tile): uniform type tables, device-built list, positions + accumulators fit 64 KB of LDS
+int mmd_lj_half_tiles_available(mmd_handle* h)
+{
+  return h->style == 0 && h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && !h->opt_exact_div &&
+         3 * lj_tile_pos_bytes(h) + 4096 <= 64 * 1024 && h->neigh_nlocal == h->nlocal;
+}
+
 // the production tile kernel can carry finalIntegrate(n) + initialIntegrate(n+1) (no energy/virial on that step)
 int mmd_lj_can_fuse_integrate(mmd_handle* h)
 {
@@ -680,7 +689,7 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define F(EVv, Uv, Xv) if(ev == EVv && uni == Uv && ex == Xv) launch_full<EVv, Uv, (Xv != 0)>(h, nblocks, T)
     F(0, 0, 0); F(0, 0, 1); F(0, 1, 0); F(0, 1, 1); F(1, 0, 0); F(1, 0, 1); F(1, 1, 0); F(1, 1, 1);
 #undef F
-  } else if(h->tiles_ready && h->opt_tiles && uni && !ex && 3 * lj_tile_pos_bytes(h) + 4096 <= 64 * 1024) {
+  } else if(mmd_lj_half_tiles_available(h)) {
     // half lists in tile form: on-chip scatter (k_lj_half_tile)
     MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));     // ref/force_lj.cpp:286-291
     nsum = h->ntiles;
@@ -689,12 +698,24 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     const size_t acc_bytes = pos_bytes * (sizeof(double) / sizeof(real));
     const size_t lds = pos_bytes + acc_bytes + lj_tile_sf_bytes(2) + 16 * sizeof(double) + (size_t)(h->tile_cmax + 2) + 16;
     const int gn = h->ghost_newton ? 1 : 0;
-#define HT(EVv, Gv) if(ev == EVv && gn == Gv)                                                                                        \
-      hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(h->ntiles)), dim3(128), lds, h->stream, h->x.p, h->binned.p,          \
-                         h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, h->ntiles,     \
+#define HT(EVv, Gv, LIST, CNT) if(ev == EVv && gn == Gv && (CNT) > 0)                                                                \
+      hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(CNT)), dim3(128), lds, h->stream, h->x.p, h->binned.p,              \
+                         h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,  \
                          h->nl16.p, h->tile_self.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,            \
                          h->partials.p, h->opt_ablate)
-    HT(0, 0); HT(0, 1); HT(1, 0); HT(1, 1);
+#define HT4(LIST, CNT) { HT(0, 0, LIST, CNT); HT(0, 1, LIST, CNT); HT(1, 0, LIST, CNT); HT(1, 1, LIST, CNT); }
+    if(h->halo_pending) {
+      // overlapped step (several ranks): interior tiles (no ghost among their candidates) run while the position halo is in
+      // flight on the communication stream, the boundary tiles behind ev_halo_done
+      MMD_TRY(mmd_order_tiles(h));
+      const int n_int = h->ntiles_interior;
+      HT4(h->tile_order.p, n_int);
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
+      HT4(h->tile_order.p + n_int, h->ntiles - n_int);
+      h->halo_pending = false;
+    } else
+      HT4((const int*)nullptr, h->ntiles);
+#undef HT4
 #undef HT
   } else {
     MMD_TRY(mmd_ensure_rows(h));

@@ -223,6 +223,7 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_zero_forces(mmd_handle* h, int n);
 int mmd_lj_tiles_available(mmd_handle* h);
+int mmd_lj_half_tiles_available(mmd_handle* h);
 int mmd_lj_can_fuse_integrate(mmd_handle* h);
 int mmd_eam_can_fuse_integrate(mmd_handle* h);
 int mmd_prepare_x_alt(mmd_handle* h);        // second position buffer (capacity + dummy atom) for the fused force+integrate kernel

@@ -323,6 +323,26 @@ def test_rccl_loopback_single_rank(lists):
     s.close(); o.close()
 
 
+def test_overlap_split_half_lists_equal_single_launch():
+    """half lists: the interior tiles of the third-law kernel run under the position halo, the boundary tiles behind it, then the
+    reverse halo. The scatter uses floating-point atomics, so the comparison is to summation order (1e-9) instead of bit-wise."""
+    m = mm()
+    rows = {}
+    for ov in (1, 0):
+        s = m.Sim(["-s", 12, "-n", 60, "--half_neigh", 1])
+        h = s.handle
+        h.init_rccl(h.unique_id(), 0, 1)
+        h.set_option("force_transport", 1)
+        h.set_option("overlap", ov)
+        s.initial(); s.run()
+        rows[ov] = s.rows()
+        s.close()
+    for a, b in zip(rows[0], rows[1]):
+        assert a[0] == b[0]
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+
+
 @pytest.mark.parametrize("deck", ["in.lj.miniMD", "in.eam.miniMD"])
 def test_overlap_split_equals_single_launch(deck):
     """interior + boundary tile launches (the multi-GPU overlap path) give bit-identical results to one launch. LJ: the
