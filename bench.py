@@ -11,7 +11,8 @@ re-neighboring every 20 steps, thermo every 100 — i.e. exactly the loop the re
 (Integrate::run, ref/ljs.cpp:470-472). Atoms are resident in HBM when the timed region starts.
 Before the W warm-up steps the system is equilibrated for --equil steps (default 100, untimed, part of the set-up):
 the lattice has melted and the timed window sees the state SURVEY.md §8(d) names for the roofline figure (positions
-and neighbor lists "as they exist at step 100"), whatever K and W are. Re-neighboring follows the global step number,
+and neighbor lists "as they exist at step 100"), whatever K and W are; the GPU is then kept busy for --clock-warm-ms (default 400 ms,
+force-kernel launches that do not change the state) because the chip's clocks keep ramping for >100 ms after idling. Re-neighboring follows the global step number,
 so every 20 timed steps contain exactly one rebuild.
 Prints ONE JSON line on rank 0.
 """
@@ -72,6 +73,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--equil", type=int, default=100, help="untimed equilibration steps before the warm-up (set-up, see the module docstring)")
+    ap.add_argument("--clock-warm-ms", type=float, default=400.0,
+                    help="set-up: keep the GPU busy this long (force-kernel launches that leave the state untouched) so that the warm-up "
+                         "and the timed steps run at settled clocks whatever W is (the chip ramps for >100 ms after idling)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -142,6 +146,9 @@ def main():
     sim.initial()
     if args.equil > 0:
         sim.run_steps(args.equil)
+    t_w = time.perf_counter()
+    while args.clock_warm_ms > 0 and (time.perf_counter() - t_w) * 1e3 < args.clock_warm_ms:
+        sim.handle.profile_kernel(0, 100)            # Force::compute only (no integrator): positions / velocities unchanged
     if args.warmup > 0:
         sim.run_steps(args.warmup)
 
@@ -204,7 +211,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "in.lj.miniMD -s %d per GPU (global %dx%dx%d cells, %d atoms), full neighbor list, DP, "
-                               "reneigh 20, thermo 100; %d untimed equilibration steps before the warm-up" % (args.size, nx, ny, nz, natoms, args.equil),
+                               "reneigh 20, thermo 100; set-up: %d untimed equilibration steps + %.0f ms of clock warm-up before the warm-up steps" % (args.size, nx, ny, nz, natoms, args.equil, args.clock_warm_ms),
                    "parallelism": "spatial %dx%dx%d, %s" % (dims + ({"rccl": "RCCL p2p halos over xGMI", "host": "host-staged halos (debug transport)",
                                                                       "none": "single rank"}[tinfo["kind"]],)),
                    "transport": tinfo["kind"], "transport_ranks": tinfo["nranks"]},

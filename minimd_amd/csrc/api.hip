@@ -204,6 +204,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
   const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport);
   bool halo_pending = false, collect_pending = false;
+  // the per-step halos are timed (into TIME_COMM) only where they are more than one tiny kernel: an event pair costs the stream
+  // two markers, ~5 us per step that a -s 32 run would notice
+  const bool time_halo = h->time_force_events && (h->nprocs > 1 || h->opt_force_transport || reverse);
   int evflag_pending = 0;
   const bool fuse_force = h->opt_fuse >= 2 && !reverse && !h->halfneigh;
   bool fused_force = false;          // this step's force launch carries finalIntegrate + the next initialIntegrate
@@ -224,9 +227,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         HIP_TRY(hipEventRecord(h->ev_x_ready, h->stream));
         HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_x_ready, 0));
         std::swap(h->stream, h->comm_stream);
-        int rc = h->time_force_events ? ev_begin(h, 1) : 0;
+        int rc = time_halo ? ev_begin(h, 1) : 0;
         if(rc >= 0) rc = mmd_comm_communicate(h);
-        if(rc >= 0 && h->time_force_events) rc = ev_end(h);
+        if(rc >= 0 && time_halo) rc = ev_end(h);
         std::swap(h->stream, h->comm_stream);
         MMD_TRY(rc);
         HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
@@ -243,9 +246,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         } else
           h->halo_pending = true;                // ForceEAM::compute / the half-list LJ dispatch split their launches themselves
       } else {
-        if(h->time_force_events) MMD_TRY(ev_begin(h, 1));
+        if(time_halo) MMD_TRY(ev_begin(h, 1));
         MMD_TRY(mmd_comm_communicate(h));
-        if(h->time_force_events) MMD_TRY(ev_end(h));
+        if(time_halo) MMD_TRY(ev_end(h));
       }
     } else {
       if(h->opt_check_exchange && h->xold_n == h->nlocal) {    // ref/integrate.cpp:112-151 (warning text as there)
@@ -293,9 +296,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       MMD_TRY(rc);
     }
     if(reverse) {
-      if(h->time_force_events) MMD_TRY(ev_begin(h, 1));
+      if(time_halo) MMD_TRY(ev_begin(h, 1));
       MMD_TRY(mmd_comm_reverse_communicate(h));
-      if(h->time_force_events) MMD_TRY(ev_end(h));
+      if(time_halo) MMD_TRY(ev_end(h));
     }
     if(fused_force) {
       std::swap(h->x, h->x_alt);                 // the tile kernel wrote v and the next positions of every owned atom
