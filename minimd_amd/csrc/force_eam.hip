@@ -13,6 +13,7 @@
 // lane looks up a different knot each iteration; the per-atom embedding lookup reads HBM/L2 directly.
 // All type pairs share one table in miniMD (ref/force_eam.cpp:753-760) — verified at setup; otherwise the
 // general kernels index the per-pair tables in global memory.
+#include <type_traits>
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"
 #include "tile_lds.hpp"
@@ -395,7 +396,10 @@ __device__ __forceinline__ float rsqrt_fast(float a)
 // gathers from LDS only. EAM_TW wavefronts per tile split the k range of the same 64 atoms.
 // ---------------------------------------------------------------------------------------------------
 #define EAM_TW 4
-#define EAM_TU 4
+#define EAM_TU 4              // row padding granularity of the tile lists (NB_ROW_PAD) = pairs per trip of the density sweep
+#define EAM_DSTRIDE 6         // reals per knot record of the density sweep's LDS table
+#define EAM_FSTRIDE 10        // reals per knot record of the force sweep's LDS table
+#define EAM_FU 4              // pairs per trip of the force sweep (+ one trip of EAM_TU where 4 rows remain)
 #define EAM_STAGE 4
 
 // dynamic LDS of both kernels (nothing static precedes it, see tile_lds.hpp):
@@ -410,17 +414,19 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, int cmax, real rdr, real rdrho, real* __restrict__ fp,
-    double* __restrict__ partials)
+    double* __restrict__ partials, int mlo)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_TW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: the k loop runs on the scalar unit
   real* s_pos = (real*)s_raw;
-  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax));                // [knot][4]: coeffs 3..6 of rhor_spline
-  real* s_part = s_tab + (size_t)(nr + 1) * 4;
+  // knot window [mlo, nr]: pairs closer than r(mlo) (never seen in a sane system) read their knot from global memory
+  // records of EAM_DSTRIDE reals (48 B): a stride of 12 words spreads random knots over 16 bank offsets, 32-byte records over 8
+  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax));                // [knot - mlo][EAM_DSTRIDE]: coeffs 3..6 of rhor_spline, 2 unused
+  real* s_part = s_tab + (size_t)(nr + 1 - mlo) * EAM_DSTRIDE;
   double* s_red = (double*)(((size_t)(s_part + 64 * (EAM_TW - 1)) + 7) & ~(size_t)7);
-  for(int t = tid; t < (nr + 1) * 4; t += NT) s_tab[t] = rhor_spline[(t >> 2) * 7 + 3 + (t & 3)];
+  for(int t = tid; t < (nr + 1 - mlo) * 4; t += NT) s_tab[(t >> 2) * EAM_DSTRIDE + (t & 3)] = rhor_spline[((t >> 2) + mlo) * 7 + 3 + (t & 3)];
   // persistent workgroups: the knots are staged once, then the workgroup walks its share of the tiles of "its" XCD
   // (workgroup b runs on XCD b % 8; XCD e owns the contiguous tile range [e*per, (e+1)*per))
   const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;
@@ -476,8 +482,12 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
         m = m < nr - 1 ? m : nr - 1;
         p -= m;
         p = p < (real)1.0 ? p : (real)1.0;
-        const real* c = &s_tab[m * 4];
-        rhoi += fma_r(fma_r(fma_r(c[0], p, c[1]), p, c[2]), p, c[3]);
+        const real* c = &s_tab[(m > mlo ? m - mlo : 0) * EAM_DSTRIDE];
+        real c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+        if(__builtin_amdgcn_ballot_w64(m < mlo) != 0ull) {            // (rare: a pair closer than the window's first knot)
+          if(m < mlo) { const real* cg = &rhor_spline[m * 7 + 3]; c0 = cg[0]; c1 = cg[1]; c2 = cg[2]; c3 = cg[3]; }
+        }
+        rhoi += fma_r(fma_r(fma_r(c0, p, c1), p, c2), p, c3);
       }
     }
   }
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
-    double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce)
+    double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, int mlo)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_TW;
@@ -519,12 +529,16 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   real* s_pos = (real*)s_raw;
   real* s_fp = (real*)(s_raw + eam_pos_bytes(cmax));                 // fp of the candidates, indexed by slot
-  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax) + eam_fp_bytes(cmax));   // [knot][10]: rhor 0..2, z2r 0..6
-  real* s_f = s_tab + (size_t)(nr + 1) * 10;
+  // knot window [mlo, nr], records {rho' 0..2, z2r 3..6, -} of EAM_FSTRIDE reals (80 B: 20 words spread random knots over 16 bank
+  // offsets, a 64-byte stride over 4): four aligned ds_read_b128 per pair. The derivative
+  // coefficients of z2r are multiples of its value coefficients (array2spline, ref/force_eam.cpp:785-789:
+  // [0] = 3 [3] / delta, [1] = 2 [4] / delta, [2] = [5] / delta), so they are not stored: 56 instead of 80 gathered bytes.
+  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax) + eam_fp_bytes(cmax));
+  real* s_f = s_tab + (size_t)(nr + 1 - mlo) * EAM_FSTRIDE;
   double* s_red = (double*)(((size_t)(s_f + 3 * 64 * (EAM_TW - 1)) + 7) & ~(size_t)7);
-  for(int t = tid; t < (nr + 1) * 10; t += NT) {
-    const int m = t / 10, c = t % 10;
-    s_tab[t] = c < 3 ? rhor_spline[m * 7 + c] : z2r_spline[m * 7 + (c - 3)];
+  for(int t = tid; t < (nr + 1 - mlo) * 8; t += NT) {
+    const int m = (t >> 3) + mlo, c = t & 7;
+    s_tab[(t >> 3) * EAM_FSTRIDE + c] = c < 3 ? rhor_spline[m * 7 + c] : (c < 7 ? z2r_spline[m * 7 + c] : (real)0);
   }
   const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;     // persistent workgroups, see k_eam_density_tile
   for(int tq = blockIdx.x >> 3; tq < per_xcd; tq += wg_per_xcd) {
@@ -553,56 +567,84 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
-  int sl[EAM_TU];
+  int sl[EAM_FU];
 #pragma unroll
-  for(int u = 0; u < EAM_TU; u++) sl[u] = 0;
-  if(k0 < k1) {
+  for(int u = 0; u < EAM_FU; u++) sl[u] = 0;
+  if(k0 < k1) {                                   // (a slice of 4 rows reads 4 entries past it: in bounds — nl16 ends with 16 spare rows — and unused)
 #pragma unroll
-    for(int u = 0; u < EAM_TU; u++) sl[u] = np[u * 64];
+    for(int u = 0; u < EAM_FU; u++) sl[u] = np[u * 64];
   }
   __syncthreads();
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
-  for(int k = k0; k < k1; k += EAM_TU) {
-    real xj[EAM_TU], yj[EAM_TU], zj[EAM_TU], fpj[EAM_TU];
+  // one trip = U pairs of every lane, written without branches so that the U independent chains (position read -> 1/r -> knot ->
+  // coefficient gather -> Horner forms) interleave: with 2-3 wavefronts per SIMD (the knot table limits the occupancy) the LDS
+  // round trips must be hidden inside a wavefront. Out-of-range pairs and padding look up the last knot and are zeroed.
+  auto trip = [&](auto nu, int k) {
+    constexpr int U = decltype(nu)::value;
+    real xj[U], yj[U], zj[U], fpj[U];
 #pragma unroll
-    for(int u = 0; u < EAM_TU; u++) {
+    for(int u = 0; u < U; u++) {
       lds_read3<0>((unsigned)sl[u], xj[u], yj[u], zj[u]);
       fpj[u] = s_fp[(unsigned)sl[u] / (3u * (unsigned)sizeof(real))];
     }
-    np += EAM_TU * 64;
-    if(k + EAM_TU < k1) {
+    np += U * 64;
+    if(k + U < k1) {
 #pragma unroll
-      for(int u = 0; u < EAM_TU; u++) sl[u] = np[u * 64];
+      for(int u = 0; u < EAM_FU; u++) sl[u] = np[u * 64];
     }
+    real dx[U], dy[U], dz[U], rsq[U], recip[U], p[U];
+    const real* c[U];
+    bool low = false;
 #pragma unroll
-    for(int u = 0; u < EAM_TU; u++) {
-      const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
-      const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));      // explicit fma throughout: see tile_lds.hpp
-      if(rsq < cutforcesq) {
-        const real recip = rsqrt_fast(rsq);
-        const real r = rsq * recip;
-        real p = fma_r(r, rdr, (real)1.0);
-        int m = (int)p;
-        m = m < nr - 1 ? m : nr - 1;
-        p -= m;
-        p = p < (real)1.0 ? p : (real)1.0;
-        const real* c = &s_tab[m * 10];
-        const real rhoip = fma_r(fma_r(c[0], p, c[1]), p, c[2]);
-        const real z2p = fma_r(fma_r(c[3], p, c[4]), p, c[5]);
-        const real z2 = fma_r(fma_r(fma_r(c[6], p, c[7]), p, c[8]), p, c[9]);
-        const real phi = z2 * recip;
-        const real phip = fma_r(z2p, recip, -(phi * recip));
-        const real psip = fma_r(fpi, rhoip, fma_r(fpj[u], rhoip, phip));
-        real fpair = -psip * recip;
-        fx = fma_r(dx, fpair, fx); fy = fma_r(dy, fpair, fy); fz = fma_r(dz, fpair, fz);
-        if(EV) {
-          fpair *= (real)0.5;
-          v_acc += (double)(rsq * fpair);
-          e_acc += (double)((real)0.5 * phi);
+    for(int u = 0; u < U; u++) {
+      dx[u] = xi.x - xj[u]; dy[u] = xi.y - yj[u]; dz[u] = xi.z - zj[u];
+      rsq[u] = fma_r(dz[u], dz[u], fma_r(dy[u], dy[u], dx[u] * dx[u]));      // explicit fma throughout: see tile_lds.hpp
+      recip[u] = rsqrt_fast(rsq[u]);
+      real pp = fma_r(rsq[u] * recip[u], rdr, (real)1.0);
+      pp = pp < (real)nr ? pp : (real)nr;                        // (the dummy atom: keeps the conversion in range)
+      int m = (int)pp;
+      m = m < nr - 1 ? m : nr - 1;
+      pp -= m;
+      p[u] = pp < (real)1.0 ? pp : (real)1.0;
+      low = low || (m < mlo && rsq[u] < cutforcesq);
+      c[u] = &s_tab[(m > mlo ? m - mlo : 0) * EAM_FSTRIDE];
+    }
+    real r0[U], r1[U], r2[U], z3[U], z4[U], z5[U], z6[U];
+#pragma unroll
+    for(int u = 0; u < U; u++) { r0[u] = c[u][0]; r1[u] = c[u][1]; r2[u] = c[u][2]; z3[u] = c[u][3]; z4[u] = c[u][4]; z5[u] = c[u][5]; z6[u] = c[u][6]; }
+    if(__builtin_amdgcn_ballot_w64(low) != 0ull) {                // (rare: a pair closer than the window's first knot reads global memory)
+#pragma unroll
+      for(int u = 0; u < U; u++) {
+        int m = (int)fma_r(rsq[u] * recip[u], rdr, (real)1.0);
+        if(m < mlo && rsq[u] < cutforcesq) {
+          const real* cr = &rhor_spline[m * 7]; const real* cz = &z2r_spline[m * 7];
+          r0[u] = cr[0]; r1[u] = cr[1]; r2[u] = cr[2]; z3[u] = cz[3]; z4[u] = cz[4]; z5[u] = cz[5]; z6[u] = cz[6];
         }
       }
     }
+#pragma unroll
+    for(int u = 0; u < U; u++) {
+      const bool in = rsq[u] < cutforcesq;
+      const real rhoip = fma_r(fma_r(r0[u], p[u], r1[u]), p[u], r2[u]);
+      const real z2p = fma_r(fma_r(z3[u] * (real)3.0, p[u], z4[u] + z4[u]), p[u], z5[u]) * rdr;
+      const real z2 = fma_r(fma_r(fma_r(z3[u], p[u], z4[u]), p[u], z5[u]), p[u], z6[u]);
+      const real phi = z2 * recip[u];
+      const real phip = fma_r(z2p, recip[u], -(phi * recip[u]));
+      const real psip = fma_r(fpi, rhoip, fma_r(fpj[u], rhoip, phip));
+      real fpair = in ? -psip * recip[u] : (real)0;
+      fx = fma_r(dx[u], fpair, fx); fy = fma_r(dy[u], fpair, fy); fz = fma_r(dz[u], fpair, fz);
+      if(EV) {
+        fpair *= (real)0.5;
+        v_acc += (double)(rsq[u] * fpair);
+        e_acc += (double)(in ? (real)0.5 * phi : (real)0);
+      }
+    }
+  };
+  {
+    int k = k0;
+    for(; k + EAM_FU <= k1; k += EAM_FU) trip(std::integral_constant<int, EAM_FU>{}, k);
+    if(EAM_FU > EAM_TU && k < k1) trip(std::integral_constant<int, EAM_TU>{}, k);
   }
   if(wv > 0) { real* d = s_f + 3 * 64 * (wv - 1); d[lane] = fx; d[64 + lane] = fy; d[128 + lane] = fz; }
   __syncthreads();
@@ -697,13 +739,20 @@ extern "C" int mmd_force_eam_setup(mmd_handle* h, int ntypes, int nr, int nrho, 
   return 0;
 }
 
+// first knot kept in LDS: r = 0.3 x cutoff (1.5 A for Cu_u6; closer pairs read global memory)
+static int eam_mlo(const mmd_handle* h)
+{
+  int m = (int)(0.3 * sqrt((double)h->h_cutforcesq[0]) * (double)h->rdr);
+  if(h->opt_eam_mlo >= 0) m = h->opt_eam_mlo;               // (tests: push pairs onto the global-memory path)
+  return m < 1 ? 1 : (m > h->nr - 1 ? h->nr - 1 : m);
+}
 static size_t eam_tile_lds_density(const mmd_handle* h)
 {
-  return eam_pos_bytes(h->tile_cmax) + (size_t)(h->nr + 1) * 4 * sizeof(real) + (size_t)64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
+  return eam_pos_bytes(h->tile_cmax) + (size_t)(h->nr + 1 - eam_mlo(h)) * EAM_DSTRIDE * sizeof(real) + (size_t)64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
 }
 static size_t eam_tile_lds_force(const mmd_handle* h)
 {
-  return eam_pos_bytes(h->tile_cmax) + eam_fp_bytes(h->tile_cmax) + (size_t)(h->nr + 1) * 10 * sizeof(real) +
+  return eam_pos_bytes(h->tile_cmax) + eam_fp_bytes(h->tile_cmax) + (size_t)(h->nr + 1 - eam_mlo(h)) * EAM_FSTRIDE * sizeof(real) +
          (size_t)3 * 64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
 }
 static bool eam_tiles_available(const mmd_handle* h)
@@ -765,7 +814,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   // ---- tile path: LDS-staged candidates + knots (uniform tables, device-built list)
   const size_t tl1 = eam_tile_lds_density(h), tl2 = eam_tile_lds_force(h);
   if(eam_tiles_available(h)) {
-    const int nt = h->ntiles;
+    const int nt = h->ntiles, mlo = eam_mlo(h);
     MMD_TRY(h->partials.ensure((size_t)3 * nt + 8, false, h->stream));
     // persistent grids: as many workgroups as fit the LDS budget of every CU (multiple of 8 for the XCD split)
     const int cus = h->prop.multiProcessorCount;
@@ -782,11 +831,11 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define DT(EVv, LIST, CNT) hipLaunchKernelGGL((k_eam_density_tile<EVv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
-                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p)
+                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo)
 #define FT(EVv, Fv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv>), dim3(pgrid2), dim3(64 * EAM_TW), tl2, h->stream, h->x.p, h->binned.p,       \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
-                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce)
+                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo)
     auto density = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) DT(1, list, cnt); else DT(0, list, cnt); } };
     auto force = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) FT(1, 0, list, cnt); else if(h->fuse_now) FT(0, 1, list, cnt); else FT(0, 0, list, cnt); } };
     if(h->halo_pending) {

@@ -173,6 +173,7 @@ struct mmd_handle {
   int nr = 0, nrho = 0, nr_tot = 0, nrho_tot = 0;
   real rdr = 0, rdrho = 0;
   bool eam_uniform = true;
+  int opt_eam_mlo = -1;      // first spline knot kept in LDS by the EAM tile kernels (-1: 0.3 x cutoff)
   bool eam_attr_set = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this handle's device
   DevArr<real> rhor_spline, frho_spline, z2r_spline, fp, rho;
   // ---- Comm

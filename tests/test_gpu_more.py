@@ -39,10 +39,15 @@ def test_eam_force_full_matches_oracle(size, ntypes):
     assert np.abs(fp - fpo).max() <= 1e-12 * np.abs(fpo).max()      # owned AND ghost fp (halo)
     assert abs(eng - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl())
     assert abs(vir - o.virial()) <= 1e-10 * max(1.0, abs(o.virial()))
-    # device-built list gives the same physics
+    # device-built list (tile kernels: knot window in LDS, derived z2r derivative) gives the same physics ...
     h.neighbor_build()
     eng2, vir2 = h.force_compute(1)
     assert abs(eng2 - eng) <= 1e-12 * abs(eng) and np.abs(h.download()["f"] - f).max() <= 1e-11 * np.abs(fo).max()
+    # ... also when every pair takes the global-memory path meant for pairs closer than the window's first knot
+    h.set_option("eam_mlo", 100000)
+    eng3, vir3 = h.force_compute(1)
+    assert abs(eng3 - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl()) and np.abs(h.download()["f"] - fo).max() <= 1e-11 * np.abs(fo).max()
+    assert np.abs(h.eam_fp() - fpo).max() <= 1e-12 * np.abs(fpo).max()
     h.close(); o.close()
 
 
