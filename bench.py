@@ -138,7 +138,20 @@ def main():
         dims = (world, 1, 1)
     nx, ny, nz = (args.size * d for d in dims)
     sim_args = ["-i", "in.lj.miniMD", "-nx", nx, "-ny", ny, "-nz", nz, "--half_neigh", "0", "-n", args.steps]
-    sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
+    try:
+        sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
+    except Exception as e:  # noqa: BLE001
+        # the RCCL communicator could not be built (e.g. several ranks on one device): rather than no number at all, run the
+        # halos over the host-staged transport and say so in the JSON line ("transport": "host")
+        if dist is None or os.environ.get("MMD_BENCH_TRANSPORT") == "gloo":
+            raise
+        print("bench.py rank %d: RCCL path failed (%s); falling back to host-staged halos" % (rank, e), file=sys.stderr)
+        os.environ["MMD_BENCH_TRANSPORT"] = "gloo"
+        from minimd_amd import api
+        from minimd_amd.transport import GlooTransport
+        _tr = GlooTransport()
+        api.sim_set_host_transport(_tr.sendrecv, _tr.allreduce, "dp")
+        sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
     natoms = sim.natoms()
     for kv in filter(None, os.environ.get("MMD_BENCH_OPTIONS", "").split(",")):     # A/B knobs, e.g. "build_waves=1,fuse=1"
         k, v = kv.split("=")

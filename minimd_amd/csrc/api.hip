@@ -100,6 +100,8 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "tiles")) h->opt_tiles = value;
   else if(!strcmp(name, "build")) h->opt_build = value;
   else if(!strcmp(name, "eam_mlo")) h->opt_eam_mlo = value;
+  else if(!strcmp(name, "borders_fast")) h->opt_borders_fast = value;
+  else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) h->opt_ablate = value;
   else if(!strcmp(name, "fuse")) h->opt_fuse = value;

@@ -803,10 +803,12 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
 static int borders_one_rank_fast(mmd_handle* h)
 {
-  if(h->nprocs != 1 || h->opt_force_transport || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0 || h->nlocal <= 4096) return 0;
+  if(!h->opt_borders_fast || h->nprocs != 1 || h->opt_force_transport || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0 || h->nlocal <= 4096) return 0;
   for(auto& s : h->swaps) if(s.sendproc != h->me) return 0;
   const int nlocal = h->nlocal;
-  const int est_ghost = h->prev_nghost + h->prev_nghost / 2 + 4096, est_nb = h->prev_nb + h->prev_nb / 2 + 4096;
+  // (opt_borders_est: per cent of the previous counts the arrays are sized for; tests shrink it to force the overflow fallback)
+  const int est_ghost = h->opt_borders_est >= 100 ? (int)((long long)h->prev_nghost * h->opt_borders_est / 100) + 4096 : (int)((long long)h->prev_nghost * h->opt_borders_est / 100);
+  const int est_nb = h->prev_nb + h->prev_nb / 2 + 4096;
   MMD_TRY(mmd_ensure_atoms(h, nlocal + est_ghost + 1, true));
   MMD_TRY(h->ghost_image.ensure((size_t)est_ghost + 8, false, h->stream));
   MMD_TRY(h->ghost_root.ensure((size_t)est_ghost + 8, false, h->stream));
@@ -817,7 +819,8 @@ static int borders_one_rank_fast(mmd_handle* h)
     MMD_TRY(h->swaps[q].sendlist.ensure((size_t)est, false, h->stream));
     cap_list[q] = (int)std::min<size_t>(h->swaps[q].sendlist.cap, 0x7fffffff);
   }
-  const int cap_atoms = h->nmax, cap_ghost = (int)std::min<size_t>(std::min(h->ghost_image.cap, h->ghost_root.cap), 0x7fffffff);
+  int cap_atoms = h->nmax, cap_ghost = (int)std::min<size_t>(std::min(h->ghost_image.cap, h->ghost_root.cap), 0x7fffffff);
+  if(h->opt_borders_est < 100) { cap_ghost = std::min(cap_ghost, est_ghost); cap_atoms = std::min(cap_atoms, nlocal + est_ghost); }
   const int nt_own = div_up(nlocal, CP_TILE), nt_sw = div_up(est_nb + est_ghost, CP_TILE);
   MMD_TRY(h->flag_tmp.ensure((size_t)std::max(nt_own, 2 * nt_sw) + 8, false, h->stream));
   MMD_TRY(h->bstate.ensure(64, false, h->stream));

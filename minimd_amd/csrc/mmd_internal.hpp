@@ -189,6 +189,7 @@ struct mmd_handle {
   DevArr<int> flag_tmp, bnd_list, bstate;
   bool big_bins = false;       // some bin holds more than NB_BIGBIN atoms: binning runs the grid-wide rank sort too
   bool in_reneighbor = false;  // inside Integrate::run's re-neighboring: Comm::borders follows Atom::sort, ghosts need not ride along
+  int opt_borders_fast = 1, opt_borders_est = 150;    // device-resident one-rank borders on/off; its sizing estimate in per cent of the previous counts
   int prev_nb = 0, prev_nghost = 0;   // counts of the last Comm::borders (size the device-resident one-rank path of the next one)
   // ---- Integrate
   real dt = 0, dtforce = 0;

@@ -351,3 +351,32 @@ def test_structural_counts_s32():
     tot = s.handle.neighbor_info()["total"]
     assert abs(tot - ent["neigh_total"]) <= 5e-6 * ent["neigh_total"]
     s.close()
+
+
+def test_device_resident_borders_equal_the_swap_by_swap_path():
+    """one rank, 16 384 atoms: Comm::borders three ways on the same atoms — swap by swap with host-read counts (first call: nothing
+    to size the device path by), device-resident (second call: count/scatter pairs, one read-back), and device-resident with
+    arrays sized too small (overflow flag -> swap-by-swap fallback): identical counts, send lists and ghost atoms"""
+    o = Oracle(["-s", 16, "-n", 1, "--half_neigh", 0])
+    o.initial()
+    h = handle_from_oracle(o, with_ghosts=False)
+    h.comm_setup(o.param("cutneigh"), 0, 1)
+    h.exchange()
+    res = []
+    for mode in ("swap-by-swap", "device", "device-overflow"):
+        if mode == "device-overflow":
+            h.set_option("borders_est", 40)
+        h.borders()
+        d = h.download()
+        nsw = h.comm_info()["nswap"]
+        res.append((d["nghost"], d["x"].copy(), d["type"].copy(), [(h.swap_info(s_)["sendnum"], h.swap_info(s_)["recvnum"], h.swap_info(s_)["firstrecv"]) for s_ in range(nsw)], [h.sendlist(s_).copy() for s_ in range(nsw)]))
+    h.set_option("borders_est", 150)
+    assert res[0][0] == o.nghost() > 0
+    np.testing.assert_array_equal(res[0][1], o.x())
+    for other in res[1:]:
+        assert other[0] == res[0][0] and other[3] == res[0][3]
+        np.testing.assert_array_equal(other[1], res[0][1])
+        np.testing.assert_array_equal(other[2], res[0][2])
+        for a, b in zip(other[4], res[0][4]):
+            np.testing.assert_array_equal(a, b)
+    h.close(); o.close()
