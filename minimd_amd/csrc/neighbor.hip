@@ -665,6 +665,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
 #define NB2_BATCH 4            // chunks of 64 candidates in flight per batch of loads
 #define NB2_BUF 448            // LDS candidate buffer (slots); flushed between batches when fewer than 64*NB2_BATCH are free
 #define NB2_LEX 0x40000000     // MODE 2: candidate is an unshifted ghost (another rank's atom): (z,y,x) order decides
+#define NB2_NE (4 * NB2_BUF / 64)   // list entries (non-empty hit words) per lane that fit the recycled candidate buffer
 #define NB2_NG 40              // groups of 32 tested candidates a tile may produce (more: the global-row build takes over)
 #define NB2_PF (MMD_PRECISION == 2)
 
@@ -690,8 +691,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate)
 {
   __shared__ int rng_start[128], rng_len[128];
-  __shared__ __align__(16) float s_x[NB2_BUF], s_y[NB2_BUF], s_z[NB2_BUF];      // (PF: relative to the tile's corner)
-  __shared__ int s_cj[NB2_BUF];                       // candidate's atom index (| NB2_LEX)
+  // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index (| NB2_LEX) as bit pattern. Once the last
+  // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
+  __shared__ __align__(16) float s_buf[4 * NB2_BUF];
+  __shared__ unsigned char s_eg[NB2_NE * 64];         // group number of every list entry
   __shared__ unsigned char s_own[NB2_BUF];            // which tile atom the candidate is (0xff: none)
   __shared__ unsigned short s_selfpos[64];            // buffer position of each tile atom's own candidate record (0xffff: not in this buffer)
   __shared__ uint2 s_gSU[NB2_NG];                     // per group of 32 buffered candidates: {first slot of its union members, which of the 32 are in the union}
@@ -762,8 +765,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   auto flush = [&]() {
     const int fill8 = (fill + 7) & ~7;
     if(lane < fill8 - fill) {
-      s_x[fill + lane] = 1.0e15f; s_y[fill + lane] = 1.0e15f; s_z[fill + lane] = 1.0e15f;
-      s_cj[fill + lane] = (int)0x80000000;      // never > i, and not flagged NB2_LEX
+      s_buf[fill + lane] = 1.0e15f; s_buf[NB2_BUF + fill + lane] = 1.0e15f; s_buf[2 * NB2_BUF + fill + lane] = 1.0e15f;
+      s_buf[3 * NB2_BUF + fill + lane] = __int_as_float((int)0x80000000);      // never > i, and not flagged NB2_LEX
       s_own[fill + lane] = (unsigned char)0xff;
     }
     __syncthreads();
@@ -775,9 +778,9 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         // 8 buffered candidates per trip: 6 ds_read_b128 (uniform addresses). On this part a VALU instruction costs a
         // wavefront the same issue slot whether it is 32 or 64 bits wide, but v_pk_*_f32 handles TWO floats per lane: the
         // pre-test's rsq of two candidates takes 6 packed instructions (DP: a conservative filter, so fma is welcome).
-        const float4* vx = (const float4*)&s_x[gq + q];
-        const float4* vy = (const float4*)&s_y[gq + q];
-        const float4* vz = (const float4*)&s_z[gq + q];
+        const float4* vx = (const float4*)&s_buf[gq + q];
+        const float4* vy = (const float4*)&s_buf[NB2_BUF + gq + q];
+        const float4* vz = (const float4*)&s_buf[2 * NB2_BUF + gq + q];
         nb2_f2 cx2[4], cy2[4], cz2[4];
 #pragma unroll
         for(int u = 0; u < 2; u++) {
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             } else
               m = __builtin_amdgcn_fcmpf(rsq, (float)cutneighsq, 5 /* ordered <= : ref/neighbor.cpp:165,179 */);
             if(MODE != 0) {
-              const int cju = __builtin_amdgcn_readfirstlane(s_cj[gq + q + u]);
+              const int cju = __builtin_amdgcn_readfirstlane(__float_as_int(s_buf[3 * NB2_BUF + gq + q + u]));
               unsigned long long rule;
               if(MODE == 2 && (cju & NB2_LEX)) {
                 // (z,y,x) order on the exact positions (ref/neighbor.cpp:155-157)
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           while(amb) {
             const int bq = __builtin_ctz(amb);
             amb &= amb - 1;
-            const real4 pj = x[s_cj[gq + (G - 1 - bq)] & ~NB2_LEX];
+            const real4 pj = x[__float_as_int(s_buf[3 * NB2_BUF + gq + (G - 1 - bq)]) & ~NB2_LEX];
             const real dx = pme.x - pj.x, dy = pme.y - pj.y, dz = pme.z - pj.z;
             const real rsq = dx * dx + dy * dy + dz * dz;
             if(rsq <= cutneighsq) bits |= 1u << bq;
@@ -841,11 +844,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         const int bq = G - 1 - lane;
         if((used >> bq) & 1u) {
           const int slot = S + __popc(used >> 1 >> bq);           // used candidates before mine
-          if(slot < cstride - 1) tile_cand[cbase + slot] = s_cj[gq + lane] & ~NB2_LEX;
+          if(slot < cstride - 1) tile_cand[cbase + slot] = __float_as_int(s_buf[3 * NB2_BUF + gq + lane]) & ~NB2_LEX;
           if(MODE != 0) { const unsigned own = s_own[gq + lane]; if(own != 0xffu) s_self[own] = (unsigned short)slot; }
         }
       }
-      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && (s_cj[gq + lane] & ~NB2_LEX) >= nlocal) != 0ull;
+      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && (__float_as_int(s_buf[3 * NB2_BUF + gq + lane]) & ~NB2_LEX) >= nlocal) != 0ull;
       // ---- a lane's NON-EMPTY hit words wait, with their group numbers, in a scratch list (lane-interleaved, read back by
       // the same lane) for the lock-step expansion at the end of the tile
       if(gcount < NB2_NG) {
@@ -910,8 +913,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       if(m) {
         const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if(keep) {
-          s_x[pos] = (float)(pp[u].x - ox); s_y[pos] = (float)(pp[u].y - oy); s_z[pos] = (float)(pp[u].z - oz);
-          s_cj[pos] = cjv;
+          s_buf[pos] = (float)(pp[u].x - ox); s_buf[NB2_BUF + pos] = (float)(pp[u].y - oy); s_buf[2 * NB2_BUF + pos] = (float)(pp[u].z - oz);
+          s_buf[3 * NB2_BUF + pos] = __int_as_float(cjv);
           const unsigned own = (unsigned)(aa[u] - ta);                   // the tile's own atoms are binned[ta .. ta+63]
           if(MODE != 0) s_own[pos] = own < 64u ? (unsigned char)own : (unsigned char)0xff;
           if(MODE == 0 && own < 64u) s_selfpos[own] = (unsigned short)pos;
@@ -933,19 +936,29 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const unsigned short dummy = (unsigned short)(S * NB_SLOT_BYTES);
   __syncthreads();
   {
-    // the next list entry is read one hop ahead of its use (a scratch round trip in the dependent chain of every round
-    // would be the whole kernel); s_gSU[g] = {first slot, union mask} of group g
-    unsigned w0 = 0, w1 = 0, g1 = 0, b0 = 0, u0 = 0;
+    // the lanes' lists come back from the scratch into LDS (the candidate buffer is free now), a few loads in flight at a time:
+    // inside the loop a global load would put a full memory round trip into every round (s_waitcnt vmcnt(0) also waits for the
+    // row stores), LDS reads do not
+    unsigned* s_ew = (unsigned*)s_buf;
+    const int maxcnt = min((int)wave_max_u((unsigned)cnt), NB2_NE);
+    for(int e0 = 0; e0 < maxcnt; e0 += 4) {
+      unsigned tw[4], tg[4];
+#pragma unroll
+      for(int u = 0; u < 4; u++) { tw[u] = 0; tg[u] = 0; if(e0 + u < cnt) { tw[u] = ent_w[(unsigned)(e0 + u) * 64u]; tg[u] = ent_g[(unsigned)(e0 + u) * 64u]; } }
+#pragma unroll
+      for(int u = 0; u < 4; u++) if(e0 + u < NB2_NE) { s_ew[(e0 + u) * 64 + lane] = tw[u]; s_eg[(e0 + u) * 64 + lane] = (unsigned char)tg[u]; }
+    }
+    __syncthreads();
+    const int cn = min(cnt, NB2_NE);
+    unsigned w0 = 0, b0 = 0, u0 = 0;
     int e = 0;                                   // list entry of w0
-    if(cnt > 0) { w0 = ent_w[0]; const uint2 su = s_gSU[ent_g[0]]; b0 = su.x; u0 = su.y; }
-    if(cnt > 1) { w1 = ent_w[64]; g1 = ent_g[64]; }
+    if(cn > 0) { w0 = s_ew[lane]; const uint2 su = s_gSU[s_eg[lane]]; b0 = su.x; u0 = su.y; }
     for(int k = 0; k < kmax && !(ablate & 1); k++) {
-      if(w0 == 0u && e + 1 < cnt) {              // (entries are non-empty: one hop always lands on a set bit)
+      if(w0 == 0u && e + 1 < cn) {               // (entries are non-empty: one hop always lands on a set bit)
         e++;
-        w0 = w1;
-        const uint2 su = s_gSU[g1];
+        w0 = s_ew[e * 64 + lane];
+        const uint2 su = s_gSU[s_eg[e * 64 + lane]];
         b0 = su.x; u0 = su.y;
-        if(e + 1 < cnt) { w1 = ent_w[(unsigned)(e + 1) * 64u]; g1 = ent_g[(unsigned)(e + 1) * 64u]; }
       }
       const bool v = w0 != 0u;
       const int bq = __builtin_ctz(w0 | 0x80000000u);
@@ -957,6 +970,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   if(owned) numneigh[ii] = n;
   if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = owned ? s_self[lane] : (unsigned short)0xffff;
   const int tsum = wave_sum(n);
+  const bool maxcnt_over = (int)wave_max_u((unsigned)cnt) > NB2_NE;      // (a lane with more non-empty words than the LDS list holds)
   if(lane == 0) {
     tile_max[tile] = kmax;
     tile_ncand[tile] = S;
@@ -966,7 +980,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     // 0.8 ms at -s 80 (same-address atomics retire one at a time, ~10 ns each)
     tile_rowmax[tile] = maxn;
     tile_rowsum[tile] = tsum;
-    if(S > cstride - 2 || (S + 1) * NB_SLOT_BYTES > 65535 || gcount > NB2_NG) atomicMax(&flags[3], 1);   // (rare) union does not fit the 16-bit slot offsets / the word scratch
+    if(S > cstride - 2 || (S + 1) * NB_SLOT_BYTES > 65535 || gcount > NB2_NG || maxcnt_over) atomicMax(&flags[3], 1);   // (rare) union does not fit the 16-bit slot offsets / the word scratch
   }
 }
 
