@@ -527,16 +527,13 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     }
   }
   __syncthreads();
-  for(int t = tid; t < ncand && !(ablate & 2); t += NT) {   // partners: ONE global atomic per component and candidate
+  // partners: ONE global atomic per component and candidate. Lanes walk the accumulators in memory order (3 doubles per candidate):
+  // candidates are runs of consecutive atoms, so one wave instruction covers a few whole lines of f instead of a 24-byte stride
+  for(int e = tid; e < 3 * ncand && !(ablate & 2); e += NT) {
+    const int t = (int)(((unsigned)e * 43691u) >> 17);      // e / 3 (exact below 98304)
     const int j = cl[t];
-    if(GN || j < nlocal) {
-      const double ax = s_acc[3 * t], ay = s_acc[3 * t + 1], az = s_acc[3 * t + 2];
-      if(ax != 0 || ay != 0 || az != 0) {
-        real* fj = f + 3 * (size_t)j;
-        unsafeAtomicAdd(fj + 0, (real)(-(ax * (double)c_out))); unsafeAtomicAdd(fj + 1, (real)(-(ay * (double)c_out)));
-        unsafeAtomicAdd(fj + 2, (real)(-(az * (double)c_out)));
-      }
-    }
+    const double a = s_acc[e];
+    if((GN || j < nlocal) && a != 0) unsafeAtomicAdd(f + 3 * (size_t)j + (e - 3 * t), (real)(-(a * (double)c_out)));
   }
   if(EV) {
     if(i < 0) { e_acc = 0; v_acc = 0; }
