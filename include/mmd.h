@@ -152,7 +152,8 @@ typedef void (*mmd_thermo_fn)(void* ctx, int step, double sum_mv2, double eng_vd
  * (thermo fires when (n+1) % nstat == 0, n counted from first_step). */
 int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int thermo_nstat, mmd_thermo_fn cb, void* ctx);
 /* wall-clock buckets of the last run: TOTAL, COMM, FORCE, NEIGH, TEST(extra) (ref/timer.h:35-40),
- * then GPU-event time of the force kernel (sum ms) and its launch count */
+ * then GPU-event time of Force::compute (sum ms over the TIMED calls) and the number of timed calls: the clock is read on
+ * every 3rd call of a run (option "time_force_sample"); FORCE in out5 is their mean times the number of calls */
 int mmd_timers(mmd_handle* h, double out5[5], double* force_kernel_ms, int* force_kernel_launches);
 /* time `nrep` launches of one hot kernel with hipEvents on the handle's compute stream.
  * which: 0 = force (current style, evflag=0), 1 = neighbor build, 2 = initial integrate, 3 = final integrate */

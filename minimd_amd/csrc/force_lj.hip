@@ -13,6 +13,7 @@
 #include <type_traits>
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"
+#include <hip/hip_ext.h>
 #include "tile_lds.hpp"
 
 // 1/r^2: v_rcp_f64 + two Newton steps (<= 1 ulp class) instead of the 11-instruction IEEE divide;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, int pos_bytes, LJParams P, real* __restrict__ f,
-    double* __restrict__ partials, int ablate, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce)
+    double* __restrict__ partials, int ablate, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, GhostResolve G)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   real* s_f = (real*)(s_raw + pos_bytes);
@@ -195,8 +196,13 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
 #pragma unroll
     for(int u = 0; u < STG; u++) { tt[u] = min(t0 + u * LJ_TILE_THREADS + tid, ncand); jj[u] = cl[tt[u]]; }
     real4 pp[STG];
+    if(G.root != nullptr && G.tile_ghost[tile] != 0) {       // (workgroup-uniform) boundary tile of a one-rank run: ghosts from their owners
 #pragma unroll
-    for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
+      for(int u = 0; u < STG; u++) pp[u] = ghost_resolved(x, jj[u], nlocal, nall, G);
+    } else {
+#pragma unroll
+      for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
+    }
 #pragma unroll
     for(int u = 0; u < STG; u++) { sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z; }
   }
@@ -627,12 +633,18 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   const int ev = evflag ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
   bool launched = false;
   const int fz = h->fuse_now ? 1 : 0;
+  // the caller's event pair rides ON the dispatch (start/stop stamps of the kernel itself): timing a step's force kernel costs the
+  // stream no marker packets (a bracketing hipEventRecord pair costs ~6 us per step, 15 % of a -s 32 step)
+  hipEvent_t kev_a = h->launch_ev_a, kev_b = h->launch_ev_b;
+  h->launch_ev_a = h->launch_ev_b = nullptr;
+  GhostResolve G{nullptr, nullptr, nullptr, {h->prd[0], h->prd[1], h->prd[2]}};
+  if(h->resolve_now) { G.root = h->ghost_root.p; G.image = h->ghost_image.p; G.tile_ghost = h->tile_ghost.p; }
 #define TK(EVv, Xv, Wv, Uv, Rv, Fv) if(!launched && ev == EVv && ex == Xv && tw == Wv && tu == Uv && rd == Rv && fz == Fv) { launched = true;  \
-    hipLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv, Rv, Fv>), dim3(xcd_grid(count)), dim3(64 * Wv),                       \
-                       pos_bytes + lj_tile_sf_bytes(Wv) + 16 * sizeof(double), h->stream, h->x.p,                                    \
+    hipExtLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv, Rv, Fv>), dim3(xcd_grid(count)), dim3(64 * Wv),                    \
+                       pos_bytes + lj_tile_sf_bytes(Wv) + 16 * sizeof(double), h->stream, kev_a, kev_b, 0, h->x.p,                   \
                        h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
                        count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,              \
-                       h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce); }
+                       h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce, G); }
   const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = h->opt_tile_read;
   TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
   TK(0, 0, 2, 8, 0, 1);                                                                          // production, integrator fused

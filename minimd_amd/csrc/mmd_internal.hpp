@@ -189,6 +189,13 @@ struct mmd_handle {
   DevArr<int> flag_tmp, bnd_list, bstate;
   bool big_bins = false;       // some bin holds more than NB_BIGBIN atoms: binning runs the grid-wide rank sort too
   bool in_reneighbor = false;  // inside Integrate::run's re-neighboring: Comm::borders follows Atom::sort, ghosts need not ride along
+  // one-rank LJ full-list steps: the tile kernel stages ghosts from their owners, no per-step Comm::communicate. 1 = where it
+  // pays (small systems: the saved launch is ~3 us, the extra indirection of the boundary tiles costs ~3 us at -s 80), 2 = always
+  int opt_ghost_resolve = 1;
+  int opt_time_sample = 3;             // force-kernel clock on every n-th Force::compute of a run
+  int force_calls = 0;
+  bool resolve_now = false, ghosts_stale = false;
+  hipEvent_t launch_ev_a = nullptr, launch_ev_b = nullptr;     // event pair the next tile-kernel launch attaches to its dispatch
   int opt_borders_fast = 1, opt_borders_est = 150;    // device-resident one-rank borders on/off; its sizing estimate in per cent of the previous counts
   int prev_nb = 0, prev_nghost = 0;   // counts of the last Comm::borders (size the device-resident one-rank path of the next one)
   // ---- Integrate

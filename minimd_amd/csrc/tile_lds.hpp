@@ -32,3 +32,23 @@ __device__ __forceinline__ real mul_add_unfused(real a, real b, real c)
   return p + c;
 }
 
+
+// One-rank runs: every ghost is a periodic image of an owned atom (Comm::borders recorded its root and image vector), so a tile
+// kernel can stage a ghost candidate straight from the owner's CURRENT position plus the box shift — the per-step
+// Comm::communicate (k_ghost_update, ref/comm.cpp:276-317 with self swaps) and its launch gap disappear from the step.
+// root == nullptr: off (ghost slots of x are read as usual). The shift is applied one box length at a time, exactly like
+// the swap-by-swap packing does (pack_comm adds pbc*prd once per swap).
+struct GhostResolve { const int* root; const int* image; const int* tile_ghost; real prd[3]; };
+
+__device__ __forceinline__ real4 ghost_resolved(const real4* __restrict__ x, int j, int nlocal, int nall, const GhostResolve& G)
+{
+  if(j < nlocal || j >= nall) return x[j];
+  const int g = j - nlocal;
+  real4 p = x[G.root[g]];
+  const int code = G.image[g];
+  const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
+  for(int q = 0; q < (sx < 0 ? -sx : sx); q++) p.x += sx < 0 ? -G.prd[0] : G.prd[0];
+  for(int q = 0; q < (sy < 0 ? -sy : sy); q++) p.y += sy < 0 ? -G.prd[1] : G.prd[1];
+  for(int q = 0; q < (sz < 0 ? -sz : sz); q++) p.z += sz < 0 ? -G.prd[2] : G.prd[2];
+  return p;
+}
