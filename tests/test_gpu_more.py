@@ -369,6 +369,25 @@ def test_overlap_split_equals_single_launch(deck):
     np.testing.assert_array_equal(rows[0][2], rows[1][2])
 
 
+@pytest.mark.parametrize("args", [["-s", 12], ["-s", 3], ["-nx", 2, "-ny", 5, "-nz", 3]])
+def test_ghosts_staged_from_their_owners_equal_the_ghost_update(args):
+    """One rank: the tile kernel reads a ghost candidate as owner position + box shift (no per-step Comm::communicate) — the
+    same bits as the ghost-update kernel writes into the ghost slots, so thermo rows, forces and the final state (ghost
+    positions included: refreshed when the run returns) are identical. -s 3 and 2x5x3 have images of images."""
+    m = mm()
+    out = {}
+    for mode in (0, 2):
+        s = m.Sim(args + ["-n", 60, "--half_neigh", 0])
+        s.handle.set_option("ghost_resolve", mode)
+        s.initial(); s.run()
+        d = s.handle.download()
+        out[mode] = (s.rows(), d["x"].copy(), d["v"].copy(), d["f"].copy())
+        s.close()
+    assert out[0][0] == out[2][0]
+    for k in (1, 2, 3):
+        np.testing.assert_array_equal(out[0][k], out[2][k])
+
+
 # ---- BASELINE.json sizes: golden rows + size-independent properties -----------------------------------------
 def test_baseline_s80_full_and_half():
     ent = REFRUNS["lj_s80_full_n100"]
