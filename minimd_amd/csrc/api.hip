@@ -102,6 +102,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "eam_mlo")) h->opt_eam_mlo = value;
   else if(!strcmp(name, "ghost_resolve")) h->opt_ghost_resolve = value;
   else if(!strcmp(name, "time_force_sample")) h->opt_time_sample = value;
+  else if(!strcmp(name, "fold_reverse")) h->opt_fold_reverse = value;
   else if(!strcmp(name, "borders_fast")) h->opt_borders_fast = value;
   else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
@@ -232,7 +233,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   bool halo_pending = false, collect_pending = false;
   // the per-step halos are timed (into TIME_COMM) only where they are more than one tiny kernel: an event pair costs the stream
   // two markers, ~5 us per step that a -s 32 run would notice
-  const bool time_halo = h->time_force_events && (h->nprocs > 1 || h->opt_force_transport || reverse);
+  // one rank, half lists with ghost newton in tile form: a ghost's share of a pair goes straight to its owner
+  const bool fold = reverse && h->opt_fold_reverse && h->nprocs == 1 && !h->opt_force_transport && h->opt_fuse && h->style == 0;
+  const bool time_halo = h->time_force_events && (h->nprocs > 1 || h->opt_force_transport || (reverse && !fold));
   int evflag_pending = 0;
   const bool fuse_force = h->opt_fuse >= 2 && !reverse && !h->halfneigh;
   // one rank, LJ over full lists in tile form: no per-step ghost update at all (the tile kernel resolves ghosts itself)
@@ -310,6 +313,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     }
     const int step = first_step + n + 1;
     const int evflag = thermo_nstat > 0 && (step % thermo_nstat == 0);
+    bool folded = false;
     if(halo_pending) {
       // overlapped step: interior tiles ran under the halo; now wait for the ghosts and finish the boundary tiles
       HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
@@ -324,12 +328,14 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
       h->fuse_now = fused_force;
       h->resolve_now = h->ghosts_stale;
+      h->fold_reverse_now = folded = fold && h->ghost_chain_ok && mmd_lj_half_tiles_available(h);
       const int rc = force_compute_async(h, evflag, nullptr, nullptr, true);
       h->fuse_now = 0;
       h->resolve_now = false;
+      h->fold_reverse_now = false;
       MMD_TRY(rc);
     }
-    if(reverse) {
+    if(reverse && !folded) {
       if(time_halo) MMD_TRY(ev_begin(h, 1));
       MMD_TRY(mmd_comm_reverse_communicate(h));
       if(time_halo) MMD_TRY(ev_end(h));

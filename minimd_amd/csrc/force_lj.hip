@@ -407,7 +407,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, const unsigned short* __restrict__ tile_self, int nlocal, int nall, int maxneighs, int pos_bytes,
-    LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate)
+    LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate, const int* __restrict__ ghost_root)
 {
   constexpr int UNR = 8, NT = 128, STG = 4;
   extern __shared__ __align__(16) unsigned char s_raw[];
@@ -537,8 +537,10 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   // candidates are runs of consecutive atoms, so one wave instruction covers a few whole lines of f instead of a 24-byte stride
   for(int e = tid; e < 3 * ncand && !(ablate & 2); e += NT) {
     const int t = (int)(((unsigned)e * 43691u) >> 17);      // e / 3 (exact below 98304)
-    const int j = cl[t];
+    int j = cl[t];
     const double a = s_acc[e];
+    // one rank: a ghost is an image of an owned atom, its share goes straight to the owner (Comm::reverse_communicate folded in)
+    if(GN && ghost_root != nullptr && j >= nlocal) j = ghost_root[j - nlocal];
     if((GN || j < nlocal) && a != 0) unsafeAtomicAdd(f + 3 * (size_t)j + (e - 3 * t), (real)(-(a * (double)c_out)));
   }
   if(EV) {
@@ -711,7 +713,7 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(CNT)), dim3(128), lds, h->stream, h->x.p, h->binned.p,              \
                          h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,  \
                          h->nl16.p, h->tile_self.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,            \
-                         h->partials.p, h->opt_ablate)
+                         h->partials.p, h->opt_ablate, h->fold_reverse_now ? (const int*)h->ghost_root.p : (const int*)nullptr)
 #define HT4(LIST, CNT) { HT(0, 0, LIST, CNT); HT(0, 1, LIST, CNT); HT(1, 0, LIST, CNT); HT(1, 1, LIST, CNT); }
     if(h->halo_pending) {
       // overlapped step (several ranks): interior tiles (no ghost among their candidates) run while the position halo is in

@@ -192,6 +192,9 @@ struct mmd_handle {
   // one-rank LJ full-list steps: the tile kernel stages ghosts from their owners, no per-step Comm::communicate. 1 = where it
   // pays (small systems: the saved launch is ~3 us, the extra indirection of the boundary tiles costs ~3 us at -s 80), 2 = always
   int opt_ghost_resolve = 1;
+  // one-rank half-list LJ steps with ghost newton: the tile kernel adds a ghost's share to its owner (no Comm::reverse_communicate)
+  int opt_fold_reverse = 1;
+  bool fold_reverse_now = false;
   int opt_time_sample = 3;             // force-kernel clock on every n-th Force::compute of a run
   int force_calls = 0;
   bool resolve_now = false, ghosts_stale = false;

@@ -388,6 +388,27 @@ def test_ghosts_staged_from_their_owners_equal_the_ghost_update(args):
         np.testing.assert_array_equal(out[0][k], out[2][k])
 
 
+@pytest.mark.parametrize("args", [["-s", 12], ["-s", 3], ["-nx", 2, "-ny", 5, "-nz", 3]])
+def test_reverse_communicate_folded_into_the_half_kernel(args):
+    """One rank, half lists with ghost newton: the tile kernel adds a ghost's share of a pair to the ghost's owner directly
+    instead of summing it on the ghost and sending it home (Comm::reverse_communicate, ref/comm.cpp:321-355) — the same sums
+    in another order."""
+    m = mm()
+    out = {}
+    for mode in (0, 1):
+        s = m.Sim(args + ["-n", 60, "--half_neigh", 1])
+        s.handle.set_option("fold_reverse", mode)
+        s.initial(); s.run()
+        d = s.handle.download()
+        nl = s.handle.counts()[0]
+        out[mode] = (s.rows(), d["x"][:nl].copy(), d["f"][:nl].copy())
+        s.close()
+    rows_close(out[0][0], out[1][0], 1e-10)
+    fmax = np.abs(out[0][2]).max()
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-9
+    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-8 * fmax
+
+
 # ---- BASELINE.json sizes: golden rows + size-independent properties -----------------------------------------
 def test_baseline_s80_full_and_half():
     ent = REFRUNS["lj_s80_full_n100"]
