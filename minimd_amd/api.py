@@ -17,7 +17,8 @@ class MMDError(RuntimeError):
 
 
 def lib_path(precision="dp"):
-    return os.path.join(PKG, "lib", "libmmd_hip_%s.so" % precision)
+    # MMD_LIB_DIR: tuning builds of the same library kept next to the product one (tools/build_variant.sh)
+    return os.path.join(os.environ.get("MMD_LIB_DIR") or os.path.join(PKG, "lib"), "libmmd_hip_%s.so" % precision)
 
 
 def build(verbose=False):

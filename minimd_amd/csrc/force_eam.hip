@@ -396,34 +396,46 @@ __device__ __forceinline__ float rsqrt_fast(float a)
 // gathers from LDS only. EAM_TW wavefronts per tile split the k range of the same 64 atoms.
 // ---------------------------------------------------------------------------------------------------
 #define EAM_TW 4
+#ifndef EAM_FW
+#define EAM_FW 4              // wavefronts per tile in the force sweep
+#endif
 #define EAM_TU 4              // row padding granularity of the tile lists (NB_ROW_PAD) = pairs per trip of the density sweep
 #define EAM_DSTRIDE 6         // reals per knot record of the density sweep's LDS table
 #define EAM_FSTRIDE 10        // reals per knot record of the force sweep's LDS table
+#ifndef EAM_FU
 #define EAM_FU 4              // pairs per trip of the force sweep (+ one trip of EAM_TU where 4 rows remain)
+#endif
 #define EAM_STAGE 4
 
 // dynamic LDS of both kernels (nothing static precedes it, see tile_lds.hpp):
 //   [{x,y,z} records of the candidates: eam_pos_bytes(cmax)] [force sweep only: fp of the candidates] [spline knots] [partials] [16 doubles]
 __host__ __device__ constexpr size_t eam_pos_bytes(int cmax) { return (((size_t)3 * (cmax + 2) * sizeof(real)) + 15) & ~(size_t)15; }
 __host__ __device__ constexpr size_t eam_fp_bytes(int cmax) { return (((size_t)(cmax + 2) * sizeof(real)) + 15) & ~(size_t)15; }
+// half lists: n double accumulators per candidate (1: rho, 3: f) — doubles in both precisions, see k_lj_half_tile
+__host__ __device__ constexpr size_t eam_acc_bytes(int cmax, int n) { return (((size_t)n * (cmax + 2) * sizeof(double)) + 15) & ~(size_t)15; }
 
-template <int EV>
+// HALF=1: ForceEAM::compute_halfneigh's first loop (ref/force_eam.cpp:131-160) on a half-list tile: a pair's term goes to the atom
+// in registers and to its PARTNER through an LDS accumulator per candidate (ds_add_f64); at the end of the tile the accumulators
+// of the owned candidates are flushed to rho[] with one global atomic each, in memory order (whole lines per wave instruction,
+// see k_lj_half_tile). rho was zeroed beforehand; fp = F'(rho) is a separate pass (k_eam_half_fp) once every tile has flushed.
+template <int EV, int HALF>
 __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, int cmax, real rdr, real rdrho, real* __restrict__ fp,
-    double* __restrict__ partials, int mlo)
+    double* __restrict__ partials, int mlo, const unsigned short* __restrict__ tile_self, real* __restrict__ rho)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_TW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: the k loop runs on the scalar unit
   real* s_pos = (real*)s_raw;
+  double* s_racc = (double*)(s_raw + eam_pos_bytes(cmax));           // HALF: one density accumulator per candidate
   // knot window [mlo, nr]: pairs closer than r(mlo) (never seen in a sane system) read their knot from global memory
   // records of EAM_DSTRIDE reals (48 B): a stride of 12 words spreads random knots over 16 bank offsets, 32-byte records over 8
-  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax));                // [knot - mlo][EAM_DSTRIDE]: coeffs 3..6 of rhor_spline, 2 unused
+  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax) + (HALF ? eam_acc_bytes(cmax, 1) : 0));     // [knot - mlo][EAM_DSTRIDE]: coeffs 3..6 of rhor_spline, 2 unused
   real* s_part = s_tab + (size_t)(nr + 1 - mlo) * EAM_DSTRIDE;
   double* s_red = (double*)(((size_t)(s_part + 64 * (EAM_TW - 1)) + 7) & ~(size_t)7);
   for(int t = tid; t < (nr + 1 - mlo) * 4; t += NT) s_tab[(t >> 2) * EAM_DSTRIDE + (t & 3)] = rhor_spline[((t >> 2) + mlo) * 7 + 3 + (t & 3)];
@@ -445,7 +457,10 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) pp[u] = x[jj[u]];
 #pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) { s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; }
+    for(int u = 0; u < EAM_STAGE; u++) {
+      s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z;
+      if(HALF) s_racc[tt[u]] = 0;
+    }
   }
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
   if(i >= nlocal) i = -1;
@@ -465,8 +480,9 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   real rhoi = 0;
   for(int k = k0; k < k1; k += EAM_TU) {
     real xj[EAM_TU], yj[EAM_TU], zj[EAM_TU];
+    unsigned sc[EAM_TU];
 #pragma unroll
-    for(int u = 0; u < EAM_TU; u++) lds_read3<0>((unsigned)sl[u], xj[u], yj[u], zj[u]);
+    for(int u = 0; u < EAM_TU; u++) { sc[u] = (unsigned)sl[u]; lds_read3<0>((unsigned)sl[u], xj[u], yj[u], zj[u]); }
     np += EAM_TU * 64;
     if(k + EAM_TU < k1) {                               // the next trip's slots travel under this trip's arithmetic
 #pragma unroll
@@ -487,14 +503,31 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
         if(__builtin_amdgcn_ballot_w64(m < mlo) != 0ull) {            // (rare: a pair closer than the window's first knot)
           if(m < mlo) { const real* cg = &rhor_spline[m * 7 + 3]; c0 = cg[0]; c1 = cg[1]; c2 = cg[2]; c3 = cg[3]; }
         }
-        rhoi += fma_r(fma_r(fma_r(c0, p, c1), p, c2), p, c3);
+        const real term = fma_r(fma_r(fma_r(c0, p, c1), p, c2), p, c3);
+        rhoi += term;
+        // the partner's share (a ghost partner's accumulator is simply not flushed: `if (j < nlocal)`, ref :155)
+        if(HALF) unsafeAtomicAdd(&s_racc[sc[u] / (3u * (unsigned)sizeof(real))], (double)term);
       }
     }
   }
   if(wv > 0) s_part[64 * (wv - 1) + lane] = rhoi;
   __syncthreads();
   double e_acc = 0;
-  if(wv == 0 && i >= 0) {
+  if(HALF) {
+    if(wv == 0 && i >= 0) {
+#pragma unroll
+      for(int q = 0; q < EAM_TW - 1; q++) rhoi += s_part[64 * q + lane];
+      const unsigned own = tile_self[(size_t)tile * 64 + lane];
+      if(own != 0xffffu) s_racc[own] += (double)rhoi;            // the atom is one of the tile's candidates: one flush for both
+      else unsafeAtomicAdd(rho + i, rhoi);
+    }
+    __syncthreads();
+    for(int t = tid; t < ncand; t += NT) {
+      const int j = cl[t];
+      const double a = s_racc[t];
+      if(j < nlocal && a != 0) unsafeAtomicAdd(rho + j, (real)a);
+    }
+  } else if(wv == 0 && i >= 0) {
 #pragma unroll
     for(int q = 0; q < EAM_TW - 1; q++) rhoi += s_part[64 * q + lane];
     real p = (real)1.0 * rhoi * rdrho + (real)1.0;
@@ -506,7 +539,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     fp[i] = (c[0] * p + c[1]) * p + c[2];
     if(EV) e_acc = (double)(((c[3] * p + c[4]) * p + c[5]) * p + c[6]);
   }
-  if(EV) {
+  if(EV && !HALF) {
     const double es = block_sum(e_acc, s_red);
     if(tid == 0) partials[3 * (size_t)tile] = es;
   }
@@ -514,17 +547,22 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
 }
 
 // FUSE=1: wave 0 also applies finalIntegrate(n) + initialIntegrate(n+1) to the tile's atoms (see k_lj_full_tile)
-template <int EV, int FUSE>
-__global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
+// HALF=1: the third loop of ForceEAM::compute_halfneigh (ref/force_eam.cpp:190-267) on a half-list tile: the partner's share of a
+// pair goes to three LDS accumulators per candidate, flushed for the owned candidates at the end of the tile (see
+// k_eam_density_tile); a ghost partner gets no force and the pair counts half in energy and virial (:244-257). f was zeroed
+// beforehand; partials = {sum phi, virial} per tile.
+template <int EV, int FUSE, int HALF>
+__global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
-    double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, int mlo)
+    double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, int mlo,
+    const unsigned short* __restrict__ tile_self)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
-  constexpr int NT = 64 * EAM_TW;
+  constexpr int NT = 64 * EAM_FW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   real* s_pos = (real*)s_raw;
@@ -533,9 +571,11 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   // offsets, a 64-byte stride over 4): four aligned ds_read_b128 per pair. The derivative
   // coefficients of z2r are multiples of its value coefficients (array2spline, ref/force_eam.cpp:785-789:
   // [0] = 3 [3] / delta, [1] = 2 [4] / delta, [2] = [5] / delta), so they are not stored: 56 instead of 80 gathered bytes.
-  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax) + eam_fp_bytes(cmax));
+  double* s_acc = (double*)(s_raw + eam_pos_bytes(cmax) + eam_fp_bytes(cmax));       // HALF: force accumulators of the candidates
+  real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax) + eam_fp_bytes(cmax) + (HALF ? eam_acc_bytes(cmax, 3) : 0));
   real* s_f = s_tab + (size_t)(nr + 1 - mlo) * EAM_FSTRIDE;
-  double* s_red = (double*)(((size_t)(s_f + 3 * 64 * (EAM_TW - 1)) + 7) & ~(size_t)7);
+  double* s_red = (double*)(((size_t)(s_f + 3 * 64 * (EAM_FW - 1)) + 7) & ~(size_t)7);
+  unsigned char* s_gh = (unsigned char*)(s_red + 16);                  // HALF && EV: candidate is a ghost
   for(int t = tid; t < (nr + 1 - mlo) * 8; t += NT) {
     const int m = (t >> 3) + mlo, c = t & 7;
     s_tab[(t >> 3) * EAM_FSTRIDE + c] = c < 3 ? rhor_spline[m * 7 + c] : (c < 7 ? z2r_spline[m * 7 + c] : (real)0);
@@ -557,14 +597,18 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) { pp[u] = x[jj[u]]; ff[u] = fp[jj[u]]; }
 #pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) { s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; s_fp[tt[u]] = ff[u]; }
+    for(int u = 0; u < EAM_STAGE; u++) {
+      s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; s_fp[tt[u]] = ff[u];
+      if(HALF) { s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0; }
+      if(HALF && EV) s_gh[tt[u]] = jj[u] >= nlocal ? 1 : 0;
+    }
   }
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   const real fpi = fp[i >= 0 ? i : 0];
   const int kmax = tile_max[tile];
-  const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
+  const int per = ((kmax / EAM_TU + EAM_FW - 1) / EAM_FW) * EAM_TU;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
   int sl[EAM_FU];
@@ -583,10 +627,12 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   auto trip = [&](auto nu, int k) {
     constexpr int U = decltype(nu)::value;
     real xj[U], yj[U], zj[U], fpj[U];
+    unsigned sc[U];
 #pragma unroll
     for(int u = 0; u < U; u++) {
       lds_read3<0>((unsigned)sl[u], xj[u], yj[u], zj[u]);
-      fpj[u] = s_fp[(unsigned)sl[u] / (3u * (unsigned)sizeof(real))];
+      sc[u] = (unsigned)sl[u] / (3u * (unsigned)sizeof(real));
+      fpj[u] = s_fp[sc[u]];
     }
     np += U * 64;
     if(k + U < k1) {
@@ -633,11 +679,20 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
       const real phip = fma_r(z2p, recip[u], -(phi * recip[u]));
       const real psip = fma_r(fpi, rhoip, fma_r(fpj[u], rhoip, phip));
       real fpair = in ? -psip * recip[u] : (real)0;
-      fx = fma_r(dx[u], fpair, fx); fy = fma_r(dy[u], fpair, fy); fz = fma_r(dz[u], fpair, fz);
+      if(HALF) {
+        const real px = dx[u] * fpair, py = dy[u] * fpair, pz = dz[u] * fpair;
+        fx += px; fy += py; fz += pz;
+        if(in) {
+          double* a = s_acc + 3 * sc[u];
+          unsafeAtomicAdd(a + 0, -(double)px); unsafeAtomicAdd(a + 1, -(double)py); unsafeAtomicAdd(a + 2, -(double)pz);
+        }
+      } else {
+        fx = fma_r(dx[u], fpair, fx); fy = fma_r(dy[u], fpair, fy); fz = fma_r(dz[u], fpair, fz);
+      }
       if(EV) {
-        fpair *= (real)0.5;
-        v_acc += (double)(rsq[u] * fpair);
-        e_acc += (double)(in ? (real)0.5 * phi : (real)0);
+        const real scale = HALF ? (s_gh[sc[u]] ? (real)0.5 : (real)1.0) : (real)0.5;
+        v_acc += (double)(rsq[u] * (fpair * scale));
+        e_acc += (double)(in ? scale * phi : (real)0);
       }
     }
   };
@@ -650,8 +705,13 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
   __syncthreads();
   if(wv == 0 && i >= 0) {
 #pragma unroll
-    for(int q = 0; q < EAM_TW - 1; q++) { const real* d = s_f + 3 * 64 * q; fx += d[lane]; fy += d[64 + lane]; fz += d[128 + lane]; }
-    if(!FUSE) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
+    for(int q = 0; q < EAM_FW - 1; q++) { const real* d = s_f + 3 * 64 * q; fx += d[lane]; fy += d[64 + lane]; fz += d[128 + lane]; }
+    if(HALF) {
+      const unsigned own = tile_self[(size_t)tile * 64 + lane];
+      if(own != 0xffffu) { s_acc[3 * own] += (double)fx; s_acc[3 * own + 1] += (double)fy; s_acc[3 * own + 2] += (double)fz; }
+      else { real* fi = f + 3 * (size_t)i; unsafeAtomicAdd(fi + 0, fx); unsafeAtomicAdd(fi + 1, fy); unsafeAtomicAdd(fi + 2, fz); }
+    }
+    if(!FUSE && !HALF) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
     if(FUSE) {          // same operations, same order as k_final_initial_integrate (integrate.hip)
       real vx = v[3 * (size_t)i + 0], vy = v[3 * (size_t)i + 1], vz = v[3 * (size_t)i + 2];
       vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
@@ -660,11 +720,23 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_force_tile(
       xnew[i] = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
     }
   }
+  if(HALF) {
+    __syncthreads();
+    for(int e = tid; e < 3 * ncand; e += NT) {             // memory order: 3 doubles per candidate, candidates are runs of consecutive atoms
+      const int t = (int)(((unsigned)e * 43691u) >> 17);     // e / 3 (exact below 98304)
+      const int j = cl[t];
+      const double a = s_acc[e];
+      if(j < nlocal && a != 0) unsafeAtomicAdd(f + 3 * (size_t)j + (e - 3 * t), (real)a);
+    }
+  }
   if(EV) {
     if(i < 0) { e_acc = 0; v_acc = 0; }
     const double es = block_sum(e_acc, s_red);
     const double vs = block_sum(v_acc, s_red);
-    if(tid == 0) { partials[3 * (size_t)tile + 1] = es; partials[3 * (size_t)tile + 2] = vs; }
+    if(tid == 0) {
+      if(HALF) { partials[2 * (size_t)tile] = es; partials[2 * (size_t)tile + 1] = vs; }
+      else { partials[3 * (size_t)tile + 1] = es; partials[3 * (size_t)tile + 2] = vs; }
+    }
   }
   }   // tile loop
 }
@@ -690,9 +762,21 @@ __global__ __launch_bounds__(256) void k_fp_pack(const real* __restrict__ fp, co
   if(i < n) out[i] = fp[list[i]];
 }
 
+// one rank: every ghost is an image of an owned atom (Comm::borders recorded the owner): all six self swaps in one launch
+__global__ __launch_bounds__(256) void k_fp_ghosts(real* __restrict__ fp, const int* __restrict__ root, int nlocal, int nghost)
+{
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if(g < nghost) fp[nlocal + g] = fp[root[g]];
+}
+
 // ForceEAM::communicate (ref/force_eam.cpp:851-887): one scalar per send-list atom, swap by swap
 static int eam_fp_halo(mmd_handle* h)
 {
+  if(h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport) {
+    if(h->nghost) hipLaunchKernelGGL(k_fp_ghosts, dim3(div_up(h->nghost, 256)), dim3(256), 0, h->stream, h->fp.p, h->ghost_root.p, h->nlocal, h->nghost);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   for(auto& s : h->swaps) {
     if(s.sendproc == h->me && !h->opt_force_transport) {
       if(s.sendnum) hipLaunchKernelGGL(k_fp_self, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->fp.p, s.sendlist.p, s.sendnum, s.firstrecv);
@@ -753,7 +837,15 @@ static size_t eam_tile_lds_density(const mmd_handle* h)
 static size_t eam_tile_lds_force(const mmd_handle* h)
 {
   return eam_pos_bytes(h->tile_cmax) + eam_fp_bytes(h->tile_cmax) + (size_t)(h->nr + 1 - eam_mlo(h)) * EAM_FSTRIDE * sizeof(real) +
-         (size_t)3 * 64 * (EAM_TW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
+         (size_t)3 * 64 * (EAM_FW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
+}
+static size_t eam_tile_lds_density_half(const mmd_handle* h) { return eam_tile_lds_density(h) + eam_acc_bytes(h->tile_cmax, 1); }
+static size_t eam_tile_lds_force_half(const mmd_handle* h) { return eam_tile_lds_force(h) + eam_acc_bytes(h->tile_cmax, 3) + (size_t)h->tile_cmax + 16; }
+// half lists (without ghost newton) in tile form: third-law scatter through LDS accumulators
+static bool eam_half_tiles_available(const mmd_handle* h)
+{
+  return h->style == 1 && h->halfneigh && !h->ghost_newton && h->tiles_ready && h->opt_tiles && h->eam_uniform &&
+         eam_tile_lds_force_half(h) <= 144 * 1024 && h->neigh_nlocal == h->nlocal;
 }
 static bool eam_tiles_available(const mmd_handle* h)
 {
@@ -770,8 +862,58 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   const int nlocal = h->nlocal, nall = nlocal + h->nghost;
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
+  if(eam_half_tiles_available(h) && !h->opt_eam_half_rows) {
+    // ---- ForceEAM::compute_halfneigh (ref/force_eam.cpp:94-270) on the tile lists: the partner's share of every pair is summed in
+    // LDS, one global atomic per owned candidate and tile (k_eam_density_tile<.,1>, k_eam_force_tile<.,0,1>)
+    const int nt = h->ntiles, mlo = eam_mlo(h);
+    const int nblocks = div_up(nlocal, MMD_BLOCK);
+    MMD_TRY(h->rho.ensure((size_t)nall + 64, false, h->stream));
+    MMD_TRY(h->partials.ensure((size_t)nblocks + 2 * (size_t)nt + 32, false, h->stream));
+    double* p_embed = h->partials.p;
+    double* p_pair = h->partials.p + nblocks + 8;
+    HIP_TRY(hipMemsetAsync(h->rho.p, 0, (size_t)nlocal * sizeof(real), h->stream));
+    MMD_TRY(mmd_zero_forces(h, nall));
+    const size_t tl1 = eam_tile_lds_density_half(h), tl2 = eam_tile_lds_force_half(h);
+    const int cus = h->prop.multiProcessorCount;
+    const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl1 + 512)))) / 8 * 8);
+    const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 512)))) / 8 * 8);
+    if(!h->eam_half_attr_set) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      h->eam_half_attr_set = true;
+    }
+    hipLaunchKernelGGL((k_eam_density_tile<0, 1>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p, h->tile_first.p,
+                       h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,
+                       h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr, h->nrho, h->tile_cmax, h->rdr, h->rdrho,
+                       h->fp.p, (double*)nullptr, mlo, h->tile_self.p, h->rho.p);
+    if(evflag) hipLaunchKernelGGL((k_eam_half_fp<1>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p, 1, h->nrho,
+                                  h->nrho_tot, h->rdrho, h->fp.p, p_embed);
+    else hipLaunchKernelGGL((k_eam_half_fp<0>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p, 1, h->nrho,
+                            h->nrho_tot, h->rdrho, h->fp.p, p_embed);
+    HIP_TRY(hipGetLastError());
+    MMD_TRY(eam_fp_halo(h));
+#define FH(EVv) hipLaunchKernelGGL((k_eam_force_tile<EVv, 0, 1>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p, h->tile_first.p, \
+                       h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,   \
+                       h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr, h->tile_cmax, h->rdr, h->fp.p, h->f.p, p_pair,          \
+                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p)
+    if(evflag) FH(1); else FH(0);
+#undef FH
+    HIP_TRY(hipGetLastError());
+    if(evflag) {
+      hipLaunchKernelGGL(k_eam_half_sum, dim3(1), dim3(1024), 0, h->stream, p_embed, nblocks, p_pair, nt, h->d_result);
+      HIP_TRY(hipGetLastError());
+      if(eng || vir) {
+        HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if(eng) *eng = h->h_result[0];
+        if(vir) *vir = h->h_result[1];
+      }
+    }
+    return 0;
+  }
   if(h->halfneigh) {
-    // ---- ForceEAM::compute_halfneigh (ref/force_eam.cpp:94-270): third-law scatter with floating-point atomics
+    // ---- the same over 32-bit rows with one global floating-point atomic per pair and component (non-uniform tables, uploaded lists)
     MMD_TRY(mmd_ensure_rows(h));
     MMD_TRY(h->rho.ensure((size_t)nall + 64, false, h->stream));
     const int nblocks = div_up(nlocal, MMD_BLOCK);
@@ -821,21 +963,21 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl1 + 512)))) / 8 * 8);
     const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 512)))) / 8 * 8);
     if(!h->eam_attr_set) {     // > 64 KiB of dynamic LDS needs the opt-in (per device: the flag lives in the handle)
-      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       h->eam_attr_set = true;
     }
-#define DT(EVv, LIST, CNT) hipLaunchKernelGGL((k_eam_density_tile<EVv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
+#define DT(EVv, LIST, CNT) hipLaunchKernelGGL((k_eam_density_tile<EVv, 0>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
-                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo)
-#define FT(EVv, Fv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv>), dim3(pgrid2), dim3(64 * EAM_TW), tl2, h->stream, h->x.p, h->binned.p,       \
+                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo, (const unsigned short*)nullptr, (real*)nullptr)
+#define FT(EVv, Fv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv, 0>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p,       \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
-                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo)
+                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr)
     auto density = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) DT(1, list, cnt); else DT(0, list, cnt); } };
     auto force = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) FT(1, 0, list, cnt); else if(h->fuse_now) FT(0, 1, list, cnt); else FT(0, 0, list, cnt); } };
     if(h->halo_pending) {

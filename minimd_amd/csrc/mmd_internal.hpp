@@ -195,6 +195,8 @@ struct mmd_handle {
   // one-rank half-list LJ steps with ghost newton: the tile kernel adds a ghost's share to its owner (no Comm::reverse_communicate)
   int opt_fold_reverse = 1;
   bool fold_reverse_now = false;
+  int opt_eam_half_rows = 0;           // 1: EAM half lists on the global-atomic row kernels even where the tile kernels apply
+  bool eam_half_attr_set = false;
   int opt_time_sample = 3;             // force-kernel clock on every n-th Force::compute of a run
   int force_calls = 0;
   bool resolve_now = false, ghosts_stale = false;

@@ -85,8 +85,17 @@ def test_eam_force_half_matches_oracle(size, ntypes):
     onb = o.neighbors()
     for i in range(nl):
         assert sorted(nb[i, :nn[i]]) == sorted(onb[i, :nn[i]])
+    # device-built list: uniform tables run the TILE kernels (partner shares summed in LDS), the others the row kernels again
     eng2, vir2 = h.force_compute(1)
-    assert abs(eng2 - eng) <= 1e-12 * abs(eng) and np.abs(h.download(halfneigh=True)["f"] - fo).max() <= 1e-11 * np.abs(fo).max()
+    f2 = h.download(halfneigh=True)["f"]
+    assert abs(eng2 - eng) <= 1e-12 * abs(eng) and np.abs(f2 - fo).max() <= 1e-11 * np.abs(fo).max()
+    assert abs(vir2 - o.virial()) <= 1e-10 * max(1.0, abs(o.virial())) and not f2[nl:].any()
+    assert np.abs(h.eam_fp() - fpo).max() <= 1e-12 * np.abs(fpo).max()
+    eng3, vir3 = h.force_compute(0)                                   # (no energy/virial: another instantiation)
+    assert np.abs(h.download(halfneigh=True)["f"] - fo).max() <= 1e-11 * np.abs(fo).max()
+    h.set_option("eam_half_rows", 1)                                  # the row kernels on the device-built list
+    eng4, vir4 = h.force_compute(1)
+    assert abs(eng4 - eng) <= 1e-12 * abs(eng) and np.abs(h.download(halfneigh=True)["f"] - fo).max() <= 1e-11 * np.abs(fo).max()
     h.close(); o.close()
 
 

@@ -12,6 +12,7 @@ CONFIGS = [
     ("B  lj -s 80 full DP", ["-s", 80, "--half_neigh", 0, "-n", 100], "dp"),
     ("B' lj -s 80 half DP", ["-s", 80, "--half_neigh", 1, "-n", 100], "dp"),
     ("C  eam -s 64 full DP", ["-i", "in.eam.miniMD", "-s", 64, "--half_neigh", 0, "-n", 100], "dp"),
+    ("C' eam -s 64 half DP", ["-i", "in.eam.miniMD", "-s", 64, "--half_neigh", 1, "-n", 100], "dp"),
     ("E  lj -s 160 half SP", ["-s", 160, "--half_neigh", 1, "-n", 100], "sp"),
     ("E' lj -s 160 full SP", ["-s", 160, "--half_neigh", 0, "-n", 100], "sp"),
 ]
