@@ -232,9 +232,11 @@ class Handle:
 
     def neighbor_download(self):
         nl = self.counts()[0]
-        stride = max(self.neighbor_info()["max_row"], 1)
-        nb = np.zeros((nl, stride), np.int32)
         nn = np.zeros(nl, np.int32)
+        # counts first: a half list comes back in the reference's partition (j > i), whose rows differ in length from the device's
+        self._chk(self.L.mmd_neighbor_download(self.h, None, 0, self._ip(nn)))
+        stride = max(int(nn.max()) if nl else 0, 1)
+        nb = np.zeros((nl, stride), np.int32)
         self._chk(self.L.mmd_neighbor_download(self.h, self._ip(nb), stride, self._ip(nn)))
         return nb, nn
 

@@ -418,7 +418,10 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   const int acc_bytes = pos_bytes * (int)(sizeof(double) / sizeof(real));
   real* s_f = (real*)(s_raw + (size_t)pos_bytes + acc_bytes);
   double* s_red = (double*)(s_raw + (size_t)pos_bytes + acc_bytes + lj_tile_sf_bytes(2));
-  unsigned char* s_ghost = (unsigned char*)(s_red + 16);
+  // the candidates' atom indices wait in LDS for the flush: read from global memory there, every atomic of a lane would queue
+  // behind a load round trip (s_waitcnt vmcnt counts loads and atomics in one queue)
+  int* s_idx = (int*)(s_red + 16);
+  unsigned char* s_ghost = (unsigned char*)(s_idx + (((size_t)pos_bytes / (3 * sizeof(real)) + 3) & ~(size_t)3));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int witem = xcd_work_item(ntiles);
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     for(int u = 0; u < STG; u++) {
       sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z;
       s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0;
+      s_idx[tt[u]] = jj[u];
       if(EV && !GN) s_ghost[tt[u]] = jj[u] >= nlocal ? 1 : 0;
     }
   }
@@ -504,6 +508,12 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
           fx += px; fy += py; fz += pz;
           // the partner's accumulator collects +p, negated at the flush (sc = slot * 3 reals in bytes -> slot * 3 doubles)
           double* a = (double*)((unsigned char*)s_acc + sc[u] * (int)(sizeof(double) / sizeof(real)));
+          if(ablate & 4) {            // (profiling only: integer LDS atomics of the same width / of 32 bits)
+            atomicAdd((unsigned long long*)a + 0, (unsigned long long)__double_as_longlong((double)px)); atomicAdd((unsigned long long*)a + 1, (unsigned long long)__double_as_longlong((double)py));
+            atomicAdd((unsigned long long*)a + 2, (unsigned long long)__double_as_longlong((double)pz));
+          } else if(ablate & 8) {
+            atomicAdd((unsigned*)a + 0, (unsigned)__float_as_int((float)px)); atomicAdd((unsigned*)a + 2, (unsigned)__float_as_int((float)py)); atomicAdd((unsigned*)a + 4, (unsigned)__float_as_int((float)pz));
+          } else
           if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, (double)px); unsafeAtomicAdd(a + 1, (double)py); unsafeAtomicAdd(a + 2, (double)pz); }   // (ablate: profiling only)
           if(EV) {
             real scale = (real)1.0;
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   // candidates are runs of consecutive atoms, so one wave instruction covers a few whole lines of f instead of a 24-byte stride
   for(int e = tid; e < 3 * ncand && !(ablate & 2); e += NT) {
     const int t = (int)(((unsigned)e * 43691u) >> 17);      // e / 3 (exact below 98304)
-    int j = cl[t];
+    int j = s_idx[t];
     const double a = s_acc[e];
     // one rank: a ghost is an image of an owned atom, its share goes straight to the owner (Comm::reverse_communicate folded in)
     if(GN && ghost_root != nullptr && j >= nlocal) j = ghost_root[j - nlocal];
@@ -608,6 +618,14 @@ static void launch_half(mmd_handle* h, int nblocks, const LJTables& T)
 // bytes of the position records in the tile kernel's LDS (rounded to 16)
 static size_t lj_tile_pos_bytes(const mmd_handle* h) { return (((size_t)3 * (h->tile_cmax + 2) * sizeof(real)) + 15) & ~(size_t)15; }
 
+// dynamic LDS of k_lj_half_tile: positions, double accumulators, wave-slice forces, reduction scratch, candidate indices, ghost flags
+static size_t lj_half_tile_lds(const mmd_handle* h)
+{
+  const size_t pos_bytes = lj_tile_pos_bytes(h);
+  return pos_bytes + pos_bytes * (sizeof(double) / sizeof(real)) + lj_tile_sf_bytes(2) + 16 * sizeof(double) +
+         (pos_bytes / (3 * sizeof(real)) + 4) * sizeof(int) + (size_t)(h->tile_cmax + 2) + 16;
+}
+
 int mmd_lj_tiles_available(mmd_handle* h)
 {
   return h->style == 0 && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && lj_tile_pos_bytes(h) <= 60 * 1024 && h->neigh_nlocal == h->nlocal;
@@ -617,7 +635,7 @@ int mmd_lj_tiles_available(mmd_handle* h)
 int mmd_lj_half_tiles_available(mmd_handle* h)
 {
   return h->style == 0 && h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && !h->opt_exact_div &&
-         3 * lj_tile_pos_bytes(h) + 4096 <= 64 * 1024 && h->neigh_nlocal == h->nlocal;
+         lj_half_tile_lds(h) <= 64 * 1024 && h->neigh_nlocal == h->nlocal;
 }
 
 // the production tile kernel can carry finalIntegrate(n) + initialIntegrate(n+1) (no energy/virial on that step)
@@ -706,8 +724,7 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
     const size_t pos_bytes = lj_tile_pos_bytes(h);
-    const size_t acc_bytes = pos_bytes * (sizeof(double) / sizeof(real));
-    const size_t lds = pos_bytes + acc_bytes + lj_tile_sf_bytes(2) + 16 * sizeof(double) + (size_t)(h->tile_cmax + 2) + 16;
+    const size_t lds = lj_half_tile_lds(h);
     const int gn = h->ghost_newton ? 1 : 0;
 #define HT(EVv, Gv, LIST, CNT) if(ev == EVv && gn == Gv && (CNT) > 0)                                                                \
       hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(CNT)), dim3(128), lds, h->stream, h->x.p, h->binned.p,              \

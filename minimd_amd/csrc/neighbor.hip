@@ -659,12 +659,13 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
 // one a pair is a hit, above the upper one it is not; the ~0.1 pairs per tile in between are re-tested exactly
 // (double, unfused, `rsq <= cutneighsq` as ref/neighbor.cpp:165,179) from the global positions — rows are bit-identical
 // to an all-double build at half the VALU cycles and a third of the LDS. Single precision tests exactly in float.
-// MODE as in k_build. Half modes: candidates no tile atom may keep (owned j <= the tile's smallest atom index; mirrored
-// ghost-newton images) are dropped in the cull, so a half list's union is about half a full list's.
+// MODE as in k_build. Half modes store a pair on the atom BELOW it ((z,y,x) order of the exact positions, the rule the
+// reference applies to ghosts, ref/neighbor.cpp:155-157; without ghost newton a ghost partner is kept by whoever sees it):
+// balanced rows, and candidates below every tile atom are dropped in the cull, so the union is the upper half shell only.
+// mmd_neighbor_download re-homes the owned pairs to the reference's `j > i` partition (k_rows_to_ref_half).
 // ---------------------------------------------------------------------------------------------------
 #define NB2_BATCH 4            // chunks of 64 candidates in flight per batch of loads
 #define NB2_BUF 448            // LDS candidate buffer (slots); flushed between batches when fewer than 64*NB2_BATCH are free
-#define NB2_LEX 0x40000000     // MODE 2: candidate is an unshifted ghost (another rank's atom): (z,y,x) order decides
 #define NB2_NE (4 * NB2_BUF / 64)   // list entries (non-empty hit words) per lane that fit the recycled candidate buffer
 #define NB2_NG 40              // groups of 32 tested candidates a tile may produce (more: the global-row build takes over)
 #define NB2_PF (MMD_PRECISION == 2)
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate)
 {
   __shared__ int rng_start[128], rng_len[128];
-  // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index (| NB2_LEX) as bit pattern. Once the last
+  // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
   __shared__ __align__(16) float s_buf[4 * NB2_BUF];
   __shared__ unsigned char s_eg[NB2_NE * 64];         // group number of every list entry
@@ -743,15 +744,23 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float by0 = key_float(wave_min_u(owned ? ky : 0xffffffffu)), by1 = key_float(wave_max_u(owned ? ky : 0u));
   const float bz0 = key_float(wave_min_u(owned ? kz : 0xffffffffu)), bz1 = key_float(wave_max_u(owned ? kz : 0u));
   const float cull = (float)cutneighsq * 1.001f + 1.0e-4f;
-  const int imin = (int)wave_min_u(owned ? (unsigned)ii : 0x7fffffffu);
   // PF: local origin = the box's lower corner (exact in `real`); |local coordinate| of my atom and of every candidate that
   // survives the cull is <= Lmax, which bounds the float error of the pre-test's rsq
   const real ox = NB2_PF ? (real)bx0 : (real)0, oy = NB2_PF ? (real)by0 : (real)0, oz = NB2_PF ? (real)bz0 : (real)0;
   const float Lmax = fmaxf(fmaxf(bx1 - bx0, by1 - by0), bz1 - bz0) + 1.01f * (float)cutneigh + 0.01f;
   const float eps = 4.76837158e-07f /* 2^-21 */ * (3.0f * (float)cutneigh * Lmax + (float)cutneighsq);
   const float cut_lo = (float)cutneighsq - eps, cut_hi = (float)cutneighsq + eps;
+  // half lists: a pair is kept by the atom BELOW it — partner above in (z,y,x) order on the exact positions, the rule of
+  // ref/neighbor.cpp:155-157 for ghosts, applied here to every partner: each atom keeps the neighbors of its upper half
+  // sphere, so the rows of a tile have about the same length wherever the atom sits in its block (with `j > i` on the
+  // block-ordered indices the rows of a tile range from 0 to all neighbors: 52 % lane efficiency in the force kernels), and
+  // the tile's union is still only the upper half shell. PF: the pre-test decides z with a tolerance of 4x the float error;
+  // the pairs in the band are re-tested exactly together with the borderline distances.
+  const float ztol = 4.76837158e-07f * Lmax;
+  const float zcull = bz0 - fabsf(bz0) * 2.4e-7f - 1.0e-30f;      // a candidate below every tile atom is nobody's upper partner
   // lanes without an owned atom sit far away on the other side of the padding candidates: never a hit
   const float fxi = owned ? (float)(pme.x - ox) : -1.0e15f, fyi = owned ? (float)(pme.y - oy) : -1.0e15f, fzi = owned ? (float)(pme.z - oz) : -1.0e15f;
+  const float zlo = fzi + ztol, zhi = fzi - ztol;
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     const int fill8 = (fill + 7) & ~7;
     if(lane < fill8 - fill) {
       s_buf[fill + lane] = 1.0e15f; s_buf[NB2_BUF + fill + lane] = 1.0e15f; s_buf[2 * NB2_BUF + fill + lane] = 1.0e15f;
-      s_buf[3 * NB2_BUF + fill + lane] = __int_as_float((int)0x80000000);      // never > i, and not flagged NB2_LEX
+      s_buf[3 * NB2_BUF + fill + lane] = __int_as_float((int)0x80000000);      // (an owned index as far as MODE 1 is concerned)
       s_own[fill + lane] = (unsigned char)0xff;
     }
     __syncthreads();
@@ -807,15 +816,26 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             } else
               m = __builtin_amdgcn_fcmpf(rsq, (float)cutneighsq, 5 /* ordered <= : ref/neighbor.cpp:165,179 */);
             if(MODE != 0) {
-              const int cju = __builtin_amdgcn_readfirstlane(__float_as_int(s_buf[3 * NB2_BUF + gq + q + u]));
-              unsigned long long rule;
-              if(MODE == 2 && (cju & NB2_LEX)) {
-                // (z,y,x) order on the exact positions (ref/neighbor.cpp:155-157)
-                const real4 pj = x[cju & ~NB2_LEX];
-                rule = __builtin_amdgcn_ballot_w64(owned && !(pj.z < pme.z || (pj.z == pme.z && pj.y < pme.y) || (pj.z == pme.z && pj.y == pme.y && pj.x < pme.x)));
-              } else
-                rule = __builtin_amdgcn_sicmp(cju, ii, 38 /* signed > */);
-              m &= rule; mh &= rule;
+              const float czv = hlf ? cz2[u2].y : cz2[u2].x;
+              unsigned long long rule, rule_hi;
+              if(NB2_PF) {
+                rule = __builtin_amdgcn_fcmpf(czv, zlo, 2 /* ordered > */);
+                rule_hi = __builtin_amdgcn_fcmpf(czv, zhi, 3 /* ordered >= */);
+              } else {
+                rule = __builtin_amdgcn_fcmpf(czv, fzi, 2);
+                const unsigned long long zeq = __builtin_amdgcn_fcmpf(czv, fzi, 1 /* ordered == */);
+                if(zeq) {                                            // (a lattice: whole planes share z)
+                  const float cyv = hlf ? cy2[u2].y : cy2[u2].x, cxv = hlf ? cx2[u2].y : cx2[u2].x;
+                  const unsigned long long ygt = __builtin_amdgcn_fcmpf(cyv, fyi, 2), yeq = __builtin_amdgcn_fcmpf(cyv, fyi, 1);
+                  rule |= zeq & (ygt | (yeq & __builtin_amdgcn_fcmpf(cxv, fxi, 2)));
+                }
+                rule_hi = rule;
+              }
+              if(MODE == 1) {                                        // without ghost newton a ghost partner is kept by whoever sees it
+                const int cju = __builtin_amdgcn_readfirstlane(__float_as_int(s_buf[3 * NB2_BUF + gq + q + u]));
+                if(cju >= nlocal) { rule = ~0ull; rule_hi = ~0ull; }
+              }
+              m &= rule; mh &= rule_hi;
             }
             bits = nb2_shift_in(bits, m);
             if(NB2_PF) bits_hi = nb2_shift_in(bits_hi, mh);
@@ -829,10 +849,14 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           while(amb) {
             const int bq = __builtin_ctz(amb);
             amb &= amb - 1;
-            const real4 pj = x[__float_as_int(s_buf[3 * NB2_BUF + gq + (G - 1 - bq)]) & ~NB2_LEX];
+            const int jx = __float_as_int(s_buf[3 * NB2_BUF + gq + (G - 1 - bq)]);
+            const real4 pj = x[jx];
             const real dx = pme.x - pj.x, dy = pme.y - pj.y, dz = pme.z - pj.z;
             const real rsq = dx * dx + dy * dy + dz * dz;
-            if(rsq <= cutneighsq) bits |= 1u << bq;
+            bool ok = rsq <= cutneighsq;
+            if(MODE != 0 && !(MODE == 1 && jx >= nlocal))
+              ok = ok && (pj.z > pme.z || (pj.z == pme.z && (pj.y > pme.y || (pj.y == pme.y && pj.x > pme.x))));
+            if(ok) bits |= 1u << bq;
           }
         }
       }
@@ -844,11 +868,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         const int bq = G - 1 - lane;
         if((used >> bq) & 1u) {
           const int slot = S + __popc(used >> 1 >> bq);           // used candidates before mine
-          if(slot < cstride - 1) tile_cand[cbase + slot] = __float_as_int(s_buf[3 * NB2_BUF + gq + lane]) & ~NB2_LEX;
+          if(slot < cstride - 1) tile_cand[cbase + slot] = __float_as_int(s_buf[3 * NB2_BUF + gq + lane]);
           if(MODE != 0) { const unsigned own = s_own[gq + lane]; if(own != 0xffu) s_self[own] = (unsigned short)slot; }
         }
       }
-      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && (__float_as_int(s_buf[3 * NB2_BUF + gq + lane]) & ~NB2_LEX) >= nlocal) != 0ull;
+      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && __float_as_int(s_buf[3 * NB2_BUF + gq + lane]) >= nlocal) != 0ull;
       // ---- a lane's NON-EMPTY hit words wait, with their group numbers, in a scratch list (lane-interleaved, read back by
       // the same lane) for the lock-step expansion at the end of the tile
       if(gcount < NB2_NG) {
@@ -887,28 +911,19 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     }
     if(!more) break;
     real4 pp[NB2_BATCH];
-    int code[NB2_BATCH];
 #pragma unroll
-    for(int u = 0; u < NB2_BATCH; u++) {
-      pp[u] = x[jj[u] >= 0 ? jj[u] : 0];
-      if(MODE == 2) code[u] = jj[u] >= nlocal ? ghost_image[jj[u] - nlocal] : 62;    // (sx+2) + 5*(sy+2) + 25*(sz+2), 62 = unshifted
-    }
+    for(int u = 0; u < NB2_BATCH; u++) pp[u] = x[jj[u] >= 0 ? jj[u] : 0];
 #pragma unroll
     for(int u = 0; u < NB2_BATCH; u++) {
       const int j = jj[u];
       bool keep = j >= 0 && !(ablate & 16);
-      int cjv = j;
-      if(MODE != 0) keep = keep && (j >= nlocal || j > imin);            // an owned j <= every tile atom is nobody's j > i
-      if(MODE == 2 && j >= nlocal) {
-        const int sx = code[u] % 5 - 2, sy = (code[u] / 5) % 5 - 2, sz = code[u] / 25 - 2;
-        if(sx == 0 && sy == 0 && sz == 0) cjv = j | NB2_LEX;
-        else if(!(sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0))))) keep = false;    // the mirrored pair keeps it
-      }
+      const int cjv = j;
       const float fx = (float)pp[u].x, fy = (float)pp[u].y, fz = (float)pp[u].z;
       const float ddx = fmaxf(fmaxf(bx0 - fx, fx - bx1), 0.0f);
       const float ddy = fmaxf(fmaxf(by0 - fy, fy - by1), 0.0f);
       const float ddz = fmaxf(fmaxf(bz0 - fz, fz - bz1), 0.0f);
       keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
+      if(MODE != 0) keep = keep && (fz >= zcull || (MODE == 1 && j >= nlocal));
       const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
       if(m) {
         const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -1260,6 +1275,24 @@ __global__ void k_rows_to_ref(const int* __restrict__ neigh, const int* __restri
   const size_t rowbase = ((size_t)(i >> 6) * stride_dev) * 64 + (i & 63);
   for(int k = threadIdx.x; k < n; k += blockDim.x) out[(size_t)i * stride_ref + k] = neigh[rowbase + (size_t)k * 64];
 }
+// half lists: the device-built rows partition the pairs by the (z,y,x) order of the two positions (k_build_rows); the
+// reference keeps an owned-owned pair on the atom with the SMALLER index (ref/neighbor.cpp:171: j <= i skipped). Re-home those
+// entries on the way out, so a downloaded list is the reference's list (rows as sets). Ghost partners stay where they are
+// (same rule in both). cnt[] must be zero; out == nullptr: counts only.
+__global__ void k_rows_to_ref_half(const int* __restrict__ neigh, const int* __restrict__ numneigh, int nlocal, int stride_dev,
+                                   int* __restrict__ out, int stride_ref, int* __restrict__ cnt)
+{
+  const int i = blockIdx.x;
+  if(i >= nlocal) return;
+  const int n = numneigh[i];
+  const size_t rowbase = ((size_t)(i >> 6) * stride_dev) * 64 + (i & 63);
+  for(int k = threadIdx.x; k < n; k += blockDim.x) {
+    const int j = neigh[rowbase + (size_t)k * 64];
+    const int home = (j >= nlocal || j > i) ? i : j;
+    const int pos = atomicAdd(&cnt[home], 1);
+    if(out && pos < stride_ref) out[(size_t)home * stride_ref + pos] = home == i ? j : i;
+  }
+}
 __global__ void k_rows_from_ref(const int* __restrict__ in, const int* __restrict__ numneigh, int nlocal, int stride_ref,
                                 int* __restrict__ neigh, int stride_dev)
 {
@@ -1275,6 +1308,25 @@ extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneigh
   if(!h || h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_neighbor_download: no neighbor list for the current atoms"); return -1; }
   MMD_TRY(mmd_ensure_rows(h));
   const int n = h->nlocal;
+  if(h->halfneigh && n) {
+    DevArr<int> tmp, cnt;
+    MMD_TRY(cnt.ensure((size_t)n + 1, false, h->stream));
+    if(neighbors) MMD_TRY(tmp.ensure((size_t)n * maxneighs, false, h->stream));
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, (size_t)n * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_rows_to_ref_half, dim3(n), dim3(64), 0, h->stream, h->neigh.p, h->numneigh.p, n, h->maxneighs,
+                       neighbors ? tmp.p : (int*)nullptr, maxneighs, cnt.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<int> hc((size_t)n);
+    HIP_TRY(hipMemcpyAsync(hc.data(), cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if(neighbors) HIP_TRY(hipMemcpyAsync(neighbors, tmp.p, (size_t)n * maxneighs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    tmp.release(); cnt.release();
+    int worst = 0;
+    for(int i = 0; i < n; i++) worst = hc[i] > worst ? hc[i] : worst;
+    if(neighbors && worst > maxneighs) { mmd_set_error("mmd_neighbor_download: a row holds %d entries, the stride is %d", worst, maxneighs); return -1; }
+    if(numneigh) memcpy(numneigh, hc.data(), (size_t)n * sizeof(int));
+    return 0;
+  }
   if(numneigh) HIP_TRY(hipMemcpyAsync(numneigh, h->numneigh.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if(neighbors && n) {
     DevArr<int> tmp;
