@@ -438,6 +438,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax) + (HALF ? eam_acc_bytes(cmax, 1) : 0));     // [knot - mlo][EAM_DSTRIDE]: coeffs 3..6 of rhor_spline, 2 unused
   real* s_part = s_tab + (size_t)(nr + 1 - mlo) * EAM_DSTRIDE;
   double* s_red = (double*)(((size_t)(s_part + 64 * (EAM_TW - 1)) + 7) & ~(size_t)7);
+  int* s_idx = (int*)(s_red + 16);                                   // HALF: the candidates' atom indices, for the flush (see k_lj_half_tile)
   for(int t = tid; t < (nr + 1 - mlo) * 4; t += NT) s_tab[(t >> 2) * EAM_DSTRIDE + (t & 3)] = rhor_spline[((t >> 2) + mlo) * 7 + 3 + (t & 3)];
   // persistent workgroups: the knots are staged once, then the workgroup walks its share of the tiles of "its" XCD
   // (workgroup b runs on XCD b % 8; XCD e owns the contiguous tile range [e*per, (e+1)*per))
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) {
       s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z;
-      if(HALF) s_racc[tt[u]] = 0;
+      if(HALF) { s_racc[tt[u]] = 0; s_idx[tt[u]] = jj[u]; }
     }
   }
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     }
     __syncthreads();
     for(int t = tid; t < ncand; t += NT) {
-      const int j = cl[t];
+      const int j = s_idx[t];
       const double a = s_racc[t];
       if(j < nlocal && a != 0) unsafeAtomicAdd(rho + j, (real)a);
     }
@@ -575,7 +576,8 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
   real* s_tab = (real*)(s_raw + eam_pos_bytes(cmax) + eam_fp_bytes(cmax) + (HALF ? eam_acc_bytes(cmax, 3) : 0));
   real* s_f = s_tab + (size_t)(nr + 1 - mlo) * EAM_FSTRIDE;
   double* s_red = (double*)(((size_t)(s_f + 3 * 64 * (EAM_FW - 1)) + 7) & ~(size_t)7);
-  unsigned char* s_gh = (unsigned char*)(s_red + 16);                  // HALF && EV: candidate is a ghost
+  int* s_idx = (int*)(s_red + 16);                                     // HALF: the candidates' atom indices, for the flush
+  unsigned char* s_gh = (unsigned char*)(s_idx + ((cmax + 2 + 3) & ~3)); // HALF && EV: candidate is a ghost
   for(int t = tid; t < (nr + 1 - mlo) * 8; t += NT) {
     const int m = (t >> 3) + mlo, c = t & 7;
     s_tab[(t >> 3) * EAM_FSTRIDE + c] = c < 3 ? rhor_spline[m * 7 + c] : (c < 7 ? z2r_spline[m * 7 + c] : (real)0);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) {
       s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; s_fp[tt[u]] = ff[u];
-      if(HALF) { s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0; }
+      if(HALF) { s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0; s_idx[tt[u]] = jj[u]; }
       if(HALF && EV) s_gh[tt[u]] = jj[u] >= nlocal ? 1 : 0;
     }
   }
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     __syncthreads();
     for(int e = tid; e < 3 * ncand; e += NT) {             // memory order: 3 doubles per candidate, candidates are runs of consecutive atoms
       const int t = (int)(((unsigned)e * 43691u) >> 17);     // e / 3 (exact below 98304)
-      const int j = cl[t];
+      const int j = s_idx[t];
       const double a = s_acc[e];
       if(j < nlocal && a != 0) unsafeAtomicAdd(f + 3 * (size_t)j + (e - 3 * t), (real)a);
     }
@@ -839,8 +841,8 @@ static size_t eam_tile_lds_force(const mmd_handle* h)
   return eam_pos_bytes(h->tile_cmax) + eam_fp_bytes(h->tile_cmax) + (size_t)(h->nr + 1 - eam_mlo(h)) * EAM_FSTRIDE * sizeof(real) +
          (size_t)3 * 64 * (EAM_FW - 1) * sizeof(real) + 8 + 16 * sizeof(double);
 }
-static size_t eam_tile_lds_density_half(const mmd_handle* h) { return eam_tile_lds_density(h) + eam_acc_bytes(h->tile_cmax, 1); }
-static size_t eam_tile_lds_force_half(const mmd_handle* h) { return eam_tile_lds_force(h) + eam_acc_bytes(h->tile_cmax, 3) + (size_t)h->tile_cmax + 16; }
+static size_t eam_tile_lds_density_half(const mmd_handle* h) { return eam_tile_lds_density(h) + eam_acc_bytes(h->tile_cmax, 1) + (size_t)4 * (h->tile_cmax + 8); }
+static size_t eam_tile_lds_force_half(const mmd_handle* h) { return eam_tile_lds_force(h) + eam_acc_bytes(h->tile_cmax, 3) + (size_t)5 * (h->tile_cmax + 8) + 16; }
 // half lists (without ghost newton) in tile form: third-law scatter through LDS accumulators
 static bool eam_half_tiles_available(const mmd_handle* h)
 {
