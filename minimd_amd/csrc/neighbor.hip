@@ -203,9 +203,8 @@ int mmd_bin_atoms(mmd_handle* h, int count)
 // Neighbor::build (ref/neighbor.cpp:79-213)
 // ---------------------------------------------------------------------------------------------------
 // MODE 0: full list (every j != i).  MODE 1: half, no ghost newton (keep j > i; ghosts always, ref :171).
-// MODE 2: half with ghost newton: every pair stored once globally — owned j: j > i; ghost j that is a
-//         periodic image: by the sign of its image vector (the mirrored pair carries the opposite one);
-//         unshifted ghost (other rank's atom): (z,y,x) lexicographic order as ref/neighbor.cpp:155-157.
+// MODE 2: half with ghost newton: every pair stored once globally — owned j: j > i; ghost j (periodic image or another
+//         rank's atom alike): (z,y,x) lexicographic order of the positions as ref/neighbor.cpp:155-157.
 //
 // Work decomposition (one wavefront per 2x2x2-bin block):
 //   * the ~27 blocks x ~57 atoms of candidates are loaded ONCE into REGISTERS, transposed: lane l holds
@@ -288,13 +287,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
           unsigned info = 1;
           if(MODE == 1) info = j >= nlocal ? 1 : 3;
           if(MODE == 2) {
-            if(j < nlocal) info = 3;
-            else {
-              const int code = ghost_image[j - nlocal];      // (sx+2) + 5*(sy+2) + 25*(sz+2), 62 = unshifted
-              const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
-              if(sx == 0 && sy == 0 && sz == 0) info = 2;
-              else info = (sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0)))) ? 1 : 0;
-            }
+            info = j < nlocal ? 3 : 2;                       // ghosts: (z,y,x) order of the positions decides (ref/neighbor.cpp:155-157)
           }
           cw[c] = (unsigned)j | (info << 29);
         }
@@ -386,9 +379,8 @@ __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, cons
 // ---------------------------------------------------------------------------------------------------
 // MODE as in k_build: 0 full list, 1 half (owned j > i, every ghost), 2 half with ghost newton (every pair once globally).
 // For the half modes the candidate index itself carries the rule: a hit also needs cj > i, which is "j > i" for owned
-// candidates and always true for ghosts (their indices follow the owned atoms); ghost-newton images that must NOT be
-// kept are stored as negative indices (never > i), unshifted ghosts (another rank's atoms) are flagged per chunk and
-// decided by the (z,y,x) order of ref/neighbor.cpp:155-157.
+// candidates and always true for ghosts (their indices follow the owned atoms); with ghost newton the ghosts are flagged
+// per chunk and decided by the (z,y,x) order of ref/neighbor.cpp:155-157.
 template <int MODE>
 __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__ x, const int* __restrict__ binned,
                                                        const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
@@ -488,16 +480,11 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
     }
   }
   // ---- half-list rules folded into the candidate index (see the kernel comment)
-  unsigned lex = 0;                                           // chunks in which MY candidate is an unshifted ghost
+  unsigned lex = 0;                                           // chunks in which MY candidate is a ghost (MODE 2)
   if(MODE == 2) {
 #pragma unroll
     for(int c = 0; c < NB_CHUNKS; c++) {
-      if(cj[c] >= nlocal) {
-        const int code = ghost_image[cj[c] - nlocal];         // (sx+2) + 5*(sy+2) + 25*(sz+2), 62 = unshifted
-        const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
-        if(sx == 0 && sy == 0 && sz == 0) lex |= 1u << c;
-        else if(!(sz > 0 || (sz == 0 && (sy > 0 || (sy == 0 && sx > 0))))) cj[c] = -2 - cj[c];   // mirrored pair keeps it
-      }
+      if(cj[c] >= nlocal) lex |= 1u << c;                     // ghosts: (z,y,x) order of the positions decides (ref/neighbor.cpp:155-157)
     }
   }
   const bool any_lex = MODE == 2 && __builtin_amdgcn_ballot_w64(lex != 0) != 0ull;
@@ -1095,10 +1082,6 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   const int nlocal = h->nlocal, nall = h->nlocal + h->nghost;
   const int nwaves = div_up(nlocal, 64);
   const BinGeom& g = h->bg;
-  if(h->halfneigh && h->ghost_newton && h->ghost_image.cap < (size_t)h->nghost + 1) {
-    mmd_set_error("mmd_neighbor_build: half lists with ghost newton need ghosts created by mmd_comm_borders");
-    return -1;
-  }
   MMD_TRY(mmd_bin_atoms(h, -1));
   MMD_TRY(h->numneigh.ensure((size_t)nlocal + 64, false, h->stream));
   const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];

@@ -173,9 +173,12 @@ def test_run_lj_half_rows_match_reference(name):
     s.close()
 
 
-def test_half_gn1_device_list_pairs_once():
-    """our ghost-newton rule (image vector) differs from the reference's bin rule but must store each pair once:
-    the half-list forces after reverse communication equal the full-list forces"""
+@pytest.mark.parametrize("build", [1, 0, -1])
+def test_half_gn1_device_list_pairs_once(build):
+    """our ghost-newton partitions (tiles: every pair on its lower atom in (z,y,x) order; row builders: owned j > i, ghosts by
+    that order) differ from the reference's half-stencil bin rule (ref/neighbor.cpp:150-170 + its half stencil) but must store
+    each pair once: the half-list forces after reverse communication equal the full-list forces, the list holds half the
+    full list's entries. build 1 = k_build_rows, 0 = k_build_tiles, -1 = k_build (no tiles)."""
     o = Oracle(["-s", 6, "-n", 20, "--half_neigh", 0])
     o.initial(); o.run()
     fo = o.f()
@@ -188,8 +191,16 @@ def test_half_gn1_device_list_pairs_once():
     h.comm_setup(o.param("cutneigh"), 0, 1)
     h.neighbor_setup(o.nbins(), o.param("cutneigh"), 1, 1, o.ntypes())
     h.force_lj_setup(*o.lj_tables())
+    if build < 0:
+        h.set_option("tiles", 0)
+    else:
+        h.set_option("build", build)
     h.exchange(); h.borders(); h.neighbor_build()
     assert h.neighbor_info()["total"] * 2 == int(o.numneigh().sum())
+    nb, nn = h.neighbor_download()                    # the downloaded rows: owned partners on the smaller index, same total
+    assert int(nn.sum()) * 2 == int(o.numneigh().sum())
+    nl = o.nlocal()
+    assert all((nb[i, :nn[i]] > i).all() for i in range(nl))
     eng, vir = h.force_compute(1)
     h.reverse_communicate()
     f = h.download(halfneigh=True)["f"][: o.nlocal()]
