@@ -165,7 +165,7 @@ def test_lj_force_half_tile_kernel_matches_oracle(prec):
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_lj_force_half_ghost_newton_tile_kernel_matches_oracle(prec):
-    """same with ghost newton (the device stores every pair once by the ghost's image vector, the reference by bin order):
+    """same with ghost newton (the device stores every pair once on its lower atom in (z,y,x) order, the reference by its half-stencil bin order):
     whole setup through the driver, forces compared on owned atoms after the reverse halo, matched by tag"""
     args = ["-s", "6", "-n", "20", "--half_neigh", "1", "-gn", "1"]
     o = Oracle(args, precision=prec)
