@@ -801,7 +801,13 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
 }
 
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
-static int borders_one_rank_fast(mmd_handle* h)
+__global__ void k_set_dummy_deferred(real4* x, int nlocal, int cap, const int* __restrict__ nghost_dev)
+{
+  x[nlocal + min(*nghost_dev, cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};      // (as k_set_dummy, util.hip)
+}
+static int borders_fast_finish(mmd_handle* h);
+
+static int borders_one_rank_fast(mmd_handle* h, bool defer)
 {
   if(!h->opt_borders_fast || h->nprocs != 1 || h->opt_force_transport || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0 || h->nlocal <= 4096) return 0;
   for(auto& s : h->swaps) if(s.sendproc != h->me) return 0;
@@ -821,6 +827,7 @@ static int borders_one_rank_fast(mmd_handle* h)
   }
   int cap_atoms = h->nmax, cap_ghost = (int)std::min<size_t>(std::min(h->ghost_image.cap, h->ghost_root.cap), 0x7fffffff);
   if(h->opt_borders_est < 100) { cap_ghost = std::min(cap_ghost, est_ghost); cap_atoms = std::min(cap_atoms, nlocal + est_ghost); }
+  const int cap_ghost_eff = std::min(cap_ghost, cap_atoms - nlocal - 1);     // ghosts the scatter kernels can place at most
   const int nt_own = div_up(nlocal, CP_TILE), nt_sw = div_up(est_nb + est_ghost, CP_TILE);
   MMD_TRY(h->flag_tmp.ensure((size_t)std::max(nt_own, 2 * nt_sw) + 8, false, h->stream));
   MMD_TRY(h->bstate.ensure(64, false, h->stream));
@@ -846,12 +853,28 @@ static int borders_one_rank_fast(mmd_handle* h)
   }
   HIP_TRY(hipGetLastError());
   static_assert(BST_GHOSTS + 6 < 40, "bst read-back window");
-  std::vector<int>& hb = h->h_bstate;
-  hb.resize(40);
+  h->bf_est_nb = est_nb;
+  if(defer) {
+    // inside a re-neighboring the counts are not needed on the host before the neighbor build has run: the kernels up to there read
+    // the ghost count from bst (deferred_count), the build's own read-back brings bst along (mmd_borders_deferred_finish)
+    h->nghost = cap_ghost_eff;                                   // (a bound, for array sizes and grids only)
+    h->nghost_dev = h->bstate.p + BST_GHOSTS + 6;
+    hipLaunchKernelGGL(k_set_dummy_deferred, dim3(1), dim3(1), 0, h->stream, h->x.p, nlocal, cap_ghost_eff, (const int*)h->nghost_dev);
+    HIP_TRY(hipGetLastError());
+    for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x.p) h->xalt_dummy_slot[k] = -1;
+    return 2;
+  }
   HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));      // nb, ovf, sendnum[6], ghost prefix
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return borders_fast_finish(h);
+}
+
+// host side of the one-rank fast path, from the bst copy in h_flags_big: 1 = done, 0 = estimates too small (general path must redo it)
+static int borders_fast_finish(mmd_handle* h)
+{
+  const int nlocal = h->nlocal;
   const int* hf = h->h_flags_big;
-  if(hf[BST_OVF] || hf[BST_NB] > est_nb) return 0;              // estimates too small: general path (it grows the arrays)
+  if(hf[BST_OVF] || hf[BST_NB] > h->bf_est_nb) return 0;        // estimates too small: general path (it grows the arrays)
   int nall = nlocal;
   for(int q = 0; q < 6; q++) {
     Swap& s = h->swaps[q];
@@ -867,22 +890,53 @@ static int borders_one_rank_fast(mmd_handle* h)
   return 1;
 }
 
+static int borders_general(mmd_handle* h);
+
 extern "C" int mmd_comm_borders(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
   h->nghost = 0;
+  h->nghost_dev = nullptr;
   {
-    const int rc = borders_one_rank_fast(h);
+    const bool defer = h->in_reneighbor && h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && h->neigh_ready;
+    const int rc = borders_one_rank_fast(h, defer);
     if(rc < 0) return rc;
-    if(rc == 1) {
-      MMD_TRY(mmd_set_dummy(h));
+    if(rc == 1) MMD_TRY(mmd_set_dummy(h));
+    if(rc >= 1) {
       h->neigh_nlocal = 0;
       h->tiles_ready = false;
       return 0;
     }
     h->nghost = 0;
   }
+  return borders_general(h);
+}
+
+// deferred one-rank borders: the bst copy has arrived in h_flags_big (the caller synchronised). 1 = host state filled in,
+// 0 = the estimates were too small: borders redone swap by swap (the caller must bin and build again), < 0 error
+int mmd_borders_deferred_finish(mmd_handle* h)
+{
+  h->nghost_dev = nullptr;
+  const int rc = borders_fast_finish(h);
+  if(rc != 0) return rc;
+  h->nghost = 0;
+  const int rg = borders_general(h);
+  return rg < 0 ? rg : 0;
+}
+// the same when nobody else is about to synchronise: fetch bst first
+int mmd_borders_deferred_resolve(mmd_handle* h)
+{
+  if(!h->nghost_dev) return 1;
+  HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int rc = mmd_borders_deferred_finish(h);
+  if(rc == 1) MMD_TRY(mmd_set_dummy(h));
+  return rc < 0 ? rc : 1;
+}
+
+static int borders_general(mmd_handle* h)
+{
   int iswap = 0;
   MMD_TRY(h->ghost_image.ensure(1024, false, h->stream));
   MMD_TRY(h->ghost_root.ensure(1024, false, h->stream));

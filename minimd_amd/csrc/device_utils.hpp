@@ -155,6 +155,12 @@ __device__ __forceinline__ int xcd_work_item(int n)
 }
 static inline int xcd_grid(int n) { return ((n + 7) / 8) * 8; }
 
+// a count that may still be on its way to the host: `bound` = nlocal + the capacity the arrays were sized for
+__device__ __forceinline__ int deferred_count(int bound, int nlocal, const int* __restrict__ nghost_dev)
+{
+  return nghost_dev ? nlocal + min(*nghost_dev, bound - nlocal) : bound;
+}
+
 // broadcast lane `l` (wave-uniform index) of a value to the whole wavefront through v_readlane (SGPR result),
 // not through the LDS crossbar
 __device__ __forceinline__ double readlane_d(double v, int l)

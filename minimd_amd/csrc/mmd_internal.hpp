@@ -197,6 +197,10 @@ struct mmd_handle {
   bool fold_reverse_now = false;
   int opt_eam_half_rows = 0;           // 1: EAM half lists on the global-atomic row kernels even where the tile kernels apply
   bool eam_half_attr_set = false;
+  const int* nghost_dev = nullptr;     // != nullptr: one-rank borders enqueued, ghost count still on the device (nghost holds a bound)
+  int bf_est_nb = 0;
+  int opt_async_counts = 1;            // re-neighboring: list sizes from the previous build, the counts return with the build's flags
+  int ntiles_hint = 0;
   int opt_time_sample = 3;             // force-kernel clock on every n-th Force::compute of a run
   int force_calls = 0;
   bool resolve_now = false, ghosts_stale = false;
@@ -230,6 +234,8 @@ struct mmd_handle {
 // ---- shared device/host helpers implemented across the .hip files
 int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve);
 int mmd_set_dummy(mmd_handle* h);
+int mmd_borders_deferred_finish(mmd_handle* h);
+int mmd_borders_deferred_resolve(mmd_handle* h);
 int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host);   // in-place, returns total
 int mmd_exclusive_scan_from(mmd_handle* h, const int* src, int* data, int n, int* total_host);   // src -> data (may alias)
 int mmd_bin_atoms(mmd_handle* h, int count);

@@ -99,9 +99,12 @@ __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
 // second round of atomics nor a zeroed cursor array (the arrival order is made deterministic by k_bin_sort).
 // Atoms arrive (nearly) sorted by bin, so the lanes of a wavefront form runs of equal bins: the first lane of a run
 // adds the run length once and the others derive their rank from it — ~7x fewer atomics on a sorted system.
+// nghost_dev != nullptr: the ghost count of a one-rank Comm::borders is still on its way to the host; n = owned atoms + the
+// capacity the arrays were sized for, the kernel clamps to owned + *nghost_dev (deferred_count, device_utils.hpp)
 __global__ __launch_bounds__(256) void k_bin_count(const real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ atom_rank,
-                                                   int* __restrict__ bin_count)
+                                                   int* __restrict__ bin_count, int nlocal, const int* __restrict__ nghost_dev)
 {
+  n = deferred_count(n, nlocal, nghost_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool valid = i < n;
@@ -121,8 +124,9 @@ __global__ __launch_bounds__(256) void k_bin_count(const real4* __restrict__ x, 
 }
 
 __global__ void k_bin_fill(const int* __restrict__ atom_bin, const int* __restrict__ atom_rank, int n, const int* __restrict__ bin_start,
-                           int* __restrict__ binned, int* __restrict__ big_flag)
+                           int* __restrict__ binned, int* __restrict__ big_flag, int nlocal, const int* __restrict__ nghost_dev)
 {
+  n = deferred_count(n, nlocal, nghost_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i == 0) *big_flag = 0;                                    // (set by k_bin_sort, the next kernel on the stream)
   if(i >= n) return;
@@ -184,9 +188,9 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   MMD_TRY(h->atom_rank.ensure((size_t)n + 1, false, h->stream));
   MMD_TRY(h->binned.ensure((size_t)n + 1, false, h->stream));
   HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
-  if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p);
+  if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr);
   MMD_TRY(mmd_exclusive_scan_from(h, h->bin_count.p, h->bin_start.p, g.mbins, nullptr));
-  hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n > 0 ? n : 1, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p, h->d_flags + 12);
+  hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n > 0 ? n : 1, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p, h->d_flags + 12, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr);
   hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->d_flags + 12);
   // bins longer than NB_BIGBIN are ordered by the grid-wide rank count (atom_bin is free again after the fill: its scratch).
   // The two launches are skipped while no such bin has been seen: the neighbor build reads the flag k_bin_sort raises
@@ -355,14 +359,14 @@ __global__ void k_tile_count(const int* __restrict__ binned, const int* __restri
   ntile_of_block[b] = owned ? (a1 - a0 + 63) >> 6 : 0;
 }
 __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, const int* __restrict__ tile_of_block,
-                            int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags)
+                            int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags, int cap)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b == 0) { flags[1] = 0; flags[3] = 0; }                   // (result flags of the build kernel that follows on the stream)
   if(b >= nblocks) return;
   const int t0 = tile_of_block[b], t1 = tile_of_block[b + 1];
   const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
-  for(int t = t0; t < t1; t++) {
+  for(int t = t0; t < t1 && t < cap; t++) {                     // (cap: the arrays may be sized from the previous build's count)
     tile_block[t] = b;
     tile_first[t] = a0 + (t - t0) * 64;
     tile_cnt[t] = min(64, a1 - tile_first[t]);
@@ -676,8 +680,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    unsigned short* __restrict__ nl16, int* __restrict__ tile_cand,
                                                    int* __restrict__ tile_ncand, int* __restrict__ tile_max, int* __restrict__ tile_ghost,
                                                    unsigned short* __restrict__ tile_self, int* __restrict__ tile_rowmax,
-                                                   int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate)
+                                                   int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate,
+                                                   const int* __restrict__ ntiles_dev, const int* __restrict__ nghost_dev)
 {
+  nall = deferred_count(nall, nlocal, nghost_dev);
   __shared__ int rng_start[128], rng_len[128];
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
@@ -688,7 +694,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   __shared__ uint2 s_gSU[NB2_NG];                     // per group of 32 buffered candidates: {first slot of its union members, which of the 32 are in the union}
   __shared__ unsigned short s_self[64];               // final slot of each tile atom itself (0xffff: not in the union)
   const int lane = threadIdx.x;
-  const int tile = xcd_work_item(ntiles);
+  // the tile count may still be on its way to the host (ntiles = capacity of the arrays, *ntiles_dev = the count)
+  const int tile = xcd_work_item(ntiles_dev ? min(ntiles, *ntiles_dev) : ntiles);
   if(tile < 0) return;
   const int b = tile_block[tile];
   const int ta = tile_first[tile], tcn = tile_cnt[tile];
@@ -989,9 +996,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
 // flags[0] = longest row, flags[2] = largest union, *total_out = sum of the row lengths
 __global__ __launch_bounds__(1024) void k_tile_reduce(const int* __restrict__ tile_rowmax, const int* __restrict__ tile_rowsum,
                                                       const int* __restrict__ tile_ncand, int ntiles, int* __restrict__ flags,
-                                                      unsigned long long* __restrict__ total_out)
+                                                      unsigned long long* __restrict__ total_out, const int* __restrict__ ntiles_dev)
 {
   __shared__ int s_a[16], s_b[16];
+  if(ntiles_dev) { if(threadIdx.x == 0) flags[6] = *ntiles_dev; ntiles = min(ntiles, *ntiles_dev); }     // flags[6]: the count for the host
   __shared__ long long s_c[16];
   int a = 0, b = 0;
   long long c = 0;
@@ -1079,6 +1087,10 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 {
   if(!h || !h->neigh_ready) { mmd_set_error("mmd_neighbor_build: call mmd_neighbor_setup first"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
+  if(h->nghost_dev && !(h->opt_tiles && h->opt_build == 1 && h->nlocal > 0)) {       // only k_build_rows reads the deferred count
+    const int rc = mmd_borders_deferred_resolve(h);
+    if(rc < 0) return rc;
+  }
   const int nlocal = h->nlocal, nall = h->nlocal + h->nghost;
   const int nwaves = div_up(nlocal, 64);
   const BinGeom& g = h->bg;
@@ -1093,8 +1105,13 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   if(want_tiles) {
     MMD_TRY(h->tile_of_block.ensure((size_t)nblocks + 2, false, h->stream));
     hipLaunchKernelGGL(k_tile_count, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->binned.p, h->bin_start.p, nblocks, nlocal, h->tile_of_block.p);
+    // the tile count sizes the lists. Once a build has succeeded the previous count (+3 %) does that and the count itself
+    // comes back with the build's result flags: one host synchronisation less per re-neighboring
     int nt = 0;
-    MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nblocks, &nt));
+    const bool nt_async = h->opt_build == 1 && h->opt_async_counts && h->ntiles_hint > 0;
+    MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nblocks, nt_async ? nullptr : &nt));
+    if(nt_async) nt = h->ntiles_hint + h->ntiles_hint / 32 + 64;
+    const int* nt_dev = nt_async ? h->tile_of_block.p + nblocks : nullptr;
     h->ntiles = nt;
     MMD_TRY(h->tile_block.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_first.ensure((size_t)nt + 2, false, h->stream));
@@ -1108,7 +1125,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
-    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags);
+    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags, nt);
     HIP_TRY(hipGetLastError());
     for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
       MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 16 * 64, false, h->stream));   // (+ prefetch overrun of the last tile)
@@ -1128,11 +1145,11 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   hipLaunchKernelGGL(k_build_rows<M>, dim3(xcd_grid(h->ntiles)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,           \
                      h->ghost_image.p, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
                      h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
-                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate)
+                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate, nt_dev, h->nghost_dev)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         hipLaunchKernelGGL(k_tile_reduce, dim3(1), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
-                           h->d_flags, (unsigned long long*)(h->d_flags + 4));
+                           h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev);
       } else if(lds > 64 * 1024) {        // the candidate-per-lane form keeps maxneighs x 64 raw slots in LDS
         want_tiles = false;
         break;
@@ -1143,9 +1160,19 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, h->stream));     // [0..3] results, [4..5] total, [12] long-bin flag
+      if(h->nghost_dev) HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       if(h->opt_build != 1) HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
       if(h->opt_build == 1) memcpy(h->h_result, h->h_flags + 4, sizeof(double));
+      if(h->nghost_dev) {                   // the ghost counts of the deferred one-rank borders arrived with the flags
+        const int rc = mmd_borders_deferred_finish(h);
+        if(rc < 0) return rc;
+        if(rc == 0) return mmd_neighbor_build(h);       // (estimates too small: borders were redone swap by swap; build again)
+      }
+      if(nt_async) {
+        if(h->h_flags[6] > h->ntiles) { h->ntiles_hint = 0; return mmd_neighbor_build(h); }     // more tiles than provided for: size from the count
+        h->ntiles = h->h_flags[6];
+      }
       if(h->h_flags[12] && !h->big_bins) {                       // a bin longer than NB_BIGBIN showed up: bin again with the rank sort on
         h->big_bins = true;
         return mmd_neighbor_build(h);
@@ -1163,6 +1190,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       h->total_neigh = (long long)tot;
       h->tile_cmax = h->h_flags[2];
       h->tiles_ready = true;
+      h->ntiles_hint = h->ntiles;
       h->neigh_nlocal = nlocal;
       h->ntiles_interior = -1;              // interior/boundary order is derived on demand (multi-rank overlap)
       return 0;

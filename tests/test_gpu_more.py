@@ -429,6 +429,33 @@ def test_reverse_communicate_folded_into_the_half_kernel(args):
     assert np.abs(out[0][2] - out[1][2]).max() <= 1e-8 * fmax
 
 
+@pytest.mark.parametrize("half", [0, 1])
+def test_reneighboring_with_counts_left_on_the_device(half):
+    """inside Integrate::run a one-rank re-neighboring reads no count before the neighbor build has run: list sizes come from the
+    previous build, the ghost and tile counts return with the build's result flags (option async_counts). Same rows, same final
+    state as the synchronous path; with estimates that are too small (borders_est 60 %) the swap-by-swap path redoes the borders."""
+    m = mm()
+    out = {}
+    for mode in ("sync", "async", "async_overflow"):
+        s = m.Sim(["-s", 14, "-n", 100, "--half_neigh", half])
+        s.handle.set_option("async_counts", 0 if mode == "sync" else 1)
+        if mode == "async_overflow":
+            s.handle.set_option("borders_est", 60)
+        s.initial(); s.run()
+        d = s.handle.download()
+        nl, ng, _ = s.handle.counts()
+        out[mode] = (s.rows(), nl, ng, s.handle.neighbor_info()["total"], d["x"][:nl].copy(), d["tag"].copy())
+        s.close()
+    for mode in ("async", "async_overflow"):
+        assert out[mode][1:4] == out["sync"][1:4]
+        if half:
+            rows_close(out[mode][0], out["sync"][0], 1e-10)          # (atomics: summation order)
+        else:
+            assert out[mode][0] == out["sync"][0]
+            np.testing.assert_array_equal(out[mode][4], out["sync"][4])
+            np.testing.assert_array_equal(out[mode][5], out["sync"][5])
+
+
 # ---- BASELINE.json sizes: golden rows + size-independent properties -----------------------------------------
 def test_baseline_s80_full_and_half():
     ent = REFRUNS["lj_s80_full_n100"]
