@@ -38,11 +38,11 @@ extern "C" int mmd_create(int device, mmd_handle** out)
   HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   HIP_TRY(hipHostMalloc((void**)&h->h_result, 32 * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&h->d_result, 32 * sizeof(double)));
-  HIP_TRY(hipHostMalloc((void**)&h->h_flags, 32 * sizeof(int), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&h->h_flags, 64 * sizeof(int), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&h->h_flags_big, 64 * sizeof(int), hipHostMallocDefault));
-  HIP_TRY(hipMalloc((void**)&h->d_flags, 32 * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&h->d_flags, 64 * sizeof(int)));
   HIP_TRY(hipMemset(h->d_result, 0, 32 * sizeof(double)));
-  HIP_TRY(hipMemset(h->d_flags, 0, 32 * sizeof(int)));
+  HIP_TRY(hipMemset(h->d_flags, 0, 64 * sizeof(int)));
   *out = h;
   return 0;
 }
@@ -301,8 +301,13 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       // completed are folded into the timers after the build, whose own count read-back has drained the stream anyway
       h->in_reneighbor = true;
       int rc = ev_begin(h, 2);
+      const bool sort_now = first_step + n + 1 >= h->next_sort;
+      // one rank: Comm::exchange is Atom::pbc alone; when Atom::sort follows, its binning pass wraps the atoms on the way
+      h->pbc_defer = sort_now && h->nprocs == 1 && h->opt_async_counts && h->nlocal > 0 && h->neigh_ready;
       if(rc >= 0) rc = mmd_comm_exchange(h);
-      if(rc >= 0 && first_step + n + 1 >= h->next_sort) { rc = mmd_atom_sort(h); h->next_sort += h->sort_every; }
+      h->pbc_defer = false;
+      if(rc >= 0 && sort_now) { rc = mmd_atom_sort(h); h->next_sort += h->sort_every; }
+      if(h->pbc_pending) { mmd_set_error("Integrate::run: deferred Atom::pbc was not applied"); rc = -1; h->pbc_pending = false; }
       if(rc >= 0) rc = mmd_comm_borders(h);
       h->in_reneighbor = false;
       MMD_TRY(rc);

@@ -133,6 +133,7 @@ __global__ void k_pbc(real4* __restrict__ x, int n, real xprd, real yprd, real z
 extern "C" int mmd_atom_pbc(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
+  if(h->pbc_defer) { h->pbc_pending = true; return 0; }        // (Atom::sort follows: its binning pass wraps the atoms on the way)
   if(h->nlocal)
     hipLaunchKernelGGL(k_pbc, dim3(div_up(h->nlocal, 256)), dim3(256), 0, h->stream, h->x.p, h->nlocal, h->prd[0], h->prd[1], h->prd[2]);
   HIP_TRY(hipGetLastError());

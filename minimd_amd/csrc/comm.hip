@@ -684,9 +684,10 @@ __device__ __forceinline__ int block_prefix_total(const int* __restrict__ cnt, i
   return tot;
 }
 
-__global__ __launch_bounds__(256) void k_bnd_count(const real4* __restrict__ x, int nlocal, SlabSet S, int* __restrict__ cnt)
+__global__ __launch_bounds__(256) void k_bnd_count(const real4* __restrict__ x, int nlocal, SlabSet S, int* __restrict__ cnt, int* __restrict__ bst)
 {
   __shared__ int lds[17];
+  if(blockIdx.x == 0 && threadIdx.x < 64) bst[threadIdx.x] = 0;          // the state words of this borders pass (first written by k_bnd_scatter)
   const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
   int c = 0;
 #pragma unroll
@@ -801,10 +802,6 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
 }
 
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
-__global__ void k_set_dummy_deferred(real4* x, int nlocal, int cap, const int* __restrict__ nghost_dev)
-{
-  x[nlocal + min(*nghost_dev, cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};      // (as k_set_dummy, util.hip)
-}
 static int borders_fast_finish(mmd_handle* h);
 
 static int borders_one_rank_fast(mmd_handle* h, bool defer)
@@ -831,11 +828,10 @@ static int borders_one_rank_fast(mmd_handle* h, bool defer)
   const int nt_own = div_up(nlocal, CP_TILE), nt_sw = div_up(est_nb + est_ghost, CP_TILE);
   MMD_TRY(h->flag_tmp.ensure((size_t)std::max(nt_own, 2 * nt_sw) + 8, false, h->stream));
   MMD_TRY(h->bstate.ensure(64, false, h->stream));
-  HIP_TRY(hipMemsetAsync(h->bstate.p, 0, 64 * sizeof(int), h->stream));
   SlabSet S;
   S.n = 6;
   for(int q = 0; q < 6; q++) { S.lo[q] = h->swaps[q].slablo; S.hi[q] = h->swaps[q].slabhi; S.dim[q] = h->swaps[q].dim; }
-  hipLaunchKernelGGL(k_bnd_count, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p);
+  hipLaunchKernelGGL(k_bnd_count, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bstate.p);
   hipLaunchKernelGGL(k_bnd_scatter, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bnd_list.p, h->bstate.p);
   for(int q = 0; q < 6; q += 2) {
     SwapPair P;
@@ -859,8 +855,7 @@ static int borders_one_rank_fast(mmd_handle* h, bool defer)
     // the ghost count from bst (deferred_count), the build's own read-back brings bst along (mmd_borders_deferred_finish)
     h->nghost = cap_ghost_eff;                                   // (a bound, for array sizes and grids only)
     h->nghost_dev = h->bstate.p + BST_GHOSTS + 6;
-    hipLaunchKernelGGL(k_set_dummy_deferred, dim3(1), dim3(1), 0, h->stream, h->x.p, nlocal, cap_ghost_eff, (const int*)h->nghost_dev);
-    HIP_TRY(hipGetLastError());
+    // (the dummy atom behind the last ghost is written by k_tile_fill of the neighbor build that follows)
     for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x.p) h->xalt_dummy_slot[k] = -1;
     return 2;
   }

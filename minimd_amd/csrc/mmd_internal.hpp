@@ -199,6 +199,8 @@ struct mmd_handle {
   bool eam_half_attr_set = false;
   const int* nghost_dev = nullptr;     // != nullptr: one-rank borders enqueued, ghost count still on the device (nghost holds a bound)
   int bf_est_nb = 0;
+  bool pbc_defer = false, pbc_pending = false;     // Atom::pbc folded into the binning pass of the Atom::sort that follows
+  int bin_count_clean = -1;            // mbins for which bin_count is known to be all zero (k_bin_sort leaves it so)
   int opt_async_counts = 1;            // re-neighboring: list sizes from the previous build, the counts return with the build's flags
   int ntiles_hint = 0;
   int opt_time_sample = 3;             // force-kernel clock on every n-th Force::compute of a run

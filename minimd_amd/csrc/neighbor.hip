@@ -65,6 +65,7 @@ extern "C" int mmd_neighbor_setup(mmd_handle* h, const int nbin[3], mmd_float cu
   h->neigh_nlocal = 0;
   if(h->host_only) return 0;
   MMD_TRY(h->bin_count.ensure((size_t)g.mbins + 2, false, h->stream));
+  h->bin_count_clean = -1;
   MMD_TRY(h->bin_start.ensure((size_t)g.mbins + 2, false, h->stream));
   h->neigh_ready = true;
   h->neigh_nlocal = 0;
@@ -101,15 +102,30 @@ __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
 // adds the run length once and the others derive their rank from it — ~7x fewer atomics on a sorted system.
 // nghost_dev != nullptr: the ghost count of a one-rank Comm::borders is still on its way to the host; n = owned atoms + the
 // capacity the arrays were sized for, the kernel clamps to owned + *nghost_dev (deferred_count, device_utils.hpp)
-__global__ __launch_bounds__(256) void k_bin_count(const real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ atom_rank,
-                                                   int* __restrict__ bin_count, int nlocal, const int* __restrict__ nghost_dev)
+// pbc: Atom::pbc (ref/atom.cpp:106-122, same tests in the same order as k_pbc) is applied on the way — one-rank re-neighborings that sort
+// wrap and bin the owned atoms in one pass.
+__global__ __launch_bounds__(256) void k_bin_count(real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ atom_rank,
+                                                   int* __restrict__ bin_count, int nlocal, const int* __restrict__ nghost_dev, int pbc,
+                                                   real xprd, real yprd, real zprd)
 {
   n = deferred_count(n, nlocal, nghost_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool valid = i < n;
   int b = -1 - lane;                                          // lanes past the end never join a run
-  if(valid) { const real4 p = x[i]; b = bin_of(g, p.x, p.y, p.z); }
+  if(valid) {
+    real4 p = x[i];
+    if(pbc) {
+      if(p.x < (real)0.0) p.x += xprd;
+      if(p.x >= xprd) p.x -= xprd;
+      if(p.y < (real)0.0) p.y += yprd;
+      if(p.y >= yprd) p.y -= yprd;
+      if(p.z < (real)0.0) p.z += zprd;
+      if(p.z >= zprd) p.z -= zprd;
+      x[i] = p;
+    }
+    b = bin_of(g, p.x, p.y, p.z);
+  }
   const int prev = __shfl_up(b, 1, 64);
   const bool head = lane == 0 || b != prev;
   const unsigned long long heads = __builtin_amdgcn_ballot_w64(head);
@@ -136,10 +152,13 @@ __global__ void k_bin_fill(const int* __restrict__ atom_bin, const int* __restri
 // one thread per bin: insertion sort of its (short) slice -> ascending atom index, run-to-run identical.
 // Bins longer than NB_BIGBIN (e.g. `-b 1`: every atom in one bin) are left to k_bin_sort_big.
 #define NB_BIGBIN 96
-__global__ void k_bin_sort(const int* __restrict__ bin_start, int mbins, int* __restrict__ binned, int* __restrict__ big_flag)
+__global__ void k_bin_sort(const int* __restrict__ bin_start, int mbins, int* __restrict__ binned, int* __restrict__ big_flag,
+                           int* __restrict__ bin_count)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if(b >= mbins) return;
+  if(b > mbins) return;
+  bin_count[b] = 0;                                           // the histogram has been scanned: leave it zeroed for the next binning
+  if(b == mbins) return;
   const int s = bin_start[b], e = bin_start[b + 1];
   if(e - s > NB_BIGBIN) { *big_flag = 1; return; }
   for(int a = s + 1; a < e; a++) {
@@ -187,11 +206,15 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   MMD_TRY(h->atom_bin.ensure((size_t)n + 1, false, h->stream));
   MMD_TRY(h->atom_rank.ensure((size_t)n + 1, false, h->stream));
   MMD_TRY(h->binned.ensure((size_t)n + 1, false, h->stream));
-  HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
-  if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr);
+  if(h->bin_count_clean != g.mbins)            // (first use / new geometry; afterwards k_bin_sort leaves the histogram zeroed)
+    HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
+  h->bin_count_clean = -1;
+  if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr,
+                           h->pbc_pending ? 1 : 0, h->prd[0], h->prd[1], h->prd[2]);
+  h->pbc_pending = false;
   MMD_TRY(mmd_exclusive_scan_from(h, h->bin_count.p, h->bin_start.p, g.mbins, nullptr));
   hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n > 0 ? n : 1, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p, h->d_flags + 12, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr);
-  hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->d_flags + 12);
+  hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins + 1, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->d_flags + 12, h->bin_count.p);
   // bins longer than NB_BIGBIN are ordered by the grid-wide rank count (atom_bin is free again after the fill: its scratch).
   // The two launches are skipped while no such bin has been seen: the neighbor build reads the flag k_bin_sort raises
   // (with its own result flags) and then switches them on and bins again.
@@ -200,6 +223,7 @@ int mmd_bin_atoms(mmd_handle* h, int count)
     hipLaunchKernelGGL(k_bin_copy_big, dim3(128), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->atom_bin.p, h->d_flags + 12);
   }
   HIP_TRY(hipGetLastError());
+  h->bin_count_clean = g.mbins;
   return 0;
 }
 
@@ -359,10 +383,13 @@ __global__ void k_tile_count(const int* __restrict__ binned, const int* __restri
   ntile_of_block[b] = owned ? (a1 - a0 + 63) >> 6 : 0;
 }
 __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, const int* __restrict__ tile_of_block,
-                            int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags, int cap)
+                            int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags, int cap,
+                            real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b == 0) { flags[1] = 0; flags[3] = 0; }                   // (result flags of the build kernel that follows on the stream)
+  // deferred one-rank borders: the dummy atom (far outside any cutoff, see k_set_dummy) goes behind the last ghost, whose number only the device knows yet
+  if(b == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
   if(b >= nblocks) return;
   const int t0 = tile_of_block[b], t1 = tile_of_block[b + 1];
   const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
@@ -996,9 +1023,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
 // flags[0] = longest row, flags[2] = largest union, *total_out = sum of the row lengths
 __global__ __launch_bounds__(1024) void k_tile_reduce(const int* __restrict__ tile_rowmax, const int* __restrict__ tile_rowsum,
                                                       const int* __restrict__ tile_ncand, int ntiles, int* __restrict__ flags,
-                                                      unsigned long long* __restrict__ total_out, const int* __restrict__ ntiles_dev)
+                                                      unsigned long long* __restrict__ total_out, const int* __restrict__ ntiles_dev,
+                                                      const int* __restrict__ bst)
 {
   __shared__ int s_a[16], s_b[16];
+  if(bst && threadIdx.x < 40) flags[16 + threadIdx.x] = bst[threadIdx.x];          // deferred one-rank borders: its counts travel with the flags
   if(ntiles_dev) { if(threadIdx.x == 0) flags[6] = *ntiles_dev; ntiles = min(ntiles, *ntiles_dev); }     // flags[6]: the count for the host
   __shared__ long long s_c[16];
   int a = 0, b = 0;
@@ -1125,7 +1154,8 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
-    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags, nt);
+    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags, nt,
+                       h->x.p, nlocal, h->nghost, h->nghost_dev);
     HIP_TRY(hipGetLastError());
     for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
       MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 16 * 64, false, h->stream));   // (+ prefetch overrun of the last tile)
@@ -1149,7 +1179,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         hipLaunchKernelGGL(k_tile_reduce, dim3(1), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
-                           h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev);
+                           h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr);
       } else if(lds > 64 * 1024) {        // the candidate-per-lane form keeps maxneighs x 64 raw slots in LDS
         want_tiles = false;
         break;
@@ -1159,12 +1189,13 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #undef LAUNCH_ROWS
 #undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, h->stream));     // [0..3] results, [4..5] total, [12] long-bin flag
-      if(h->nghost_dev) HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      // [0..3] results, [4..5] total, [6] tile count, [12] long-bin flag, [16..55] bst of a deferred one-rank borders
+      HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, (h->nghost_dev ? 56 : 16) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       if(h->opt_build != 1) HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
       if(h->opt_build == 1) memcpy(h->h_result, h->h_flags + 4, sizeof(double));
       if(h->nghost_dev) {                   // the ghost counts of the deferred one-rank borders arrived with the flags
+        memcpy(h->h_flags_big, h->h_flags + 16, 40 * sizeof(int));
         const int rc = mmd_borders_deferred_finish(h);
         if(rc < 0) return rc;
         if(rc == 0) return mmd_neighbor_build(h);       // (estimates too small: borders were redone swap by swap; build again)
