@@ -232,6 +232,9 @@ def main():
         # new x: +80 B/atom, and skips the f store: -24 B); `achieved` still counts only SURVEY §8d's force-kernel bytes
         "roofline": {"bound": "hbm", "kernel": "k_lj_full_tile (ForceLJ::compute_fullneigh + fused Integrate)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
+                     # `frac` is the in-run figure (events on the timed region's own launches, every 3rd one; these launches also carry the
+                     # integrator); `frac_kernel_only` = SURVEY 8(d)'s force kernel alone on the same thermalised state, 20 launches
+                     "frac_in_run": (achieved / HBM_PEAK_GBS) if achieved else None, "launches_timed_every": 3,
                      "kernel_only_ms": k_only_ms,
                      "frac_kernel_only": (bpa * nlocal / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_only_ms else None,
                      "measured_copy_GBs": copy_gbs,
