@@ -104,7 +104,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+        import datetime
+        # control plane only; a short timeout so that a rank that died does not park the others for the default half hour
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
         ndev = max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank % ndev)
         if ndev < world and "MMD_BENCH_TRANSPORT" not in os.environ:
