@@ -64,7 +64,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->buf_send.release(); h->buf_recv.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if(h->ev_x_ready) { (void)hipEventDestroy(h->ev_x_ready); (void)hipEventDestroy(h->ev_halo_done); }
-  h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release(); h->tile_words.release();
+  h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release(); h->tile_words.release(); h->tile_kcore.release(); h->xbuild.release(); h->core_words.release();
   if(h->h_result) (void)hipHostFree(h->h_result);
   if(h->d_result) (void)hipFree(h->d_result);
   if(h->h_flags) (void)hipHostFree(h->h_flags);
@@ -105,6 +105,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "fold_reverse")) h->opt_fold_reverse = value;
   else if(!strcmp(name, "eam_half_rows")) h->opt_eam_half_rows = value;
   else if(!strcmp(name, "async_counts")) h->opt_async_counts = value;
+  else if(!strcmp(name, "core_pct")) h->opt_core_pct = value;
   else if(!strcmp(name, "borders_fast")) h->opt_borders_fast = value;
   else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
@@ -233,6 +234,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
   const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport);
   bool halo_pending = false, collect_pending = false;
+  int core_next = 0;                 // CoreRows: what the next force call may assume about the displacement since the build
   // the per-step halos are timed (into TIME_COMM) only where they are more than one tiny kernel: an event pair costs the stream
   // two markers, ~5 us per step that a -s 32 run would notice
   // one rank, half lists with ghost newton in tile form: a ghost's share of a pair goes straight to its owner
@@ -316,6 +318,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       MMD_TRY(ev_begin(h, 3));
       MMD_TRY(mmd_neighbor_build(h));
       MMD_TRY(ev_end(h));
+      core_next = 1;                               // the atoms are where the build saw them
       collect_pending = true;                  // (folded into the timers once this step's force kernel is in flight)
     }
     const int step = first_step + n + 1;
@@ -336,10 +339,14 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       h->fuse_now = fused_force;
       h->resolve_now = h->ghosts_stale;
       h->fold_reverse_now = folded = fold && h->ghost_chain_ok && mmd_lj_half_tiles_available(h);
+      h->core.mode_now = core_next;                // rows in two parts (CoreRows): which part this call may walk
+      h->core.tracked_last = false;
       const int rc = force_compute_async(h, evflag, nullptr, nullptr, true);
       h->fuse_now = 0;
       h->resolve_now = false;
       h->fold_reverse_now = false;
+      h->core.mode_now = 0;
+      core_next = h->core.tracked_last ? 2 : 0;
       MMD_TRY(rc);
     }
     if(reverse && !folded) {

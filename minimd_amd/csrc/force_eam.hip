@@ -414,6 +414,25 @@ __host__ __device__ constexpr size_t eam_fp_bytes(int cmax) { return (((size_t)(
 // half lists: n double accumulators per candidate (1: rho, 3: f) — doubles in both precisions, see k_lj_half_tile
 __host__ __device__ constexpr size_t eam_acc_bytes(int cmax, int n) { return (((size_t)n * (cmax + 2) * sizeof(double)) + 15) & ~(size_t)15; }
 
+// Rows in two parts (CoreRows, mmd_internal.hpp): which part a launch walks, and the displacement tracking of the fused integrator
+struct EamCore {
+  const int* tile_kcore;        // nullptr: whole rows always
+  int mode;                     // 0 whole rows, 1 core part, 2 core part if the displacement read from words_read allows it
+  const unsigned* words_read;   // 64 words: float bits of the largest squared displacement since the build (written by the previous launch)
+  unsigned* words_write;        // FUSE launches: this launch's set / the set to clear for the next launch
+  unsigned* words_zero;
+  float thr_d2;                 // (margin / 2)^2
+  const real4* xbuild;          // positions at the build
+  int ablate;                   // profiling only (results invalid): 1 no staging, 2 no pair loop
+};
+__device__ __forceinline__ bool eam_use_core(const EamCore& C, int lane)
+{
+  if(C.tile_kcore == nullptr || C.mode == 0) return false;
+  if(C.mode == 1) return true;
+  const unsigned w = wave_max_u(C.words_read[lane & 63]);
+  return __uint_as_float(w) <= C.thr_d2;
+}
+
 // HALF=1: ForceEAM::compute_halfneigh's first loop (ref/force_eam.cpp:131-160) on a half-list tile: a pair's term goes to the atom
 // in registers and to its PARTNER through an LDS accumulator per candidate (ds_add_f64); at the end of the tile the accumulators
 // of the owned candidates are flushed to rho[] with one global atomic each, in memory order (whole lines per wave instruction,
@@ -425,7 +444,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, int cmax, real rdr, real rdrho, real* __restrict__ fp,
-    double* __restrict__ partials, int mlo, const unsigned short* __restrict__ tile_self, real* __restrict__ rho)
+    double* __restrict__ partials, int mlo, const unsigned short* __restrict__ tile_self, real* __restrict__ rho, EamCore C)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_TW;
@@ -443,6 +462,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   // persistent workgroups: the knots are staged once, then the workgroup walks its share of the tiles of "its" XCD
   // (workgroup b runs on XCD b % 8; XCD e owns the contiguous tile range [e*per, (e+1)*per))
   const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;
+  const bool use_core = eam_use_core(C, lane);          // (uniform over the whole launch)
   for(int tq = blockIdx.x >> 3; tq < per_xcd; tq += wg_per_xcd) {
   const int witem = (blockIdx.x & 7) * per_xcd + tq;          // ntiles = length of the work list (all tiles, or one part of them)
   if(witem >= ntiles) break;
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   __syncthreads();                                      // previous tile's readers are done with s_pos / s_part
   const int ncand = tile_ncand[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int t0 = 0; t0 <= ncand; t0 += EAM_STAGE * NT) {  // branch-free: cl[ncand] holds the dummy atom's index
+  for(int t0 = 0; t0 <= ncand && !(C.ablate & 1); t0 += EAM_STAGE * NT) {  // branch-free: cl[ncand] holds the dummy atom's index
     int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
@@ -466,7 +486,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
-  const int kmax = tile_max[tile];
+  const int kmax = (C.ablate & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
   const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
@@ -560,7 +580,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
     double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, int mlo,
-    const unsigned short* __restrict__ tile_self)
+    const unsigned short* __restrict__ tile_self, EamCore C)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_FW;
@@ -583,6 +603,9 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     s_tab[(t >> 3) * EAM_FSTRIDE + c] = c < 3 ? rhor_spline[m * 7 + c] : (c < 7 ? z2r_spline[m * 7 + c] : (real)0);
   }
   const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;     // persistent workgroups, see k_eam_density_tile
+  const bool use_core = eam_use_core(C, lane);
+  if(FUSE && C.words_zero != nullptr && blockIdx.x == 0 && tid < 64) C.words_zero[tid] = 0;       // the set the NEXT launch will write
+  float d2max = 0;                                    // FUSE: largest squared displacement since the build over this workgroup's atoms
   for(int tq = blockIdx.x >> 3; tq < per_xcd; tq += wg_per_xcd) {
   const int witem = (blockIdx.x & 7) * per_xcd + tq;          // ntiles = length of the work list (all tiles, or one part of them)
   if(witem >= ntiles) break;
@@ -590,7 +613,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
   __syncthreads();
   const int ncand = tile_ncand[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int t0 = 0; t0 <= ncand; t0 += EAM_STAGE * NT) {
+  for(int t0 = 0; t0 <= ncand && !(C.ablate & 1); t0 += EAM_STAGE * NT) {
     int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
@@ -609,7 +632,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   const real fpi = fp[i >= 0 ? i : 0];
-  const int kmax = tile_max[tile];
+  const int kmax = (C.ablate & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
   const int per = ((kmax / EAM_TU + EAM_FW - 1) / EAM_FW) * EAM_TU;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
@@ -719,7 +742,13 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
       vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
       vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
       v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
-      xnew[i] = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
+      const real4 xn = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
+      xnew[i] = xn;
+      if(C.words_write != nullptr) {                  // how far from its position at the build (rounded up: it gates the core rows)
+        const real4 xb = C.xbuild[i];
+        const real ex = xn.x - xb.x, ey = xn.y - xb.y, ez = xn.z - xb.z;
+        d2max = fmaxf(d2max, (float)(ex * ex + ey * ey + ez * ez) * 1.000001f + 1.0e-30f);
+      }
     }
   }
   if(HALF) {
@@ -741,6 +770,10 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     }
   }
   }   // tile loop
+  if(FUSE && C.words_write != nullptr && wv == 0) {
+    const unsigned m = wave_max_u(__float_as_uint(d2max));       // (d2 >= 0: float bits order like the values)
+    if(lane == 0 && m != 0u) atomicMax(&C.words_write[blockIdx.x & 63], m);
+  }
 }
 
 // eng_vdwl = 2*(E_embed + sum phi/2) (ref/force_eam.cpp:446), virial = sum
@@ -888,7 +921,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     hipLaunchKernelGGL((k_eam_density_tile<0, 1>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p, h->tile_first.p,
                        h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,
                        h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr, h->nrho, h->tile_cmax, h->rdr, h->rdrho,
-                       h->fp.p, (double*)nullptr, mlo, h->tile_self.p, h->rho.p);
+                       h->fp.p, (double*)nullptr, mlo, h->tile_self.p, h->rho.p, EamCore{});
     if(evflag) hipLaunchKernelGGL((k_eam_half_fp<1>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p, 1, h->nrho,
                                   h->nrho_tot, h->rdrho, h->fp.p, p_embed);
     else hipLaunchKernelGGL((k_eam_half_fp<0>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p, 1, h->nrho,
@@ -898,7 +931,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define FH(EVv) hipLaunchKernelGGL((k_eam_force_tile<EVv, 0, 1>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p, h->tile_first.p, \
                        h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,   \
                        h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr, h->tile_cmax, h->rdr, h->fp.p, h->f.p, p_pair,          \
-                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p)
+                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p, EamCore{})
     if(evflag) FH(1); else FH(0);
 #undef FH
     HIP_TRY(hipGetLastError());
@@ -972,14 +1005,28 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       h->eam_attr_set = true;
     }
+    // rows in two parts (CoreRows): the run loop says which part this call may walk; a fused launch tracks the displacement for the next
+    EamCore core{};
+    core.ablate = h->opt_ablate;
+    if(h->core.rows_built && h->core_words.p) {
+      core.tile_kcore = h->tile_kcore.p;
+      core.mode = h->core.mode_now;
+      core.words_read = h->core_words.p + 64 * ((h->core.step + 2) % 3);       // written by the previous tracked launch
+      core.thr_d2 = (float)(0.25 * (double)h->core.margin * (double)h->core.margin * (1.0 - 1.0e-6));
+      core.xbuild = h->xbuild.p;
+      if(h->fuse_now && !h->halo_pending) {
+        core.words_write = h->core_words.p + 64 * (h->core.step % 3);
+        core.words_zero = h->core_words.p + 64 * ((h->core.step + 1) % 3);
+      }
+    }
 #define DT(EVv, LIST, CNT) hipLaunchKernelGGL((k_eam_density_tile<EVv, 0>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
-                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo, (const unsigned short*)nullptr, (real*)nullptr)
+                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo, (const unsigned short*)nullptr, (real*)nullptr, core)
 #define FT(EVv, Fv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv, 0>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p,       \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
-                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr)
+                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr, core)
     auto density = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) DT(1, list, cnt); else DT(0, list, cnt); } };
     auto force = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) FT(1, 0, list, cnt); else if(h->fuse_now) FT(0, 1, list, cnt); else FT(0, 0, list, cnt); } };
     if(h->halo_pending) {
@@ -1009,6 +1056,8 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       MMD_TRY(eam_fp_halo(h));
       force(nullptr, nt);
     }
+    h->core.tracked_last = core.words_write != nullptr && !evflag;       // (the launch that just went out advanced the atoms and recorded how far they are from the build)
+    if(h->core.tracked_last) h->core.step++;
 #undef DT
 #undef FT
     HIP_TRY(hipGetLastError());

@@ -144,6 +144,24 @@ struct mmd_handle {
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
   DevArr<unsigned short> tile_self;       // half lists: union slot of each tile atom itself (0xffff: not in the union)
+  // Rows in two parts (full lists, one rank): pairs closer than `radius` = cutforce + margin at the build come first ("core"), the rest of
+  // the skin behind them; tile_kcore = padded length of the core part. A pair of the rest can only come inside the force cutoff after
+  // its two atoms have moved `margin` towards each other, so for as long as no atom has moved further than margin/2 since the build a
+  // force kernel may stop after the core part — and computes exactly the same forces. The fused integrator of the tile force kernels
+  // tracks the largest displacement since the build (xbuild) in `words` (3 sets of 64 unsigned = float bits of d^2: the kernel of step n
+  // writes set n%3, the kernel of step n+1 reads it, set (n+1)%3 is zeroed meanwhile).
+  struct CoreRows {
+    real radius = 0;             // 0: off
+    real margin = 0;
+    bool rows_built = false;     // the current tile lists are in two parts
+    int mode_now = 0;            // set by Integrate::run around a force call: 0 whole rows, 1 core part (positions are those of the build),
+                                 // 2 core part if the displacement tracked by the previous launch allows it
+    bool tracked_last = false;   // the last force call advanced the atoms inside the kernel and recorded their displacement
+    unsigned step = 0;           // launches with tracking so far (selects the word sets)
+  } core;
+  DevArr<int> tile_kcore;
+  DevArr<real4> xbuild;
+  DevArr<unsigned> core_words;
   DevArr<unsigned> tile_words;            // scratch of k_build_rows: per tile the hit words of its candidate groups [group][lane]
   DevArr<int> tile_rowmax, tile_rowsum;   // per tile: longest row / sum of the row lengths (reduced by k_tile_reduce)
   DevArr<int> tile_ghost, tile_order;     // per tile: references a ghost atom?; tiles ordered interior-first
@@ -201,6 +219,7 @@ struct mmd_handle {
   int bf_est_nb = 0;
   bool pbc_defer = false, pbc_pending = false;     // Atom::pbc folded into the binning pass of the Atom::sort that follows
   int bin_count_clean = -1;            // mbins for which bin_count is known to be all zero (k_bin_sort leaves it so)
+  int opt_core_pct = 30;               // EAM full lists on one rank: rows in two parts, the core part ends this many per cent into the skin (0: off)
   int opt_async_counts = 1;            // re-neighboring: list sizes from the previous build, the counts return with the build's flags
   int ntiles_hint = 0;
   int opt_time_sample = 3;             // force-kernel clock on every n-th Force::compute of a run

@@ -387,7 +387,7 @@ __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, cons
                             real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if(b == 0) { flags[1] = 0; flags[3] = 0; }                   // (result flags of the build kernel that follows on the stream)
+  if(b == 0) { flags[1] = 0; flags[3] = 0; flags[7] = 0; }     // (result flags of the build kernel that follows on the stream)
   // deferred one-rank borders: the dummy atom (far outside any cutoff, see k_set_dummy) goes behind the last ghost, whose number only the device knows yet
   if(b == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
   if(b >= nblocks) return;
@@ -698,7 +698,7 @@ __device__ __forceinline__ unsigned nb2_shift_in(unsigned bits, unsigned long lo
 
 typedef float nb2_f2 __attribute__((ext_vector_type(2)));
 
-template <int MODE>
+template <int MODE, int CORE>
 __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, const int* __restrict__ binned,
                                                    const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
                                                    BinGeom g, int ntiles, int nlocal, int nall, real cutneigh, real cutneighsq, int maxneighs, int cstride,
@@ -708,7 +708,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    int* __restrict__ tile_ncand, int* __restrict__ tile_max, int* __restrict__ tile_ghost,
                                                    unsigned short* __restrict__ tile_self, int* __restrict__ tile_rowmax,
                                                    int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate,
-                                                   const int* __restrict__ ntiles_dev, const int* __restrict__ nghost_dev)
+                                                   const int* __restrict__ ntiles_dev, const int* __restrict__ nghost_dev,
+                                                   float core_thr, real4* __restrict__ xbuild, int* __restrict__ tile_kcore)
 {
   nall = deferred_count(nall, nlocal, nghost_dev);
   __shared__ int rng_start[128], rng_len[128];
@@ -785,10 +786,17 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
-  // scratch of this tile: NB2_NG x 64 words followed by NB2_NG x 64 group numbers (bytes)
-  unsigned* __restrict__ ent_w = tile_words + (size_t)tile * (NB2_NG * 80) + lane;
-  unsigned char* __restrict__ ent_g = (unsigned char*)(tile_words + (size_t)tile * (NB2_NG * 80) + NB2_NG * 64) + lane;
+  // scratch of this tile: NB2_NG x 64 words followed by NB2_NG x 64 group numbers (bytes); CORE: a second list of the same shape
+  constexpr int WSTRIDE = NB2_NG * 80 * (CORE ? 2 : 1);
+  unsigned* __restrict__ ent_w = tile_words + (size_t)tile * WSTRIDE + lane;
+  unsigned char* __restrict__ ent_g = (unsigned char*)(tile_words + (size_t)tile * WSTRIDE + NB2_NG * 64) + lane;
   int n = 0;                               // my row length
+  // CORE: the row is written in two parts, the entries closer than core_thr at the build first ("core"), the rest of the skin behind
+  // them: a force kernel may stop after the core part for as long as no atom has moved further than half the margin between the
+  // core radius and the force cutoff since the build (mmd_internal.hpp: CoreRows). The lists above hold the core part, these the rest.
+  unsigned* __restrict__ ent2_w = ent_w + NB2_NG * 80;
+  unsigned char* __restrict__ ent2_g = ent_g + (size_t)NB2_NG * 80 * 4;
+  int cnt2 = 0, n2 = 0;
   bool any_ghost = false;
 
   // ---- phase 2 + expansion over the buffered candidates
@@ -803,7 +811,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     const int selfpos = MODE == 0 ? (int)s_selfpos[lane] : -1;
     for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
-      unsigned bits = 0, bits_hi = 0;
+      unsigned bits = 0, bits_hi = 0, bits_c = 0;
       for(int q = 0; q < G; q += 8) {
         // 8 buffered candidates per trip: 6 ds_read_b128 (uniform addresses). On this part a VALU instruction costs a
         // wavefront the same issue slot whether it is 32 or 64 bits wide, but v_pk_*_f32 handles TWO floats per lane: the
@@ -860,6 +868,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             }
             bits = nb2_shift_in(bits, m);
             if(NB2_PF) bits_hi = nb2_shift_in(bits_hi, mh);
+            if(CORE) bits_c = nb2_shift_in(bits_c, __builtin_amdgcn_fcmpf(rsq, core_thr, 5));     // (a classification, not a decision: float is enough)
           }
         }
       }
@@ -897,6 +906,14 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       // ---- a lane's NON-EMPTY hit words wait, with their group numbers, in a scratch list (lane-interleaved, read back by
       // the same lane) for the lock-step expansion at the end of the tile
       if(gcount < NB2_NG) {
+        if(CORE) {
+          bits_c &= bits;
+          const unsigned rest = bits & ~bits_c;
+          if(bits_c != 0u) { ent_w[(unsigned)cnt * 64u] = bits_c; ent_g[(unsigned)cnt * 64u] = (unsigned char)gcount; cnt++; }
+          if(rest != 0u) { ent2_w[(unsigned)cnt2 * 64u] = rest; ent2_g[(unsigned)cnt2 * 64u] = (unsigned char)gcount; cnt2++; }
+          n2 += __popc(rest);
+          bits = bits_c;                                         // (n counts the core part below)
+        } else
         if(bits != 0u) { ent_w[(unsigned)cnt * 64u] = bits; ent_g[(unsigned)cnt * 64u] = (unsigned char)gcount; cnt++; }
         if(lane == 0) s_gSU[gcount] = uint2{(unsigned)S, used};
       }
@@ -966,30 +983,38 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // dummy slot = S, staged by the force kernels behind the candidates, once its bits are used up), so every store is one whole
   // 128-byte line of nl16 and the padding comes for free. A lane's words are walked in group order; s_gS / s_gU give the slot
   // base and the union mask of a group.
-  const int maxn = (int)wave_max_u((unsigned)n);
-  int kmax = (maxn + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD;
-  if(kmax > maxneighs) kmax = maxneighs;
+  // (CORE: n = core entries, n2 = the rest; otherwise n = the row)
+  const int maxn = (int)wave_max_u((unsigned)(n + n2));
+  const int kc = min(((int)wave_max_u((unsigned)n) + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD, maxneighs);
+  const int kr = CORE ? min(((int)wave_max_u((unsigned)n2) + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD, maxneighs - kc) : 0;
+  const int kneed = ((int)wave_max_u((unsigned)n) + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD +
+                    (CORE ? ((int)wave_max_u((unsigned)n2) + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD : 0);     // rows the tile wants (may exceed maxneighs)
+  const int kmax = kc + kr;
   const unsigned short dummy = (unsigned short)(S * NB_SLOT_BYTES);
-  __syncthreads();
-  {
+  bool maxcnt_over = false;
+  // one part of the rows: entries of the lanes' list (src_w/src_g, mycnt of them) go to rows [kfirst, kfirst + krows)
+  auto expand = [&](const unsigned* __restrict__ src_w, const unsigned char* __restrict__ src_g, int mycnt, int kfirst, int krows) {
+    __syncthreads();
     // the lanes' lists come back from the scratch into LDS (the candidate buffer is free now), a few loads in flight at a time:
     // inside the loop a global load would put a full memory round trip into every round (s_waitcnt vmcnt(0) also waits for the
     // row stores), LDS reads do not
     unsigned* s_ew = (unsigned*)s_buf;
-    const int maxcnt = min((int)wave_max_u((unsigned)cnt), NB2_NE);
+    const int wmax = (int)wave_max_u((unsigned)mycnt);
+    maxcnt_over = maxcnt_over || wmax > NB2_NE;               // (a lane with more non-empty words than the LDS list holds)
+    const int maxcnt = min(wmax, NB2_NE);
     for(int e0 = 0; e0 < maxcnt; e0 += 4) {
       unsigned tw[4], tg[4];
 #pragma unroll
-      for(int u = 0; u < 4; u++) { tw[u] = 0; tg[u] = 0; if(e0 + u < cnt) { tw[u] = ent_w[(unsigned)(e0 + u) * 64u]; tg[u] = ent_g[(unsigned)(e0 + u) * 64u]; } }
+      for(int u = 0; u < 4; u++) { tw[u] = 0; tg[u] = 0; if(e0 + u < mycnt) { tw[u] = src_w[(unsigned)(e0 + u) * 64u]; tg[u] = src_g[(unsigned)(e0 + u) * 64u]; } }
 #pragma unroll
       for(int u = 0; u < 4; u++) if(e0 + u < NB2_NE) { s_ew[(e0 + u) * 64 + lane] = tw[u]; s_eg[(e0 + u) * 64 + lane] = (unsigned char)tg[u]; }
     }
     __syncthreads();
-    const int cn = min(cnt, NB2_NE);
+    const int cn = min(mycnt, NB2_NE);
     unsigned w0 = 0, b0 = 0, u0 = 0;
     int e = 0;                                   // list entry of w0
     if(cn > 0) { w0 = s_ew[lane]; const uint2 su = s_gSU[s_eg[lane]]; b0 = su.x; u0 = su.y; }
-    for(int k = 0; k < kmax && !(ablate & 1); k++) {
+    for(int k = 0; k < krows && !(ablate & 1); k++) {
       if(w0 == 0u && e + 1 < cn) {               // (entries are non-empty: one hop always lands on a set bit)
         e++;
         w0 = s_ew[e * 64 + lane];
@@ -1000,15 +1025,20 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       const int bq = __builtin_ctz(w0 | 0x80000000u);
       w0 &= w0 - 1;
       const unsigned slot = b0 + (unsigned)__popc(u0 >> 1 >> bq);
-      rowp[(unsigned)k * 64u] = v ? (unsigned short)(slot * NB_SLOT_BYTES) : dummy;
+      rowp[(unsigned)(kfirst + k) * 64u] = v ? (unsigned short)(slot * NB_SLOT_BYTES) : dummy;
     }
-  }
+  };
+  expand(ent_w, ent_g, cnt, 0, kc);
+  if(CORE) expand(ent2_w, ent2_g, cnt2, kc, kr);
+  n += n2;
+  if(CORE && owned) xbuild[ii] = pme;
   if(owned) numneigh[ii] = n;
   if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = owned ? s_self[lane] : (unsigned short)0xffff;
   const int tsum = wave_sum(n);
-  const bool maxcnt_over = (int)wave_max_u((unsigned)cnt) > NB2_NE;      // (a lane with more non-empty words than the LDS list holds)
   if(lane == 0) {
     tile_max[tile] = kmax;
+    if(CORE) tile_kcore[tile] = kc;
+    if(kneed > maxneighs) atomicMax(&flags[7], kneed);       // (rare) the two padded parts do not fit the row capacity: the host grows it
     tile_ncand[tile] = S;
     tile_cand[cbase + min(S, cstride - 1)] = nall;          // the dummy atom closes the list
     tile_ghost[tile] = any_ghost ? 1 : 0;
@@ -1046,7 +1076,8 @@ __global__ __launch_bounds__(1024) void k_tile_reduce(const int* __restrict__ ti
 __global__ __launch_bounds__(64) void k_tiles_to_rows(int nlocal, int maxneighs, int cstride, const int* __restrict__ binned,
                                                       const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
                                                       const int* __restrict__ tile_cand, const unsigned short* __restrict__ nl16,
-                                                      const int* __restrict__ numneigh, int* __restrict__ neigh)
+                                                      const int* __restrict__ numneigh, int* __restrict__ neigh,
+                                                      const int* __restrict__ tile_max, const int* __restrict__ tile_ncand)
 {
   const int tile = blockIdx.x, lane = threadIdx.x;
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
@@ -1055,7 +1086,13 @@ __global__ __launch_bounds__(64) void k_tiles_to_rows(int nlocal, int maxneighs,
   const unsigned short* in = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
   const int* cl = tile_cand + (size_t)tile * cstride;
   const size_t rowbase = i >= 0 ? ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63) : 0;
-  for(int k = 0; k < n; k++) neigh[rowbase + (size_t)k * 64] = cl[in[(size_t)k * 64] / NB_SLOT_BYTES];
+  // (rows written in two padded parts hold dummy entries between them: skipped)
+  const int kmax = tile_max[tile], dummy = tile_ncand[tile];
+  int m = 0;
+  for(int k = 0; k < kmax && m < n; k++) {
+    const int slot = in[(size_t)k * 64] / NB_SLOT_BYTES;
+    if(slot != dummy) { neigh[rowbase + (size_t)m * 64] = cl[slot]; m++; }
+  }
 }
 
 // pad every row with the dummy atom up to its wavefront's longest row (rounded up to the unroll factor)
@@ -1107,7 +1144,7 @@ int mmd_ensure_rows(mmd_handle* h)
   MMD_TRY(h->wave_max.ensure((size_t)nwaves + 1, false, h->stream));
   if(h->ntiles)
     hipLaunchKernelGGL(k_tiles_to_rows, dim3(h->ntiles), dim3(64), 0, h->stream, h->nlocal, h->maxneighs, h->tile_cstride, h->binned.p,
-                       h->tile_first.p, h->tile_cnt.p, h->tile_cand.p, h->nl16.p, h->numneigh.p, h->neigh.p);
+                       h->tile_first.p, h->tile_cnt.p, h->tile_cand.p, h->nl16.p, h->numneigh.p, h->neigh.p, h->tile_max.p, h->tile_ncand.p);
   HIP_TRY(hipGetLastError());
   return finish_rows(h, false);
 }
@@ -1150,7 +1187,30 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     MMD_TRY(h->tile_ghost.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_rowmax.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_rowsum.ensure((size_t)nt + 2, false, h->stream));
-    if(h->opt_build == 1) MMD_TRY(h->tile_words.ensure((size_t)nt * NB2_NG * 80 + 64, false, h->stream));
+    // rows in two parts (core first, rest of the skin behind): full lists of a force style that asked for it (CoreRows, mmd_internal.hpp)
+    h->core.radius = 0; h->core.margin = 0;
+    if(h->opt_core_pct > 0 && h->style == 1 && h->eam_uniform && h->nprocs == 1 && !h->opt_force_transport && !h->h_cutforcesq.empty()) {
+      // EAM decks carry a generous skin (1 A for a solid whose atoms move ~0.15 A between re-neighborings): the core part ends
+      // opt_core_pct per cent into it
+      const double cutforce = sqrt((double)h->h_cutforcesq[0]);
+      h->core.margin = (real)((double)h->opt_core_pct * 0.01 * ((double)h->cutneigh - cutforce));
+      if(h->core.margin > 0) h->core.radius = (real)(cutforce + (double)h->core.margin);
+    }
+    const bool core_rows = h->opt_build == 1 && !h->halfneigh && h->core.radius > 0;
+    float core_thr = 0;
+    if(core_rows) {
+      // classification threshold in the frame of the build's float pre-test (positions relative to the tile corner): 2^-19 of
+      // relative margin covers its rounding, so every pair closer than the core radius is classified core
+      core_thr = (float)((double)h->core.radius * h->core.radius) * (1.0f + 1.9e-6f) + 1.0e-6f;
+      MMD_TRY(h->tile_kcore.ensure((size_t)nt + 2, false, h->stream));
+      MMD_TRY(h->xbuild.ensure((size_t)h->nmax + 2, false, h->stream));
+      if(!h->core_words.p) {
+        MMD_TRY(h->core_words.ensure(192, false, h->stream));
+        HIP_TRY(hipMemsetAsync(h->core_words.p, 0, 192 * sizeof(unsigned), h->stream));
+      }
+    }
+    h->core.rows_built = false;
+    if(h->opt_build == 1) MMD_TRY(h->tile_words.ensure((size_t)nt * NB2_NG * 80 * (core_rows ? 2 : 1) + 64, false, h->stream));
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
@@ -1171,13 +1231,15 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
                      h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p, h->tile_max.p, h->tile_ghost.p,      \
                      h->tile_self.p,                                                                                                     \
                      h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate)
-#define LAUNCH_ROWS(M)                                                                                                                  \
-  hipLaunchKernelGGL(k_build_rows<M>, dim3(xcd_grid(h->ntiles)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,           \
+#define LAUNCH_ROWS(M) LAUNCH_ROWS2(M, 0)
+#define LAUNCH_ROWS2(M, CR)                                                                                                             \
+  hipLaunchKernelGGL((k_build_rows<M, CR>), dim3(xcd_grid(h->ntiles)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,     \
                      h->ghost_image.p, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
                      h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
-                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate, nt_dev, h->nghost_dev)
+                     h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate, nt_dev, h->nghost_dev, \
+                     core_thr, h->xbuild.p, h->tile_kcore.p)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
-        if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
+        if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         hipLaunchKernelGGL(k_tile_reduce, dim3(1), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
                            h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr);
       } else if(lds > 64 * 1024) {        // the candidate-per-lane form keeps maxneighs x 64 raw slots in LDS
@@ -1187,6 +1249,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
         if(tmode == 0) LAUNCH_TILES(0); else if(tmode == 1) LAUNCH_TILES(1); else LAUNCH_TILES(2);
       }
 #undef LAUNCH_ROWS
+#undef LAUNCH_ROWS2
 #undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
       // [0..3] results, [4..5] total, [6] tile count, [12] long-bin flag, [16..55] bst of a deferred one-rank borders
@@ -1211,11 +1274,13 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       if(h->h_flags[3]) { want_tiles = false; break; }           // a block has too many candidates: global-row build below
       const int maxn = h->h_flags[0];
       h->max_row = maxn;
-      if(maxn >= h->maxneighs) {                                   // ref/neighbor.cpp:186-208
-        int m = (int)(maxn * 1.2);
+      const int need = core_rows ? std::max(maxn, h->h_flags[7]) : maxn;      // (two padded parts per row need a little more room)
+      if(maxn >= h->maxneighs || need > h->maxneighs) {            // ref/neighbor.cpp:186-208
+        int m = (int)(std::max(maxn, need) * 1.2);
         h->maxneighs = (m + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
         continue;
       }
+      h->core.rows_built = core_rows;
       unsigned long long tot;
       memcpy(&tot, h->h_result, sizeof(tot));
       h->total_neigh = (long long)tot;

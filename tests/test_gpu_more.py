@@ -456,6 +456,31 @@ def test_reneighboring_with_counts_left_on_the_device(half):
             np.testing.assert_array_equal(out[mode][5], out["sync"][5])
 
 
+def test_eam_rows_in_two_parts_give_the_same_run():
+    """EAM full lists on one rank: rows are written core-first (pairs closer than cutforce + 30 % of the skin at the build), the
+    force kernels stop after the core part for as long as the tracked displacement since the build stays below half that margin.
+    A pair of the rest cannot be inside the force cutoff then, so the run is the same run: thermo rows, positions and velocities
+    after 100 steps (5 re-neighborings, a thermo step) against whole rows (core_pct 0) and against a margin so small (2 %) that the
+    kernels must fall back to whole rows after a few steps of every window."""
+    m = mm()
+    out = {}
+    for pct in (0, 30, 2):
+        s = m.Sim(["-i", "in.eam.miniMD", "-s", 10, "-n", 100, "--half_neigh", 0])
+        s.handle.set_option("core_pct", pct)
+        s.initial(); s.run()
+        d = s.handle.download()
+        nl = s.handle.counts()[0]
+        out[pct] = (s.rows(), d["x"][:nl].copy(), d["v"][:nl].copy(), s.handle.neighbor_info()["total"], d["tag"].copy())
+        s.close()
+    for pct in (30, 2):
+        rows_close(out[pct][0], out[0][0], 1e-11)
+        assert out[pct][3] == out[0][3]
+        np.testing.assert_array_equal(out[pct][4], out[0][4])
+        # (the two parts change the order of the sums, nothing else: 1e-10 A after 100 steps)
+        assert np.abs(out[pct][1] - out[0][1]).max() <= 1e-10
+        assert np.abs(out[pct][2] - out[0][2]).max() <= 1e-9
+
+
 # ---- BASELINE.json sizes: golden rows + size-independent properties -----------------------------------------
 def test_baseline_s80_full_and_half():
     ent = REFRUNS["lj_s80_full_n100"]
@@ -779,11 +804,14 @@ def test_check_exchange_flag_is_silent_on_a_healthy_run_and_changes_nothing():
 def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
     """fuse=2 (default: finalIntegrate(n)+initialIntegrate(n+1) at the end of the LJ / EAM tile force kernel, positions double
     buffered) against fuse=1 (separate k_final_initial_integrate) and fuse=0 (reference call order): same bits after
-    130 steps with 6 re-neighborings, thermo rows included"""
+    130 steps with 6 re-neighborings, thermo rows included. (EAM: whole rows in all three — only the fused kernel tracks the
+    displacement that lets it stop after the core part of the rows, which changes the order of the sums: core_pct 0 here,
+    test_eam_rows_in_two_parts_give_the_same_run covers that feature.)"""
     res = []
     for fuse in (2, 1, 0):
         s = mm().Sim(["-i", deck, "-s", "8", "-n", "130", "--half_neigh", "0"], precision=prec)
         s.handle.set_option("fuse", fuse)
+        s.handle.set_option("core_pct", 0)
         s.initial(); s.run()
         d = s.handle.download()
         res.append((s.rows(), d["x"][:d["nlocal"]].copy(), d["v"].copy(), d["f"].copy(), d["tag"].copy()))

@@ -22,6 +22,9 @@ for name, args, prec in CONFIGS:
         continue
     t0 = time.time()
     s = minimd_amd.Sim(args, precision=prec)
+    for kv in filter(None, os.environ.get("MMD_SIM_OPTIONS", "").split(",")):      # A/B knobs, e.g. MMD_SIM_OPTIONS=core_pct=30
+        k, v = kv.split("=")
+        s.handle.set_option(k, int(v))
     s.initial()
     s.run_steps(20)
     sec = s.run_steps(100)
