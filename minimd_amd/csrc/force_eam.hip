@@ -633,8 +633,10 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
   const real4 xi = x[i >= 0 ? i : 0];
   const real fpi = fp[i >= 0 ? i : 0];
   const int kmax = (C.ablate & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
-  const int per = ((kmax / EAM_TU + EAM_FW - 1) / EAM_FW) * EAM_TU;
-  const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
+  // the rows (a multiple of 4) are dealt to the wavefronts two at a time: 52 rows = 14,14,12,12 instead of 16,16,16,4 — the slowest
+  // wavefront is the tile's critical path
+  const int hq = kmax >> 1, hbase = hq / EAM_FW, hrem = hq - hbase * EAM_FW;
+  const int k0 = 2 * (wv * hbase + min(wv, hrem)), k1 = k0 + 2 * (hbase + (wv < hrem ? 1 : 0));
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
   int sl[EAM_FU];
 #pragma unroll
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
   {
     int k = k0;
     for(; k + EAM_FU <= k1; k += EAM_FU) trip(std::integral_constant<int, EAM_FU>{}, k);
-    if(EAM_FU > EAM_TU && k < k1) trip(std::integral_constant<int, EAM_TU>{}, k);
+    if(k < k1) trip(std::integral_constant<int, 2>{}, k);            // (slices are even)
   }
   if(wv > 0) { real* d = s_f + 3 * 64 * (wv - 1); d[lane] = fx; d[64 + lane] = fy; d[128 + lane] = fz; }
   __syncthreads();
