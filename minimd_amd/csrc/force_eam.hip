@@ -1012,7 +1012,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     core.ablate = h->opt_ablate;
     if(h->core.rows_built && h->core_words.p) {
       core.tile_kcore = h->tile_kcore.p;
-      core.mode = h->core.mode_now;
+      core.mode = (h->opt_ablate & 4) ? 1 : h->core.mode_now;          // (ablate 4, profiling: the core part whatever the displacement)
       core.words_read = h->core_words.p + 64 * ((h->core.step + 2) % 3);       // written by the previous tracked launch
       core.thr_d2 = (float)(0.25 * (double)h->core.margin * (double)h->core.margin * (1.0 - 1.0e-6));
       core.xbuild = h->xbuild.p;
