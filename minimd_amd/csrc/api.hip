@@ -359,7 +359,10 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       initial_done = true;
       fused_force = false;
     } else if(h->opt_fuse && !evflag && n + 1 < ntimes) {
-      MMD_TRY(mmd_integrate_final_initial(h));
+      h->zero_f_in_integrate = folded;           // (the next step's half-list force call starts from zeros: no separate fill)
+      const int rci = mmd_integrate_final_initial(h);
+      h->zero_f_in_integrate = false;
+      MMD_TRY(rci);
       initial_done = true;
     } else MMD_TRY(mmd_integrate_final(h));
     if(collect_pending) { MMD_TRY(ev_collect(h, false)); collect_pending = false; }      // host work under the force kernel

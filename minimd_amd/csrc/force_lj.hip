@@ -697,7 +697,14 @@ int mmd_lj_compute_tiles_split(mmd_handle* h, int evflag, int part)
 
 // ForceLJ::compute dispatch (ref/force_lj.cpp:72-113); eng_vdwl/virial (reference conventions) land in
 // h->d_result[0..1] when evflag
+static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir);
 int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
+{
+  const int rc = lj_compute(h, evflag, eng, vir);
+  h->f_zeroed_n = 0;                    // (whatever was known about f is consumed)
+  return rc;
+}
+static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 {
   if(h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_force_compute: neighbor list is stale (build or upload one first)"); return -1; }
   const int nlocal = h->nlocal;
@@ -720,7 +727,9 @@ int mmd_lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #undef F
   } else if(mmd_lj_half_tiles_available(h)) {
     // half lists in tile form: on-chip scatter (k_lj_half_tile)
-    MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));     // ref/force_lj.cpp:286-291
+    // ref/force_lj.cpp:286-291 clears f first; inside Integrate::run on one rank the integrator has done that behind itself, and no
+    // ghost receives a force (their shares go to the owners in the flush)
+    if(!(h->fold_reverse_now && h->f_zeroed_n == nlocal)) MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));
     const size_t pos_bytes = lj_tile_pos_bytes(h);

@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void k_final_integrate(real* __restrict__ v, c
 
 // finalIntegrate of step n fused with initialIntegrate of step n+1 (same f, same operation order:
 // v += dtf*f ; v += dtf*f ; x += dt*v) — 136 instead of 208 bytes per atom; used when step n is not a thermo step
-__global__ __launch_bounds__(256) void k_final_initial_integrate(real4* __restrict__ x, real* __restrict__ v, const real* __restrict__ f,
-                                                                 int n, real dt, real dtforce)
+// zero_f: the forces are cleared on the way out (half lists accumulate into f: the next Force::compute then needs no separate fill pass)
+__global__ __launch_bounds__(256) void k_final_initial_integrate(real4* __restrict__ x, real* __restrict__ v, real* __restrict__ f,
+                                                                 int n, real dt, real dtforce, int zero_f)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n) return;
@@ -41,13 +42,16 @@ __global__ __launch_bounds__(256) void k_final_initial_integrate(real4* __restri
   p.x += dt * vx; p.y += dt * vy; p.z += dt * vz;
   v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
   x[i] = p;
+  if(zero_f) { f[3 * (size_t)i + 0] = 0; f[3 * (size_t)i + 1] = 0; f[3 * (size_t)i + 2] = 0; }
 }
 
 int mmd_integrate_final_initial(mmd_handle* h)
 {
+  const int zero_f = h->zero_f_in_integrate ? 1 : 0;
   if(h->nlocal)
-    hipLaunchKernelGGL(k_final_initial_integrate, dim3(div_up(h->nlocal, 256)), dim3(256), 0, h->stream, h->x.p, h->v.p, h->f.p, h->nlocal, h->dt, h->dtforce);
+    hipLaunchKernelGGL(k_final_initial_integrate, dim3(div_up(h->nlocal, 256)), dim3(256), 0, h->stream, h->x.p, h->v.p, h->f.p, h->nlocal, h->dt, h->dtforce, zero_f);
   HIP_TRY(hipGetLastError());
+  h->f_zeroed_n = zero_f ? h->nlocal : 0;
   return 0;
 }
 
