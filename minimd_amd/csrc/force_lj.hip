@@ -512,7 +512,8 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
             atomicAdd((unsigned long long*)a + 0, (unsigned long long)__double_as_longlong((double)px)); atomicAdd((unsigned long long*)a + 1, (unsigned long long)__double_as_longlong((double)py));
             atomicAdd((unsigned long long*)a + 2, (unsigned long long)__double_as_longlong((double)pz));
           } else if(ablate & 8) {
-            atomicAdd((unsigned*)a + 0, (unsigned)__float_as_int((float)px)); atomicAdd((unsigned*)a + 2, (unsigned)__float_as_int((float)py)); atomicAdd((unsigned*)a + 4, (unsigned)__float_as_int((float)pz));
+            if(ablate & 16) { unsafeAtomicAdd((float*)a + 0, (float)px); unsafeAtomicAdd((float*)a + 2, (float)py); unsafeAtomicAdd((float*)a + 4, (float)pz); }
+            else { atomicAdd((unsigned*)a + 0, (unsigned)__float_as_int((float)px)); atomicAdd((unsigned*)a + 2, (unsigned)__float_as_int((float)py)); atomicAdd((unsigned*)a + 4, (unsigned)__float_as_int((float)pz)); }
           } else
           if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, (double)px); unsafeAtomicAdd(a + 1, (double)py); unsafeAtomicAdd(a + 2, (double)pz); }   // (ablate: profiling only)
           if(EV) {

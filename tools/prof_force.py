@@ -75,7 +75,7 @@ if os.environ.get("SHAPES"):
     h.set_option("tile_waves", 2); h.set_option("tile_unroll", 8)
 if os.environ.get("ABLATE"):
     h.set_option("tiles", 1)
-    for ab in (0, 1, 2, 3, 4, 8, 0):
+    for ab in (0, 1, 2, 3, 4, 8, 24, 0):
         h.set_option("ablate", ab)
         print("ablate=%d  tile force %.4f ms" % (ab, h.profile_kernel(0, a.reps)))
     h.set_option("tiles", 0)
