@@ -428,6 +428,10 @@ extern "C" int mmd_profile_kernel(mmd_handle* h, int which, int nrep, double* av
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, a, b));
   *avg_ms = ms / nrep;
+  // half lists with ghost newton: Force::compute alone leaves the ghosts' shares on the ghosts; the step loop expects f AFTER
+  // Comm::reverse_communicate (it continues with initialIntegrate). One rank: complete it here, so that profiling between two slices
+  // of a run leaves the run untouched (up to the order of the sums). Several ranks: the caller has to (it is a collective).
+  if(which == 0 && h->halfneigh && h->ghost_newton && h->nprocs == 1 && !h->opt_force_transport) MMD_TRY(mmd_comm_reverse_communicate(h));
   if(which == 2 || which == 3) {
     HIP_TRY(hipMemcpyAsync(h->v.p, vsave.p, (size_t)3 * h->nlocal * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->x.p, xsave.p, (size_t)h->nlocal * sizeof(real4), hipMemcpyDeviceToDevice, h->stream));

@@ -481,6 +481,25 @@ def test_eam_rows_in_two_parts_give_the_same_run():
         assert np.abs(out[pct][2] - out[0][2]).max() <= 1e-9
 
 
+@pytest.mark.parametrize("half", [0, 1])
+def test_profiling_the_force_kernel_between_two_slices_leaves_the_run_untouched(half):
+    """mmd_profile_kernel(0) = Force::compute launches on the current state (bench.py and tools/run_configs.py warm the clocks with
+    it): the run continues as if nothing had happened — with half lists and ghost newton that needs the ghosts' shares sent home
+    before the next initialIntegrate"""
+    m = mm()
+    rows = {}
+    for probe in (0, 1):
+        s = m.Sim(["-s", 10, "-n", 100, "--half_neigh", half])
+        s.initial()
+        s.run_steps(37)
+        if probe:
+            s.handle.profile_kernel(0, 3)
+        s.run_steps(63)
+        rows[probe] = s.rows()
+        s.close()
+    rows_close(rows[1], rows[0], 1e-11 if half else 0.0)
+
+
 # ---- BASELINE.json sizes: golden rows + size-independent properties -----------------------------------------
 def test_baseline_s80_full_and_half():
     ent = REFRUNS["lj_s80_full_n100"]
