@@ -635,7 +635,7 @@ int mmd_lj_tiles_available(mmd_handle* h)
 // half lists in tile form (k_lj_half_tile): uniform type tables, device-built list, positions + accumulators fit 64 KB of LDS
 int mmd_lj_half_tiles_available(mmd_handle* h)
 {
-  return h->style == 0 && h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && !h->opt_exact_div &&
+  return h->style == 0 && h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && !h->opt_exact_div && !h->opt_lj_original &&
          lj_half_tile_lds(h) <= 64 * 1024 && h->neigh_nlocal == h->nlocal;
 }
 

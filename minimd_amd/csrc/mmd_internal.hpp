@@ -222,6 +222,7 @@ struct mmd_handle {
   int opt_core_pct = 30;               // EAM full lists on one rank: rows in two parts, the core part ends this many per cent into the skin (0: off)
   bool zero_f_in_integrate = false;    // Integrate::run, one-rank half lists: k_final_initial_integrate clears f behind itself
   int f_zeroed_n = 0;                  // f[0 .. 3*f_zeroed_n) is known to be zero (consumed by the next half-list Force::compute)
+  int opt_lj_original = 0;             // --half_neigh -1: ForceLJ::compute_original (ref/force_lj.cpp:118-176) = the row kernel k_lj_half, not the tile kernel
   int opt_async_counts = 1;            // re-neighboring: list sizes from the previous build, the counts return with the build's flags
   int ntiles_hint = 0;
   int opt_time_sample = 3;             // force-kernel clock on every n-th Force::compute of a run

@@ -207,8 +207,9 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     else if(is_flag(a, "-h", "--help")) { if(s->me == 0) print_help(); delete s; return 1; }
     // unknown flags are ignored, like the reference (run_one_test passes -dm)
   }
-  // --half_neigh -1 ("original miniMD force", ref/force_lj.cpp:118-176) computes the same half-list physics with
-  // force on both partners and a reverse halo; on the device it is the half-list + ghost-newton path
+  // --half_neigh -1 ("original miniMD force", ref/force_lj.cpp:118-176: half list, force on both partners, reverse halo): the
+  // half-list + ghost-newton lists with the un-tiled force kernel (k_lj_half: one atom per lane walks its row, the partner is
+  // updated with one atomic per pair and component) — the direct rendering of that loop, kept as a path of its own
   if(s->halfneigh < 0) s->ghost_newton = s->in.forcetype == 1 ? 0 : 1;
   if(s->in.forcetype == 1 && s->ghost_newton == 1) {
     if(s->me == 0 && !quiet) printf("# EAM currently requires '--ghost_newton 0'; Changing setting now.\n");
@@ -272,6 +273,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
   s->dev_half = s->halfneigh != 0 ? 1 : 0;
   if(s->in.forcetype == 1 && s->eam_half_full) s->dev_half = 0;
   SIM_TRY(mmd_neighbor_setup(h, s->nbin, s->in.neigh_cut, s->dev_half, s->ghost_newton, s->ntypes));
+  if(s->halfneigh < 0 && s->in.forcetype == 0) SIM_TRY(mmd_set_option(h, "lj_original", 1));      // ForceLJ::compute_original
   s->dtforce = 0.5 * s->dt;                        // Integrate::setup (ref/integrate.cpp:41-44)
   const int nt2 = s->ntypes * s->ntypes;
   if(s->in.forcetype == 0) {

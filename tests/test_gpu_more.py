@@ -738,7 +738,9 @@ def test_stale_list_and_bad_arguments_are_errors():
 def test_eam_half_request_and_original_force_alias():
     """EAM with the reference's default --half_neigh 1 (serial-only path there) runs the device half-list kernels; with
     --eam_half_full the full-list kernels stand in (energy converted to the half-list convention): both reproduce the rows
-    of the reference's half-list run; --half_neigh -1 (original miniMD force) is the half + ghost-newton path"""
+    of the reference's half-list run; --half_neigh -1 (ForceLJ::compute_original, ref/force_lj.cpp:118-176) runs the half +
+    ghost-newton lists through the un-tiled row kernel k_lj_half (a path of its own: its timers show no tile kernel), rows as
+    the reference's half-list run"""
     ent = REFRUNS["eam_s10_half_n300"]
     for extra in ([], ["--eam_half_full"]):
         s = mm().Sim([a for a in ent["args"]] + extra)
@@ -753,6 +755,15 @@ def test_eam_half_request_and_original_force_alias():
     ref = REFRUNS["lj_s10_half_gn1_n1000"]
     rows = sim_rows(["-s", 10, "-n", 300, "--half_neigh", -1])
     rows_close(rows, [r_ for r_ in ref["rows"] if r_[0] <= 300], 2e-6)
+    # the same request through the tile kernel (option lj_original 0) and through the row kernel: same physics
+    out = {}
+    for orig in (1, 0):
+        s = mm().Sim(["-s", 10, "-n", 100, "--half_neigh", -1])
+        s.handle.set_option("lj_original", orig)
+        s.initial(); s.run()
+        out[orig] = s.rows()
+        s.close()
+    rows_close(out[1], out[0], 1e-9)
 
 
 def test_yaml_report_matches_reference_counts(tmp_path):
