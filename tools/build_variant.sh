@@ -1,18 +1,19 @@
 #!/bin/bash
 # tools/build_variant.sh <name> <unit> <extra hipcc flags...>: a tuning build of the DP library with ONE unit (force_lj, force_eam,
 # neighbor ...) recompiled with extra -D flags, into variants/<name>/libmmd_hip_dp.so (travels with gpurun; git-ignored).
-# Run with MMD_LIB_DIR=variants/<name>.
+# Run with MMD_LIB_DIR=variants/<name>. PREC=sp builds the single-precision library instead (libmmd_hip_sp.so).
 set -e
 cd "$(dirname "$0")/../minimd_amd/csrc"
 name=$1; unit=$2; shift 2
 out=../../variants/$name
 mkdir -p $out
-make -j8 dp > /dev/null
+P=${PREC:-dp}; PN=2; [ $P = sp ] && PN=1
+make -j8 $P > /dev/null
 fl="-ffp-contract=off"; case $unit in force_lj|force_eam) fl="-ffp-contract=fast";; esac
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-result -I/opt/rocm/include $fl -DMMD_PRECISION=2 "$@" -c $unit.hip -o $out/$unit.o
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-result -I/opt/rocm/include $fl -DMMD_PRECISION=$PN "$@" -c $unit.hip -o $out/$unit.o
 objs=""
 for u in util atom neighbor integrate comm api force_lj force_eam host sim; do
-  if [ $u = $unit ]; then objs="$objs $out/$unit.o"; else objs="$objs ../build/dp/$u.o"; fi
+  if [ $u = $unit ]; then objs="$objs $out/$unit.o"; else objs="$objs ../build/$P/$u.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $out/libmmd_hip_dp.so -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
-echo "built $out/libmmd_hip_dp.so ($*)"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $out/libmmd_hip_$P.so -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+echo "built $out/libmmd_hip_$P.so ($*)"
