@@ -64,6 +64,23 @@ def cpu_baseline(size, nsteps):
         return {"value": None, "unit": "Matom-steps/s", "cores": cores, "kind": kind, "sample": "failed: %r" % (e,)}
 
 
+def perf_summary_cold(size):
+    """what a user of the drop-in executable sees: `miniMD_dp -i in.lj.miniMD -s <size> --half_neigh 0` as a fresh process (cold GPU clocks,
+    no equilibration, no warm-up, the deck's 100 steps) and the value of its own PERF_SUMMARY line = natoms*ntimes/t_total of
+    Integrate::run (ref/ljs.cpp:470-495). Reported beside the steady-state `value`, never instead of it."""
+    exe = os.path.join(REPO, "minimd_amd", "bin", "miniMD_dp")
+    cmd = [exe, "-i", "in.lj.miniMD", "-s", str(size), "--half_neigh", "0"]
+    try:
+        r = subprocess.run(cmd, cwd=os.path.join(REPO, "data"), capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if "PERF_SUMMARY" in l and not l.startswith("#")][0].split()
+        rows = [l.split() for l in r.stdout.splitlines() if l[:1].isdigit() and len(l.split()) == 5]
+        return {"value": float(line[9]) / 1e6, "unit": "Matom-steps/s", "steps": int(line[2]), "natoms": int(line[3]), "t_total_s": float(line[4]),
+                "t_force_s": float(line[5]), "t_neigh_s": float(line[6]), "t_comm_s": float(line[7]),
+                "last_row": " ".join(rows[-1][:4]) if rows else None, "cmd": "minimd_amd/bin/miniMD_dp " + " ".join(cmd[1:])}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "unit": "Matom-steps/s", "cmd": " ".join(cmd), "error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +89,7 @@ def main():
     ap.add_argument("--size", type=int, default=80, help="unit cells per GPU edge (BASELINE configs[1]: 80)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold run of the drop-in executable (perf_summary_cold)")
     ap.add_argument("--equil", type=int, default=100, help="untimed equilibration steps before the warm-up (set-up, see the module docstring)")
     ap.add_argument("--clock-warm-ms", type=float, default=400.0,
                     help="set-up: keep the GPU busy this long (force-kernel launches that leave the state untouched) so that the warm-up "
@@ -140,24 +158,36 @@ def main():
         dims = (world, 1, 1)
     nx, ny, nz = (args.size * d for d in dims)
     sim_args = ["-i", "in.lj.miniMD", "-nx", nx, "-ny", ny, "-nz", nz, "--half_neigh", "0", "-n", args.steps]
+    sim, err = None, None
     try:
         sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
     except Exception as e:  # noqa: BLE001
-        # the RCCL communicator could not be built (e.g. several ranks on one device): rather than no number at all, run the
-        # halos over the host-staged transport and say so in the JSON line ("transport": "host")
         if dist is None or os.environ.get("MMD_BENCH_TRANSPORT") == "gloo":
             raise
-        print("bench.py rank %d: RCCL path failed (%s); falling back to host-staged halos" % (rank, e), file=sys.stderr)
-        os.environ["MMD_BENCH_TRANSPORT"] = "gloo"
-        from minimd_amd import api
-        from minimd_amd.transport import GlooTransport
-        _tr = GlooTransport()
-        api.sim_set_host_transport(_tr.sendrecv, _tr.allreduce, "dp")
-        sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
+        err = e
+    if dist is not None and os.environ.get("MMD_BENCH_TRANSPORT") != "gloo":
+        # the RCCL communicator may fail on some ranks only (e.g. several ranks on one device): the ranks agree over the gloo control
+        # plane, and either ALL keep RCCL or ALL switch to the host-staged transport (the JSON line says which: "transport")
+        ok = torch.tensor([0 if sim is None else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if rank == 0 or err is not None:
+                print("bench.py rank %d: RCCL path failed on some rank (%s); every rank falls back to host-staged halos" % (rank, err), file=sys.stderr)
+            if sim is not None:
+                sim.close()
+            os.environ["MMD_BENCH_TRANSPORT"] = "gloo"
+            from minimd_amd import api
+            from minimd_amd.transport import GlooTransport
+            _tr = GlooTransport()
+            api.sim_set_host_transport(_tr.sendrecv, _tr.allreduce, "dp")
+            sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
     natoms = sim.natoms()
     for kv in filter(None, os.environ.get("MMD_BENCH_OPTIONS", "").split(",")):     # A/B knobs, e.g. "build_waves=1,fuse=1"
         k, v = kv.split("=")
         sim.handle.set_option(k, int(v))
+    # the force kernel's clock: every launch of a short timed region (<= 50 steps), every 3rd one of a long run (library default)
+    timed_every = 1 if args.steps <= 50 else 3
+    sim.handle.set_option("time_force_sample", timed_every)
     sim.initial()
     if args.equil > 0:
         sim.run_steps(args.equil)
@@ -184,14 +214,23 @@ def main():
         dt = float(t.item())
 
     tm = sim.handle.timers()
+    rs = sim.handle.run_stats()
     nlocal, nghost, _ = sim.handle.counts()
+    # per-rank view of the timed region (max over ranks of every phase, rank 0's own next to it): with these a SCALE line is
+    # diagnosable from the record alone — where the time went, how often the host stalled the GPU, how many bytes the halos moved
+    mine = {"phases_s": {k: tm[k] for k in ("total", "comm", "force", "neigh", "extra")}, "host_syncs": rs["host_syncs"],
+            "bytes_sent": rs["bytes_sent"], "nlocal": nlocal, "nghost": nghost}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     ninfo = sim.handle.neighbor_info()
     kbar = ninfo["total"] / max(nlocal, 1)
     bpa = algorithmic_bytes_per_atom(kbar, nghost / max(nlocal, 1))
     k_ms = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
     achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
     traffic, traffic_source = None, None
-    for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if world == 1 and args.size == 80 and os.path.exists(tpath):
             # HBM bytes per launch of the same kernel on the same workload from the committed rocprofv3 --pmc passes
@@ -234,9 +273,9 @@ def main():
         # new x: +80 B/atom, and skips the f store: -24 B); `achieved` still counts only SURVEY §8d's force-kernel bytes
         "roofline": {"bound": "hbm", "kernel": "k_lj_full_tile (ForceLJ::compute_fullneigh + fused Integrate)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
-                     # `frac` is the in-run figure (events on the timed region's own launches, every 3rd one; these launches also carry the
+                     # `frac` is the in-run figure (events on the timed region's own launches — every launch when --steps <= 50, else every 3rd; these launches also carry the
                      # integrator); `frac_kernel_only` = SURVEY 8(d)'s force kernel alone on the same thermalised state, 20 launches
-                     "frac_in_run": (achieved / HBM_PEAK_GBS) if achieved else None, "launches_timed_every": 3,
+                     "frac_in_run": (achieved / HBM_PEAK_GBS) if achieved else None, "launches_timed_every": timed_every,
                      "kernel_only_ms": k_only_ms,
                      "frac_kernel_only": (bpa * nlocal / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_only_ms else None,
                      "measured_copy_GBs": copy_gbs,
@@ -246,14 +285,24 @@ def main():
                      "achieved_incl_fused_integrator": ((bpa + 56.0) * nlocal / (k_ms * 1e-3) / 1e9) if k_ms > 0 else None,
                      "kbar": kbar, "ghost_ratio": nghost / max(nlocal, 1)},
         "phases_s": {k: tm[k] for k in ("total", "comm", "force", "neigh", "extra")},
+        # max over the ranks (the slowest rank sets the step time); rebuild steps = steps/20
+        "phases_s_max": {k: max(r["phases_s"][k] for r in per_rank) for k in ("total", "comm", "force", "neigh", "extra")},
+        "host_syncs_per_step": max(r["host_syncs"] for r in per_rank) / max(args.steps, 1),
+        "host_syncs_per_rebuild": max(r["host_syncs"] for r in per_rank) / max(args.steps // 20, 1),
+        "halo_bytes_per_step": {"sum_over_ranks": sum(r["bytes_sent"] for r in per_rank) / max(args.steps, 1),
+                                "max_rank": max(r["bytes_sent"] for r in per_rank) / max(args.steps, 1)},
+        "atoms_per_rank": {"owned_min": min(r["nlocal"] for r in per_rank), "owned_max": max(r["nlocal"] for r in per_rank),
+                           "ghost_max": max(r["nghost"] for r in per_rank)},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_steps)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     sim.close()
+    if rank == 0:
+        out["perf_summary_cold"] = perf_summary_cold(args.size) if (world == 1 and not args.no_cold) else None
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

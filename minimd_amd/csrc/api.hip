@@ -88,7 +88,7 @@ extern "C" int mmd_device_info(mmd_handle* h, char* name, int name_len, int* cu_
 extern "C" int mmd_sync(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return 0;
 }
 
@@ -110,7 +110,13 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "borders_fast")) h->opt_borders_fast = value;
   else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
-  else if(!strcmp(name, "ablate")) h->opt_ablate = value;
+  else if(!strcmp(name, "ablate")) {
+#ifdef MMD_PROFILE
+    h->opt_ablate = value;
+#else
+    if(value) { mmd_set_error("mmd_set_option: 'ablate' needs a library built with -DMMD_PROFILE (tools/build_variant.sh)"); return -1; }
+#endif
+  }
   else if(!strcmp(name, "fuse")) h->opt_fuse = value;
   else if(!strcmp(name, "overlap")) h->opt_overlap = value;
   else if(!strcmp(name, "tile_waves")) h->opt_tile_waves = value;
@@ -162,6 +168,7 @@ static int ev_collect(mmd_handle* h, bool sync = true)
     HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
     switch(h->ev_pool[i].kind) {
       case 0: h->force_ms += ms; h->force_launches++; break;
+      case 4: h->force_ms_all += ms; h->force_launches_all++; break;      // Force::compute calls that are timed EVERY time (overlapped steps)
       case 1: h->comm_ms += ms; break;
       case 2: h->timer[1] += ms * 1e-3; h->timer[4] += ms * 1e-3; break;     // ref/integrate.cpp:155-166
       default: h->timer[3] += ms * 1e-3; break;
@@ -207,8 +214,9 @@ extern "C" int mmd_force_compute(mmd_handle* h, int evflag, double* eng_vdwl, do
   if(!h) { mmd_set_error("null handle"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
   double e = 0, v = 0;
+  if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }
   MMD_TRY(force_compute_async(h, evflag, &e, &v, false));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   if(evflag) { if(eng_vdwl) *eng_vdwl = e; if(virial) *virial = v; }
   return 0;
 }
@@ -222,6 +230,19 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   HIP_TRY(hipSetDevice(h->device));
   for(int i = 0; i < 5; i++) h->timer[i] = 0;
   h->force_ms = 0; h->comm_ms = 0; h->force_launches = 0; h->force_calls = 0; h->ev_used = 0;
+  h->force_ms_all = 0; h->force_launches_all = 0;
+  h->host_syncs = 0; h->halo_bytes = 0;
+  // the step loop steers the kernels through transient flags of the handle; whatever way this function is left (an overflowing
+  // build, a transport error), they are cleared, so a later call on the same handle never waits on a stale event or skips a halo
+  struct TransientGuard {
+    mmd_handle* h;
+    ~TransientGuard() {
+      h->fuse_now = 0; h->resolve_now = false; h->fold_reverse_now = false; h->core.mode_now = 0; h->zero_f_in_integrate = false;
+      h->halo_pending = false; h->in_reneighbor = false; h->pbc_defer = false; h->launch_ev_a = h->launch_ev_b = nullptr;
+    }
+  } transient_guard{h};
+  // (a previous run that failed mid-step may have left the ghosts one step behind their owners)
+  if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double t_start = mmd_wall();
   // host-side phase clocks need the device drained at phase boundaries only when a phase is to be
@@ -271,7 +292,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         MMD_TRY(rc);
         HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
         if(h->style == 0 && !h->halfneigh) {
-          if(h->time_force_events) MMD_TRY(ev_begin(h));
+          if(h->time_force_events) MMD_TRY(ev_begin(h, 4));       // (its two launches are bracketed on every step: not part of the sampled subset)
           fused_force = fuse_force && !ev_now && n + 1 < ntimes && mmd_lj_can_fuse_integrate(h);
           if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
           h->fuse_now = fused_force;
@@ -370,7 +391,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     if(evflag) {
       MMD_TRY(mmd_temperature_async(h, 2));
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(mmd_stream_sync(h));
       double vals[3] = {h->h_result[2], h->h_result[0], h->h_result[1]};     // mv2, eng, virial
       MMD_TRY(mmd_transport_allreduce(h, vals, 3));
       if(cb) cb(ctx, step, vals[0], vals[1], vals[2]);
@@ -380,7 +401,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   MMD_TRY(ev_collect(h));
   h->timer[0] = mmd_wall() - t_start;
   // TIME_FORCE: GPU time between the events around Force::compute (scaled from the sampled calls to all of them)
-  h->timer[2] = h->force_ms * 1e-3 * (h->force_launches > 0 && h->force_calls > h->force_launches ? (double)h->force_calls / h->force_launches : 1.0);
+  // force_calls / force_launches count the SAMPLED path only (force_compute_async); calls that are bracketed every time add their time as it is
+  h->timer[2] = h->force_ms * 1e-3 * (h->force_launches > 0 && h->force_calls > h->force_launches ? (double)h->force_calls / h->force_launches : 1.0) +
+                h->force_ms_all * 1e-3;
   h->timer[1] += h->comm_ms * 1e-3;          // TIME_COMM also counts the per-step halos (GPU time between their events)
   return 0;
 }
@@ -389,8 +412,16 @@ extern "C" int mmd_timers(mmd_handle* h, double out5[5], double* force_kernel_ms
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
   if(out5) for(int i = 0; i < 5; i++) out5[i] = h->timer[i];
-  if(force_kernel_ms) *force_kernel_ms = h->force_ms;
-  if(force_kernel_launches) *force_kernel_launches = h->force_launches;
+  if(force_kernel_ms) *force_kernel_ms = h->force_ms + h->force_ms_all;
+  if(force_kernel_launches) *force_kernel_launches = h->force_launches + h->force_launches_all;
+  return 0;
+}
+
+extern "C" int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* bytes_sent)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  if(host_syncs) *host_syncs = h->host_syncs;
+  if(bytes_sent) *bytes_sent = h->halo_bytes;
   return 0;
 }
 
@@ -421,7 +452,7 @@ extern "C" int mmd_profile_kernel(mmd_handle* h, int which, int nrep, double* av
     }
   };
   MMD_TRY(once());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   HIP_TRY(hipEventRecord(a, h->stream));
   for(int r = 0; r < nrep; r++) MMD_TRY(once());
   HIP_TRY(hipEventRecord(b, h->stream));
@@ -436,7 +467,7 @@ extern "C" int mmd_profile_kernel(mmd_handle* h, int which, int nrep, double* av
   if(which == 2 || which == 3) {
     HIP_TRY(hipMemcpyAsync(h->v.p, vsave.p, (size_t)3 * h->nlocal * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->x.p, xsave.p, (size_t)h->nlocal * sizeof(real4), hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     vsave.release(); xsave.release();
   }
   (void)hipEventDestroy(a);

@@ -66,7 +66,7 @@ extern "C" int mmd_atom_upload(mmd_handle* h, const mmd_float* x, const mmd_floa
   h->nlocal = nlocal;
   h->nghost = nghost;
   MMD_TRY(mmd_set_dummy(h));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   tmp.release();
   h->neigh_nlocal = 0;
   return 0;
@@ -83,7 +83,7 @@ extern "C" int mmd_atom_download(mmd_handle* h, mmd_float* x, mmd_float* v, mmd_
     hipLaunchKernelGGL(k_unpack_x4, dim3(div_up(nall, 256)), dim3(256), 0, h->stream, h->x.p, tmp.p, nall);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(x, tmp.p, (size_t)3 * nall * sizeof(real), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     tmp.release();
   }
   if(v) HIP_TRY(hipMemcpyAsync(v, h->v.p, (size_t)3 * h->nlocal * sizeof(real), hipMemcpyDeviceToHost, h->stream));
@@ -93,7 +93,7 @@ extern "C" int mmd_atom_download(mmd_handle* h, mmd_float* x, mmd_float* v, mmd_
   }
   if(type) HIP_TRY(hipMemcpyAsync(type, h->type.p, (size_t)nall * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if(tag) HIP_TRY(hipMemcpyAsync(tag, h->tag.p, (size_t)h->nlocal * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return 0;
 }
 
@@ -101,7 +101,7 @@ extern "C" int mmd_atom_upload_f(mmd_handle* h, const mmd_float* f, int n)
 {
   if(!h || !f || n > h->nmax) { mmd_set_error("mmd_atom_upload_f: bad arguments"); return -1; }
   HIP_TRY(hipMemcpyAsync(h->f.p, f, (size_t)3 * n * sizeof(real), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return 0;
 }
 
@@ -162,6 +162,14 @@ extern "C" int mmd_atom_sort(mmd_handle* h)
   const int n = h->nlocal;
   if(n == 0) return 0;
   MMD_TRY(mmd_bin_atoms(h, n));               // Neighbor::binatoms(atom, nlocal)
+  // bins longer than the one-thread sort handles are ordered by the grid-wide rank count, which is skipped until such a bin has
+  // been seen. Inside Integrate::run the neighbor build that follows reads the flag with its own results; a bare Atom::sort
+  // (C-ABI users) reads it here, so its permutation never depends on the arrival order of the histogram atomics
+  if(!h->big_bins && !h->in_reneighbor) {
+    HIP_TRY(hipMemcpyAsync(h->h_flags + 12, h->d_flags + 12, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(mmd_stream_sync(h));
+    if(h->h_flags[12]) { h->big_bins = true; MMD_TRY(mmd_bin_atoms(h, n)); }
+  }
   // the copies only need to hold the current atoms (+ dummy slot); sizing them by the live arrays' capacity
   // made the two buffers leap-frog each other and re-allocate on every sort
   const size_t need = (size_t)h->nmax + 1;

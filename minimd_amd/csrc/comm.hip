@@ -130,7 +130,7 @@ extern "C" int mmd_comm_download_lists(mmd_handle* h, int iswap, int* sendlist)
   if(!h || iswap < 0 || iswap >= (int)h->swaps.size() || !sendlist) { mmd_set_error("mmd_comm_download_lists: bad arguments"); return -1; }
   const Swap& s = h->swaps[iswap];
   if(s.sendnum) HIP_TRY(hipMemcpyAsync(sendlist, s.sendlist.p, (size_t)s.sendnum * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return 0;
 }
 
@@ -185,6 +185,7 @@ extern "C" int mmd_comm_set_host_transport(mmd_handle* h, mmd_sendrecv_fn sr, mm
 // device buffers in, device buffers out; byte counts
 int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int dest, void* drecv, size_t nrecv, int src)
 {
+  h->halo_bytes += (long long)nsend;
   if(h->rccl) {
     ncclComm_t c = (ncclComm_t)h->rccl;
     NCCL_TRY(ncclGroupStart());
@@ -197,11 +198,11 @@ int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int d
     if(h->stage_send.size() < nsend + 8) h->stage_send.resize(nsend + 8);
     if(h->stage_recv.size() < nrecv + 8) h->stage_recv.resize(nrecv + 8);
     if(nsend) HIP_TRY(hipMemcpyAsync(h->stage_send.data(), dsend, nsend, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     const long long got = h->host_sr(h->host_ctx, h->stage_send.data(), (long long)nsend, dest, h->stage_recv.data(), (long long)nrecv, src);
     if(got != (long long)nrecv) { mmd_set_error("host transport: expected %zu bytes from rank %d, got %lld", nrecv, src, got); return -1; }
     if(nrecv) HIP_TRY(hipMemcpyAsync(drecv, h->stage_recv.data(), nrecv, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     return 0;
   }
   mmd_set_error("rank %d has a remote partner but no transport is attached (mmd_comm_init_rccl / mmd_comm_set_host_transport)", h->me);
@@ -210,6 +211,7 @@ int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int d
 
 int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv, int src)
 {
+  h->halo_bytes += (long long)sizeof(int);
   if(h->rccl) {
     ncclComm_t c = (ncclComm_t)h->rccl;
     h->h_flags[8] = nsend;
@@ -219,7 +221,7 @@ int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv
     NCCL_TRY(ncclRecv(h->d_flags + 9, 1, ncclInt, src, c, h->stream));
     NCCL_TRY(ncclGroupEnd());
     HIP_TRY(hipMemcpyAsync(h->h_flags + 9, h->d_flags + 9, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     *nrecv = h->h_flags[9];
     return 0;
   }
@@ -240,6 +242,7 @@ int mmd_transport_sendrecv_counts(mmd_handle* h, int nsend, int dest, int* nrecv
 int mmd_transport_sendrecv_counts_pair(mmd_handle* h, const int nsend[2], const int dest[2], int nrecv[2], const int src[2])
 {
   if(h->rccl) {
+    h->halo_bytes += 2 * (long long)sizeof(int);
     ncclComm_t c = (ncclComm_t)h->rccl;
     h->h_flags[8] = nsend[0]; h->h_flags[9] = nsend[1];
     HIP_TRY(hipMemcpyAsync(h->d_flags + 8, h->h_flags + 8, 2 * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -250,7 +253,7 @@ int mmd_transport_sendrecv_counts_pair(mmd_handle* h, const int nsend[2], const 
     }
     NCCL_TRY(ncclGroupEnd());
     HIP_TRY(hipMemcpyAsync(h->h_flags + 10, h->d_flags + 10, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     nrecv[0] = h->h_flags[10]; nrecv[1] = h->h_flags[11];
     return 0;
   }
@@ -261,6 +264,7 @@ int mmd_transport_sendrecv_pair(mmd_handle* h, const void* const dsend[2], const
                                 const size_t nrecv[2], const int src[2])
 {
   if(h->rccl) {
+    h->halo_bytes += (long long)(nsend[0] + nsend[1]);
     ncclComm_t c = (ncclComm_t)h->rccl;
     NCCL_TRY(ncclGroupStart());
     for(int q = 0; q < 2; q++) {
@@ -283,7 +287,7 @@ int mmd_transport_allreduce(mmd_handle* h, double* vals, int n)
     HIP_TRY(hipMemcpyAsync(h->d_result + 8, vals, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     NCCL_TRY(ncclAllReduce(h->d_result + 8, h->d_result + 8, n, ncclDouble, ncclSum, c, h->stream));
     HIP_TRY(hipMemcpyAsync(vals, h->d_result + 8, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     return 0;
   }
   if(h->host_ar) {
@@ -448,6 +452,7 @@ extern "C" int mmd_comm_communicate(mmd_handle* h)
       hipLaunchKernelGGL(k_pack_comm, dim3(div_up((long long)n2, 256)), dim3(256), 0, h->stream, h->x.p, s2->sendlist.p, (int)n2, tx, ty, tz, s2->pbc_any, b2);
     }
     if(pair) {
+      h->halo_bytes += (long long)((n1 + n2) * sizeof(real4));
       ncclComm_t c = (ncclComm_t)h->rccl;
       NCCL_TRY(ncclGroupStart());
       if(n1) NCCL_TRY(ncclSend(b1, n1 * sizeof(real4), ncclChar, s.sendproc, c, h->stream));
@@ -594,7 +599,7 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
       h->nlocal += nkeep;
     }
   }
-  if(h->nprocs > 1) HIP_TRY(hipStreamSynchronize(h->stream));     // (the scratch arrays below are only allocated when a dimension is split)
+  if(h->nprocs > 1) HIP_TRY(mmd_stream_sync(h));     // (the scratch arrays below are only allocated when a dimension is split)
   leavers.release(); fillers.release(); keep.release();
   return 0;
 }
@@ -860,7 +865,7 @@ static int borders_one_rank_fast(mmd_handle* h, bool defer)
     return 2;
   }
   HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));      // nb, ovf, sendnum[6], ghost prefix
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return borders_fast_finish(h);
 }
 
@@ -924,7 +929,7 @@ int mmd_borders_deferred_resolve(mmd_handle* h)
 {
   if(!h->nghost_dev) return 1;
   HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   const int rc = mmd_borders_deferred_finish(h);
   if(rc == 1) MMD_TRY(mmd_set_dummy(h));
   return rc < 0 ? rc : 1;
@@ -936,6 +941,9 @@ static int borders_general(mmd_handle* h)
   MMD_TRY(h->ghost_image.ensure(1024, false, h->stream));
   MMD_TRY(h->ghost_root.ensure(1024, false, h->stream));
   h->ghost_chain_ok = true;                // stays true while every swap is a self swap
+  // the image code of a ghost holds at most +-2 box lengths per dimension (image_add clamps): a box thinner than cutneigh/2
+  // (need > 2, possible with LAMMPS data files) must not rebuild its ghosts from root + image code
+  for(int d = 0; d < 3; d++) if(h->need[d] > 2) h->ghost_chain_ok = false;
   // one pass over the owned atoms keeps only those inside some send slab (~12% at -s 80); the per-swap
   // selections then scan that short list + the ghosts instead of every owned atom six times
   int nb = -1;
@@ -1044,7 +1052,7 @@ int mmd_order_tiles(mmd_handle* h)
   if(n_int) HIP_TRY(hipMemcpyAsync(h->tile_order.p, part.p, (size_t)n_int * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
   MMD_TRY(compact(h, TileFlagPred{h->tile_ghost.p, 1}, 0, nt, part, &n_bnd));
   if(n_bnd) HIP_TRY(hipMemcpyAsync(h->tile_order.p + n_int, part.p, (size_t)n_bnd * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   part.release();
   if(n_int + n_bnd != nt) { mmd_set_error("mmd_order_tiles: lost tiles (%d + %d != %d)", n_int, n_bnd, nt); return -1; }
   h->ntiles_interior = n_int;

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   __syncthreads();                                      // previous tile's readers are done with s_pos / s_part
   const int ncand = tile_ncand[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int t0 = 0; t0 <= ncand && !(C.ablate & 1); t0 += EAM_STAGE * NT) {  // branch-free: cl[ncand] holds the dummy atom's index
+  for(int t0 = 0; t0 <= ncand && !(MMD_ABLATE(C.ablate) & 1); t0 += EAM_STAGE * NT) {  // branch-free: cl[ncand] holds the dummy atom's index
     int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
-  const int kmax = (C.ablate & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
+  const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
   const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
   __syncthreads();
   const int ncand = tile_ncand[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int t0 = 0; t0 <= ncand && !(C.ablate & 1); t0 += EAM_STAGE * NT) {
+  for(int t0 = 0; t0 <= ncand && !(MMD_ABLATE(C.ablate) & 1); t0 += EAM_STAGE * NT) {
     int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   const real fpi = fp[i >= 0 ? i : 0];
-  const int kmax = (C.ablate & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
+  const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
   // the rows (a multiple of 4) are dealt to the wavefronts two at a time: 52 rows = 14,14,12,12 instead of 16,16,16,4 — the slowest
   // wavefront is the tile's critical path
   const int hq = kmax >> 1, hbase = hq / EAM_FW, hrem = hq - hbase * EAM_FW;
@@ -856,7 +856,7 @@ extern "C" int mmd_force_eam_setup(mmd_handle* h, int ntypes, int nr, int nrho, 
   HIP_TRY(hipMemcpyAsync(h->z2r_spline.p, z2r_spline, sizeof(real) * (size_t)nt2 * nr_tot, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->frho_spline.p, frho_spline, sizeof(real) * (size_t)nt2 * nrho_tot, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->lj_tables.p, cutforcesq, sizeof(real) * nt2, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return 0;
 }
 
@@ -942,7 +942,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       HIP_TRY(hipGetLastError());
       if(eng || vir) {
         HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(mmd_stream_sync(h));
         if(eng) *eng = h->h_result[0];
         if(vir) *vir = h->h_result[1];
       }
@@ -983,7 +983,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       HIP_TRY(hipGetLastError());
       if(eng || vir) {
         HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(mmd_stream_sync(h));
         if(eng) *eng = h->h_result[0];
         if(vir) *vir = h->h_result[1];
       }
@@ -1012,7 +1012,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     core.ablate = h->opt_ablate;
     if(h->core.rows_built && h->core_words.p) {
       core.tile_kcore = h->tile_kcore.p;
-      core.mode = (h->opt_ablate & 4) ? 1 : h->core.mode_now;          // (ablate 4, profiling: the core part whatever the displacement)
+      core.mode = (MMD_ABLATE(h->opt_ablate) & 4) ? 1 : h->core.mode_now;          // (ablate 4, profiling: the core part whatever the displacement)
       core.words_read = h->core_words.p + 64 * ((h->core.step + 2) % 3);       // written by the previous tracked launch
       core.thr_d2 = (float)(0.25 * (double)h->core.margin * (double)h->core.margin * (1.0 - 1.0e-6));
       core.xbuild = h->xbuild.p;
@@ -1068,7 +1068,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       HIP_TRY(hipGetLastError());
       if(eng || vir) {
         HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(mmd_stream_sync(h));
         if(eng) *eng = h->h_result[0];
         if(vir) *vir = h->h_result[1];
       }
@@ -1101,7 +1101,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     HIP_TRY(hipGetLastError());
     if(eng || vir) {
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(mmd_stream_sync(h));
       if(eng) *eng = h->h_result[0];
       if(vir) *vir = h->h_result[1];
     }
@@ -1115,6 +1115,6 @@ extern "C" int mmd_force_eam_download_fp(mmd_handle* h, mmd_float* fp)
   const int nall = h->nlocal + h->nghost;
   if(h->fp.cap < (size_t)nall) { mmd_set_error("mmd_force_eam_download_fp: no EAM force has been computed"); return -1; }
   HIP_TRY(hipMemcpyAsync(fp, h->fp.p, (size_t)nall * sizeof(real), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return 0;
 }

@@ -72,8 +72,9 @@ template <int EV, int UNIFORM, bool EXACT>
 __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__ x, const int* __restrict__ neigh,
                                                        const int* __restrict__ wave_max, int nlocal, int maxneighs,
                                                        LJParams P, LJTables T, real* __restrict__ f,
-                                                       double* __restrict__ partials, int ablate)
+                                                       double* __restrict__ partials, int ablate_arg)
 {
+  const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   __shared__ real s_cut[UNIFORM ? 1 : LJ_MAX_TYPES2], s_s6[UNIFORM ? 1 : LJ_MAX_TYPES2], s_eps[UNIFORM ? 1 : LJ_MAX_TYPES2];
   __shared__ double s_red[16];
   if(!UNIFORM) {
@@ -171,8 +172,9 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, int pos_bytes, LJParams P, real* __restrict__ f,
-    double* __restrict__ partials, int ablate, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, GhostResolve G)
+    double* __restrict__ partials, int ablate_arg, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, GhostResolve G)
 {
+  const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   extern __shared__ __align__(16) unsigned char s_raw[];
   real* s_f = (real*)(s_raw + pos_bytes);
   double* s_red = (double*)(s_raw + pos_bytes + lj_tile_sf_bytes(LJ_TILE_WAVES));
@@ -407,8 +409,9 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, const unsigned short* __restrict__ tile_self, int nlocal, int nall, int maxneighs, int pos_bytes,
-    LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate, const int* __restrict__ ghost_root)
+    LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate_arg, const int* __restrict__ ghost_root)
 {
+  const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   constexpr int UNR = 8, NT = 128, STG = 4;
   extern __shared__ __align__(16) unsigned char s_raw[];
   real* sp = (real*)s_raw;
@@ -599,7 +602,7 @@ extern "C" int mmd_force_lj_setup(mmd_handle* h, int ntypes, const mmd_float* cu
   HIP_TRY(hipMemcpyAsync(h->lj_tables.p, cutforcesq, n2 * sizeof(real), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->lj_tables.p + n2, sigma6, n2 * sizeof(real), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->lj_tables.p + 2 * n2, epsilon, n2 * sizeof(real), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return 0;
 }
 
@@ -772,7 +775,7 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     HIP_TRY(hipGetLastError());
     if(eng || vir) {
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(mmd_stream_sync(h));
       if(eng) *eng = h->h_result[0];
       if(vir) *vir = h->h_result[1];
     }

@@ -163,7 +163,7 @@ extern "C" int mmd_integrate_max_move(mmd_handle* h, double* d_max)
                                    (unsigned long long*)(h->d_result + 8));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h->h_result + 8, h->d_result + 8, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   *d_max = sqrt(h->h_result[8]);
   return 0;
 }
@@ -173,7 +173,7 @@ extern "C" int mmd_thermo_temperature(mmd_handle* h, double* sum_mv2)
   if(!h || !sum_mv2) { mmd_set_error("mmd_thermo_temperature: bad arguments"); return -1; }
   MMD_TRY(mmd_temperature_async(h, 2));
   HIP_TRY(hipMemcpyAsync(h->h_result + 2, h->d_result + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   *sum_mv2 = h->h_result[2];
   return 0;
 }

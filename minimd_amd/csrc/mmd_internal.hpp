@@ -36,6 +36,15 @@ typedef double4 real4;
 #define MMD_UNROLL 8            // neighbor rows are padded to a multiple of this (>= every kernel's unroll factor)
 #define MMD_BLOCK 256
 
+// profiling-only phase switches of the tile kernels / the tile build ("ablate": results invalid). The shipped library is built
+// WITHOUT -DMMD_PROFILE: every switch folds to 0 at compile time and mmd_set_option("ablate") is refused; tools/build_variant.sh
+// builds the profiling variant (tools/prof_force.py ABLATE=1 uses it).
+#ifdef MMD_PROFILE
+#define MMD_ABLATE(a) (a)
+#else
+#define MMD_ABLATE(a) 0
+#endif
+
 void mmd_set_error(const char* fmt, ...);
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
@@ -249,6 +258,11 @@ struct mmd_handle {
   size_t ev_used = 0;
   double force_ms = 0, comm_ms = 0;
   int force_launches = 0;
+  double force_ms_all = 0;             // Force::compute calls timed on every step (overlapped multi-rank steps), not sampled
+  int force_launches_all = 0;
+  // diagnostics of the last Integrate::run (mmd_run_stats): host synchronisations (hipStreamSynchronize / blocking copies issued by
+  // the step loop and everything below it) and bytes this rank sent to OTHER ranks (halo, exchange, borders payloads + handshakes)
+  long long host_syncs = 0, halo_bytes = 0;
   bool time_force_events = true;
   // ---- options
   int opt_exact_div = 0;
@@ -281,5 +295,8 @@ int mmd_transport_sendrecv_pair(mmd_handle* h, const void* const dsend[2], const
                                 const size_t nrecv[2], const int src[2]);
 int mmd_transport_allreduce(mmd_handle* h, double* vals, int n);
 double mmd_wall();
+
+// every blocking wait on the handle's stream goes through here, so that a run can report how often the host stalled the GPU
+static inline hipError_t mmd_stream_sync(mmd_handle* h) { h->host_syncs++; return hipStreamSynchronize(h->stream); }
 
 static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }

@@ -209,6 +209,8 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   if(h->bin_count_clean != g.mbins)            // (first use / new geometry; afterwards k_bin_sort leaves the histogram zeroed)
     HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
   h->bin_count_clean = -1;
+  // (dense bins, e.g. `-b 1`: the long-bin rank sort is on from the first binning, not only once a build has seen such a bin)
+  if(!h->big_bins && (long long)n > 32LL * g.nbin[0] * g.nbin[1] * g.nbin[2]) h->big_bins = true;
   if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr,
                            h->pbc_pending ? 1 : 0, h->prd[0], h->prd[1], h->prd[2]);
   h->pbc_pending = false;
@@ -420,8 +422,9 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
                                                        int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
                                                        int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
                                                        int* __restrict__ tile_max, int* __restrict__ tile_ghost, unsigned short* __restrict__ tile_self,
-                                                       int* __restrict__ flags, unsigned long long* __restrict__ total_out, int ablate)
+                                                       int* __restrict__ flags, unsigned long long* __restrict__ total_out, int ablate_arg)
 {
+  const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   extern __shared__ __align__(16) unsigned char s_dyn[];
   unsigned short* rows = (unsigned short*)s_dyn;              // [maxneighs][64]
   __shared__ int rng_start[128], rng_pref[130];
@@ -707,10 +710,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    unsigned short* __restrict__ nl16, int* __restrict__ tile_cand,
                                                    int* __restrict__ tile_ncand, int* __restrict__ tile_max, int* __restrict__ tile_ghost,
                                                    unsigned short* __restrict__ tile_self, int* __restrict__ tile_rowmax,
-                                                   int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate,
+                                                   int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate_arg,
                                                    const int* __restrict__ ntiles_dev, const int* __restrict__ nghost_dev,
                                                    float core_thr, real4* __restrict__ xbuild, int* __restrict__ tile_kcore)
 {
+  const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   nall = deferred_count(nall, nlocal, nghost_dev);
   __shared__ int rng_start[128], rng_len[128];
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
@@ -1126,7 +1130,7 @@ static int finish_rows(mmd_handle* h, bool count_total)
   HIP_TRY(hipGetLastError());
   if(count_total) {
     HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     unsigned long long tot;
     memcpy(&tot, h->h_result, sizeof(tot));
     h->total_neigh = (long long)tot;
@@ -1255,7 +1259,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       // [0..3] results, [4..5] total, [6] tile count, [12] long-bin flag, [16..55] bst of a deferred one-rank borders
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, (h->nghost_dev ? 56 : 16) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       if(h->opt_build != 1) HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(mmd_stream_sync(h));
       if(h->opt_build == 1) memcpy(h->h_result, h->h_flags + 4, sizeof(double));
       if(h->nghost_dev) {                   // the ghost counts of the deferred one-rank borders arrived with the flags
         memcpy(h->h_flags_big, h->h_flags + 16, 40 * sizeof(int));
@@ -1310,7 +1314,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #undef LAUNCH_BUILD
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     if(h->h_flags[12] && !h->big_bins) { h->big_bins = true; return mmd_neighbor_build(h); }
     const int maxn = h->h_flags[0];
     h->max_row = maxn;
@@ -1359,7 +1363,7 @@ extern "C" int mmd_neighbor_tile_stats(mmd_handle* h, long long out[6])
   if(!h->tiles_ready || h->ntiles <= 0) return 0;
   HIP_TRY(hipSetDevice(h->device));
   std::vector<int> nc(h->ntiles), mx(h->ntiles), ct(h->ntiles);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   HIP_TRY(hipMemcpy(nc.data(), h->tile_ncand.p, sizeof(int) * h->ntiles, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(mx.data(), h->tile_max.p, sizeof(int) * h->ntiles, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(ct.data(), h->tile_cnt.p, sizeof(int) * h->ntiles, hipMemcpyDeviceToHost));
@@ -1426,7 +1430,7 @@ extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneigh
     std::vector<int> hc((size_t)n);
     HIP_TRY(hipMemcpyAsync(hc.data(), cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if(neighbors) HIP_TRY(hipMemcpyAsync(neighbors, tmp.p, (size_t)n * maxneighs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     tmp.release(); cnt.release();
     int worst = 0;
     for(int i = 0; i < n; i++) worst = hc[i] > worst ? hc[i] : worst;
@@ -1441,10 +1445,10 @@ extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneigh
     hipLaunchKernelGGL(k_rows_to_ref, dim3(n), dim3(64), 0, h->stream, h->neigh.p, h->numneigh.p, n, h->maxneighs, tmp.p, maxneighs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(neighbors, tmp.p, (size_t)n * maxneighs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     tmp.release();
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   return 0;
 }
 
@@ -1472,7 +1476,7 @@ extern "C" int mmd_neighbor_upload(mmd_handle* h, const int* neighbors, int maxn
                        h->nlocal + h->nghost, h->neigh.p, h->numneigh.p, h->wave_max.p, (unsigned long long*)h->d_result);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(mmd_stream_sync(h));
   tmp.release();
   h->neigh_nlocal = nlocal;
   h->max_row = maxn;

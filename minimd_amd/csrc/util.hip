@@ -88,7 +88,7 @@ int mmd_exclusive_scan_from(mmd_handle* h, const int* src, int* data, int n, int
   HIP_TRY(hipGetLastError());
   if(total_host) {
     HIP_TRY(hipMemcpyAsync(h->h_flags, data + n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(mmd_stream_sync(h));
     *total_host = h->h_flags[0];
   }
   return 0;

@@ -15,6 +15,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: longer CPU case")
 
 
+def free_port():
+    """a loop-back TCP port nobody listens on right now (multi-process tests rendezvous there: a fixed number is a
+    spurious red on a shared box)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+@pytest.fixture
+def port():
+    return free_port()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _build_oracle():
     """The oracle is test infrastructure (oracle/): compile it once per session if it is missing/stale."""

@@ -248,7 +248,7 @@ def test_sp_run_passes_reference_rule_and_target_known_answer():
 
 
 # ---- two ranks sharing this GPU, halo over the gloo host transport ----------------------------------------
-@pytest.mark.parametrize("half,port", [(0, 29631), (1, 29632)])
+@pytest.mark.parametrize("half", [0, 1])
 def test_two_ranks_match_one_rank(half, port, tmp_path):
     args = ["-s", "8", "-n", "100", "--half_neigh", str(half)]
     base = sim_rows(args)
@@ -273,8 +273,8 @@ def test_two_ranks_match_one_rank(half, port, tmp_path):
     o.close()
 
 
-@pytest.mark.parametrize("nprocs,size,half,port", [(4, ["-nx", "8", "-ny", "9", "-nz", "10"], 0, 29641), (8, ["-s", "10"], 0, 29642),
-                                                   (8, ["-s", "10"], 1, 29643)])
+@pytest.mark.parametrize("nprocs,size,half", [(4, ["-nx", "8", "-ny", "9", "-nz", "10"], 0), (8, ["-s", "10"], 0),
+                                              (8, ["-s", "10"], 1)])
 def test_four_and_eight_ranks_match_one_rank(nprocs, size, half, port, tmp_path):
     """the decompositions the 4- and 8-GPU runs use (2x2x1 / 2x2x2: both neighbours of a dimension are the same rank,
     corner ghosts travel through chained swaps, atoms migrate in every dimension), here with all ranks sharing this GPU
@@ -302,7 +302,7 @@ def test_four_and_eight_ranks_match_one_rank(nprocs, size, half, port, tmp_path)
     o.close()
 
 
-@pytest.mark.parametrize("prec,deck,nprocs,port", [("dp", "in.eam.miniMD", 2, 29651), ("sp", "in.lj.miniMD", 4, 29652), ("dp", "in.eam.miniMD", 8, 29653)])
+@pytest.mark.parametrize("prec,deck,nprocs", [("dp", "in.eam.miniMD", 2), ("sp", "in.lj.miniMD", 4), ("dp", "in.eam.miniMD", 8)])
 def test_eam_and_sp_on_several_ranks(prec, deck, nprocs, port, tmp_path):
     """EAM needs a second halo per step (fp of the ghosts, ForceEAM::communicate ref/force_eam.cpp:851-913) and the SP build
     moves float4 halos: both on several ranks sharing this GPU against the one-rank run"""
@@ -598,8 +598,8 @@ def test_two_ghost_layers_one_rank(name):
     s.close()
 
 
-@pytest.mark.parametrize("size,nprocs,half,port", [(["-s", "3"], 2, 0, 29671), (["-nx", "3", "-ny", "3", "-nz", "6"], 4, 1, 29672),
-                                                   (["-nx", "4", "-ny", "3", "-nz", "3"], 3, 0, 29673)])
+@pytest.mark.parametrize("size,nprocs,half", [(["-s", "3"], 2, 0), (["-nx", "3", "-ny", "3", "-nz", "6"], 4, 1),
+                                                   (["-nx", "4", "-ny", "3", "-nz", "3"], 3, 0)])
 def test_two_ghost_layers_several_ranks(size, nprocs, half, port, tmp_path):
     """sub-domains thinner than the cutoff on several ranks (sharing this GPU, gloo host transport): a rank's ghosts come
     from its neighbor AND from the rank beyond it (second swap pair of the dimension, ref/comm.cpp:208-269). Rows equal the
@@ -876,8 +876,8 @@ def test_bench_launches_itself_for_two_ranks(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args,port", [(["-s", "12", "-n", "100", "--half_neigh", "0"], 29681), (["-s", "12", "-n", "100", "--half_neigh", "1"], 29682),
-                                       (["-i", "in.eam.miniMD", "-s", "8", "-n", "60", "--half_neigh", "0"], 29683)])
+@pytest.mark.parametrize("args", [["-s", "12", "-n", "100", "--half_neigh", "0"], ["-s", "12", "-n", "100", "--half_neigh", "1"],
+                                  ["-i", "in.eam.miniMD", "-s", "8", "-n", "60", "--half_neigh", "0"]])
 def test_rccl_two_gpus_match_one_rank(args, port, tmp_path):
     """the PRODUCTION transport between two real GPUs (skipped on a one-GPU box): RCCL count handshakes and payloads of
     exchange / borders (both swaps of a ghost layer in one group), the per-step halo pair of a 2-wide dimension (two sends to
@@ -920,3 +920,29 @@ def test_bench_contract_single_gpu():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["unit"] == "GB/s"
     cb = d["cpu_baseline"]
     assert cb and cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inp,half", [("lj", 0), ("lj", 1), ("eam", 0)])
+def test_reference_harness_scope0_passes(inp, half):
+    """the reference's own validation procedure (ref/run_tests scope 0 -> ref/run_one_test) on the drop-in executable:
+    tools/run_one_test.py runs miniMD_dp like `make test` would, cuts the thermo block and applies the PASS rule against
+    the published log of that system size"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "run_one_test.py"), "--scope", "0", "--input", inp, "--halfneigh", str(half)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PASSED" in r.stdout and "Failed" not in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_run_stats_one_rank_has_no_host_syncs_between_rebuilds():
+    """mmd_run_stats: a one-rank run blocks the host once per re-neighboring (the build's read-back) and on thermo rows only;
+    nothing is sent to other ranks"""
+    s = minimd_amd.Sim(["-s", "16", "-n", "100", "--half_neigh", "0"], quiet=True)
+    s.initial()
+    s.run_steps(19)                      # steps 1..19: no re-neighboring, no thermo row
+    st = s.handle.run_stats()
+    assert st["host_syncs"] == 0 and st["bytes_sent"] == 0, st
+    s.run_steps(41)                      # steps 20..60: three re-neighborings
+    st = s.handle.run_stats()
+    assert 3 <= st["host_syncs"] <= 6 and st["bytes_sent"] == 0, st
+    s.close()

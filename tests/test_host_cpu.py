@@ -1,8 +1,11 @@
 """CPU-only tests of the product's host side (no GPU, no compute calls): the C-ABI library loads and exports
 every symbol include/mmd.h declares; host logic (input deck, lattice, EAM tables, Comm::setup and
 Neighbor::setup geometry) is bit-identical to the oracle's; the product refuses to run without a GPU."""
+import json
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -192,3 +195,27 @@ def test_documented_force_plugin_compiles_against_the_reference_headers():
     assert r.returncode == 0, r.stdout + r.stderr
     text = open(os.path.join(REPO, "INTEGRATION.md")).read()
     assert "tests/integration/force_hip.h" in text
+
+
+# ---- the user-facing validation harness (ref/run_one_test, ref/run_tests restated as tools/run_one_test.py) -------------------
+def test_harness_pass_rule_and_a_run_of_the_cpu_oracle():
+    """tools/run_one_test.py applies the reference's statistical PASS rule (ref/run_one_test:121-138). Here (no GPU) it judges the
+    CPU oracle's executable — same CLI and stdout grammar as the drop-in — against the published 4k.lj log, and must reject rows
+    that drift by more than the rule allows."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("run_one_test", os.path.join(REPO, "tools", "run_one_test.py"))
+    rot = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rot)
+    from oracle_lib import ref_pass_rule
+    gold = json.load(open(os.path.join(REPO, "tests", "golden", "reference_output.json")))["4k.lj"]
+    rows = [tuple(r) for r in gold["rows"]]
+    assert rot.pass_rule(rows, rows, gold["natoms"], 8, False)[0]
+    bad = [(s, t * 1.05, u * 1.05, p) for s, t, u, p in rows]          # (one whole column may miss: the rule sums the three)
+    assert not rot.pass_rule(rows, bad, gold["natoms"], 8, False)[0]
+    assert rot.pass_rule(rows, bad, gold["natoms"], 8, False)[0] == ref_pass_rule(rows, bad, gold["natoms"], 8)[0]
+    nsteps, threads, runs = rot.scope_runs(1)
+    assert (nsteps, threads) == (1000, 1) and runs == [(1, 10), (3, 10), (8, 10)]          # ref/run_tests:62-66,116-145
+    exe = os.path.join(REPO, "oracle", "mmd_oracle_dp")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "run_one_test.py"), exe, "1", "1", "10", "100", "0", "0", "lj"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PASSED" in r.stdout and "Testfile: tests/reference_output/4k.lj" in r.stdout, r.stdout + r.stderr

@@ -17,7 +17,7 @@ def launch(nproc, argv, port):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("world,port", [(2, 29611), (4, 29612)])
+@pytest.mark.parametrize("world", [2, 4])
 def test_gloo_swap_pattern(world, port, tmp_path):
     out = str(tmp_path / "geo.json")
     r = launch(world, ["geometry", out], port)
