@@ -123,6 +123,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "tile_unroll")) h->opt_tile_unroll = value;
   else if(!strcmp(name, "tile_read")) h->opt_tile_read = value;
   else if(!strcmp(name, "check_exchange")) h->opt_check_exchange = value;
+  else if(!strcmp(name, "safe_exchange")) h->opt_safe_exchange = value;
   else if(!strcmp(name, "maxneighs")) h->maxneighs = (value + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
   else { mmd_set_error("mmd_set_option: unknown option '%s'", name); return -1; }
   return 0;

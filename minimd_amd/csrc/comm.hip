@@ -568,6 +568,34 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
       HIP_TRY(hipGetLastError());
     }
     h->nlocal = nlocal - nsend;
+    if(h->opt_safe_exchange) {
+      // Comm::exchange_all (ref/comm.cpp:599-689, entered from :366-367 when do_safeexchange): the leavers of this dimension are
+      // offered to every rank within need[d] sub-domains, nearest first, alternating -i / +i (sendproc_exc / recvproc_exc =
+      // MPI_Cart_shift(cartesian, d, i), :176-180), while `ineed < procgrid[d] - 1` (:656); each receiver keeps what falls inside
+      // its own [lo, hi) (:675-681). The buffer is packed once (above), arrivals are appended swap by swap.
+      for(int ineed = 0; ineed < 2 * h->need[d]; ineed++) {
+        if(!(ineed < h->procgrid[d] - 1)) continue;
+        const int dist = ineed / 2 + 1;
+        int lo_c[3] = {h->myloc[0], h->myloc[1], h->myloc[2]}, hi_c[3] = {h->myloc[0], h->myloc[1], h->myloc[2]};
+        lo_c[d] -= dist; hi_c[d] += dist;
+        const int below = cart_rank(h->procgrid, lo_c[0], lo_c[1], lo_c[2]), above = cart_rank(h->procgrid, hi_c[0], hi_c[1], hi_c[2]);
+        const int dest = ineed % 2 == 0 ? below : above, src = ineed % 2 == 0 ? above : below;
+        int nrecv = 0;
+        MMD_TRY(mmd_transport_sendrecv_counts(h, nsend, dest, &nrecv, src));
+        MMD_TRY(h->buf_recv.ensure(rec_reals * nrecv + 8, false, h->stream));
+        MMD_TRY(mmd_transport_sendrecv(h, h->buf_send.p, (size_t)nsend * sizeof(ExchRec), dest, h->buf_recv.p, (size_t)nrecv * sizeof(ExchRec), src));
+        int nkeep = 0;
+        MMD_TRY(compact(h, ArrivePred{(const ExchRec*)h->buf_recv.p, d, lo, hi}, 0, nrecv, keep, &nkeep));
+        if(nkeep) {
+          MMD_TRY(mmd_ensure_atoms(h, h->nlocal + nkeep + 1, true));
+          hipLaunchKernelGGL(k_unpack_exchange, dim3(div_up(nkeep, 256)), dim3(256), 0, h->stream, (const ExchRec*)h->buf_recv.p, keep.p, nkeep,
+                             h->nlocal, h->x.p, h->v.p, h->type.p, h->tag.p);
+          HIP_TRY(hipGetLastError());
+          h->nlocal += nkeep;
+        }
+      }
+      continue;
+    }
     // send towards -1, receive from +1; and the other way round when the grid is wider than 2 (ref :521-543): both
     // directions share one count handshake (one host sync) and one payload group
     int nrecv1 = 0, nrecv2 = 0;

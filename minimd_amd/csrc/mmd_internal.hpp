@@ -183,6 +183,7 @@ struct mmd_handle {
   int opt_build = 1;         // tile build kernel: 1 = one owned atom per lane (k_build_rows), 0 = one candidate per lane (k_build_tiles)
   int opt_force_transport = 0;   // testing: route self-swaps through the transport too (RCCL loop-back on one GPU)
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
+  int opt_safe_exchange = 0;                      // Comm::do_safeexchange (ref/comm.h:87): Comm::exchange offers leavers to every rank within `need` sub-domains
   int opt_check_exchange = 0;                     // --check_exchange: warn when an atom moved further than a sub-domain
   int opt_tile_read = 2;                          // 2: one reciprocal per four pairs (default); 0: one per pair; 1: + three separate 8-byte LDS reads per pair (A/B knobs)
   int opt_fuse = 2;          // >=1: fused final+initial integrate, single-kernel ghost update on one rank; 2: integrator inside the LJ tile kernel

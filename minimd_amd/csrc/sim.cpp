@@ -28,7 +28,7 @@ struct mmd_sim {
   mmd_input in;
   std::string input_file = "in.lj.miniMD";
   int me = 0, nprocs = 1, quiet = 0;
-  int num_threads = 1, ntypes = 4, halfneigh = 1, ghost_newton = 1, sort = -1, yaml_output = 0, yaml_screen = 0, check_exchange = 0;
+  int num_threads = 1, ntypes = 4, halfneigh = 1, ghost_newton = 1, sort = -1, yaml_output = 0, yaml_screen = 0, check_exchange = 0, safe_exchange = 0;
   int nbin[3] = {1, 1, 1};
   int natoms = 0;
   int sort_every = 0;
@@ -122,7 +122,7 @@ static void print_help()
          "  -gn / --ghost_newton <int> Newton's third law across ghosts (half lists; default 1, EAM forces 0)\n"
          "  --sort <n>                 re-sort atoms every n steps (default: every re-neighboring, 0 never)\n"
          "  -u / --units <lj|metal>    -p / --force <lj|eam>    -t / --num_threads <int> (accepted, unused)\n"
-         "  -o / --yaml_output <int>   --yaml_screen   -f / --data_file <file>   --check_exchange   -h / --help\n\n");
+         "  -o / --yaml_output <int>   --yaml_screen   -f / --data_file <file>   --check_exchange   --safe_exchange   -h / --help\n\n");
 }
 
 static void thermo_setup(mmd_sim* s)
@@ -199,6 +199,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     else if(is_flag(a, "-o", "--yaml_output") && has) s->yaml_output = atoi(argv[++i]);
     else if(is_flag(a, "--yaml_screen")) s->yaml_screen = 1;
     else if(is_flag(a, "--check_exchange")) s->check_exchange = 1;
+    else if(is_flag(a, "--safe_exchange")) s->safe_exchange = 1;        // (ref/ljs.cpp:251 lists it; Comm::do_safeexchange, ref/comm.cpp:366-367)
     else if(is_flag(a, "-f", "--data_file") && has) { s->in.has_datafile = 1; strncpy(s->in.datafile, argv[++i], sizeof(s->in.datafile) - 1); }
     else if(is_flag(a, "-u", "--units") && has) s->in.units = strcmp(argv[++i], "metal") == 0 ? 1 : 0;
     else if(is_flag(a, "-p", "--force") && has) s->in.forcetype = strcmp(argv[++i], "eam") == 0 ? 1 : 0;
@@ -340,6 +341,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
   // dtforce chain: 0.5*dt [/mvv2e] /mass (ref/integrate.cpp:43,80-81; ref/thermo.cpp:69)
   SIM_TRY(mmd_integrate_setup(h, s->dt, s->dtforce / s->mass, s->in.neigh_every, s->sort_every));
   if(s->check_exchange) SIM_TRY(mmd_set_option(h, "check_exchange", 1));
+  if(s->safe_exchange) SIM_TRY(mmd_set_option(h, "safe_exchange", 1));
 #undef SIM_TRY
   if(s->me == 0 && !quiet) {
     printf("# Done .... \n");
@@ -368,7 +370,7 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     fprintf(stdout, "\t# Thermo frequency: %i\n", s->in.thermo_nstat);
     fprintf(stdout, "\t# Ghost Newton: %i\n", s->ghost_newton);
     fprintf(stdout, "\t# Use intrinsics: %i\n", 0);
-    fprintf(stdout, "\t# Do safe exchange: %i\n", 0);
+    fprintf(stdout, "\t# Do safe exchange: %i\n", s->safe_exchange);
     fprintf(stdout, "\t# Size of float: %i\n\n", (int)sizeof(mmd_float));
   }
   *out = s;
@@ -544,7 +546,7 @@ extern "C" int mmd_sim_output(mmd_sim* s, int screen_yaml)
   out("  thermo_frequency: %i\n", s->in.thermo_nstat);
   out("  ghost_newton: %i\n", s->ghost_newton);
   out("  use_intrinsics: %i\n", 0);
-  out("  safe_exchange: %i\n", 0);
+  out("  safe_exchange: %i\n", s->safe_exchange);
   out("  float_size: %i\n\n", (int)sizeof(mmd_float));
   out("\n\nthermodynamic_output:\n");
   for(size_t i = 0; i < s->row_step.size(); i++) {

@@ -130,6 +130,7 @@ typedef struct {
 
 struct orc_world {
   int nprocs, quiet, num_threads, ntypes, halfneigh, ghost_newton, sort_flag, sort_every, yaml_output;
+  int safe_exchange;         /* Comm::do_safeexchange (ref/comm.h:87): Comm::exchange -> exchange_all (ref/comm.cpp:366-367) */
   deck_t in;
   char input_file[1024];
   rank_t* r;
@@ -892,8 +893,11 @@ void orc_reverse_communicate(orc_world* w)
  * Comm::exchange (ref/comm.cpp:364-597), single-thread semantics, on virtual ranks
  * ---------------------------------------------------------------------------------------------- */
 
+static void orc_exchange_all(orc_world* w);
+
 void orc_exchange(orc_world* w)
 {
+  if(w->safe_exchange) { orc_exchange_all(w); return; }          /* ref/comm.cpp:366-367 */
   for(int p = 0; p < w->nprocs; p++) atom_pbc(&w->r[p].atom);
   for(int d = 0; d < 3; d++) {
     if(w->r[0].comm.procgrid[d] == 1) continue;
@@ -946,6 +950,80 @@ void orc_exchange(orc_world* w)
         for(int i = 0; i < from->nsend_now; i++) {
           const real* b = &from->buf_send[i * 7];
           if(b[d] >= lo && b[d] < hi) {                 /* Atom::unpack_exchange  ref/atom.cpp:241-254 */
+            if(a->nlocal == a->nmax) atom_grow(a);
+            const int n = a->nlocal++;
+            a->x[n * PAD + 0] = b[0]; a->x[n * PAD + 1] = b[1]; a->x[n * PAD + 2] = b[2];
+            a->v[n * PAD + 0] = b[3]; a->v[n * PAD + 1] = b[4]; a->v[n * PAD + 2] = b[5];
+            a->type[n] = b[6];
+            a->tag[n] = from->tag_send[i];
+          }
+        }
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Comm::exchange_all (ref/comm.cpp:599-689): "safe exchange" — the atoms that left my box in dimension d are offered to EVERY rank
+ * within `need[d]` sub-domains in that dimension, nearest first, alternating -i / +i (sendproc_exc / recvproc_exc of
+ * MPI_Cart_shift(cartesian, d, i), ref/comm.cpp:176-180: even swaps send to me-i and receive from me+i, odd ones the other way);
+ * a swap runs only while `ineed < procgrid[d] - 1` (:656), so no rank is offered the same buffer twice. Every receiver keeps what
+ * falls inside its [lo, hi) of that dimension (:675-681). The send buffer is packed once per dimension (:625-637).
+ * ---------------------------------------------------------------------------------------------- */
+static void orc_exchange_all(orc_world* w)
+{
+  for(int p = 0; p < w->nprocs; p++) atom_pbc(&w->r[p].atom);
+  for(int d = 0; d < 3; d++) {
+    const int pgd = w->r[0].comm.procgrid[d];
+    if(pgd == 1) continue;
+    for(int p = 0; p < w->nprocs; p++) {                /* pack the leavers, close the holes: as orc_exchange */
+      rank_t* R = &w->r[p];
+      atom_t* a = &R->atom;
+      comm_t* c = &R->comm;
+      const real lo = d == 0 ? a->box.xlo : (d == 1 ? a->box.ylo : a->box.zlo);
+      const real hi = d == 0 ? a->box.xhi : (d == 1 ? a->box.yhi : a->box.zhi);
+      const int nlocal = a->nlocal;
+      int* stays = (int*)malloc(((size_t)nlocal + 1) * sizeof(int));
+      int* leavers = (int*)malloc(((size_t)nlocal + 1) * sizeof(int));
+      int nsend = 0;
+      for(int i = 0; i < nlocal; i++) {
+        const real v = a->x[i * PAD + d];
+        if(v < lo || v >= hi) { leavers[nsend++] = i; stays[i] = 0; } else stays[i] = 1;
+      }
+      if(nsend * 7 > c->maxsend) comm_growsend(c, nsend * 7);
+      if(nsend > c->tag_cap) { c->tag_cap = nsend + 1024; c->tag_send = (int*)realloc(c->tag_send, c->tag_cap * sizeof(int)); }
+      int j = nlocal - nsend;
+      for(int k = 0; k < nsend; k++) {
+        const int i = leavers[k];
+        real* b = &c->buf_send[k * 7];
+        b[0] = a->x[i * PAD + 0]; b[1] = a->x[i * PAD + 1]; b[2] = a->x[i * PAD + 2];
+        b[3] = a->v[i * PAD + 0]; b[4] = a->v[i * PAD + 1]; b[5] = a->v[i * PAD + 2];
+        b[6] = a->type[i];
+        c->tag_send[k] = a->tag[i];
+        if(i < nlocal - nsend) {
+          while(!stays[j]) j++;
+          atom_copy(a, j++, i);
+        }
+      }
+      a->nlocal = nlocal - nsend;
+      c->nsend_now = nsend;
+      free(stays); free(leavers);
+    }
+    for(int ineed = 0; ineed < 2 * w->r[0].comm.need[d]; ineed++) {
+      if(!(ineed < pgd - 1)) continue;                  /* ref/comm.cpp:656 */
+      const int dist = ineed / 2 + 1;
+      for(int p = 0; p < w->nprocs; p++) {
+        rank_t* R = &w->r[p];
+        atom_t* a = &R->atom;
+        comm_t* c = &R->comm;
+        const real lo = d == 0 ? a->box.xlo : (d == 1 ? a->box.ylo : a->box.zlo);
+        const real hi = d == 0 ? a->box.xhi : (d == 1 ? a->box.yhi : a->box.zhi);
+        int loc[3] = {c->myloc[0], c->myloc[1], c->myloc[2]};
+        loc[d] += (ineed % 2 == 0) ? dist : -dist;      /* recvproc_exc: me+i for even swaps, me-i for odd ones */
+        const comm_t* from = &w->r[cart_rank(c->procgrid, loc[0], loc[1], loc[2])].comm;
+        for(int i = 0; i < from->nsend_now; i++) {
+          const real* b = &from->buf_send[i * 7];
+          if(b[d] >= lo && b[d] < hi) {
             if(a->nlocal == a->nmax) atom_grow(a);
             const int n = a->nlocal++;
             a->x[n * PAD + 0] = b[0]; a->x[n * PAD + 1] = b[1]; a->x[n * PAD + 2] = b[2];
@@ -1589,6 +1667,7 @@ orc_world* orc_create(int argc, char** argv, int nprocs, int quiet)
     else if(arg_is(a, "-u", "--units") && has) units_override = strcmp(argv[++i], "metal") == 0 ? UNITS_METAL : UNITS_LJ;
     else if(arg_is(a, "-p", "--force") && has) force_override = strcmp(argv[++i], "eam") == 0 ? FORCE_EAM : FORCE_LJ;
     else if(arg_is(a, "-gn", "--ghost_newton") && has) w->ghost_newton = atoi(argv[++i]);
+    else if(arg_is(a, "--safe_exchange", NULL)) w->safe_exchange = 1;     /* listed by the reference's --help (ref/ljs.cpp:251), parsed here */
   }
   if(units_override >= 0) w->in.units = units_override;
   if(force_override >= 0) w->in.forcetype = force_override;
@@ -1692,7 +1771,7 @@ orc_world* orc_create(int argc, char** argv, int nprocs, int quiet)
     printf("\t# Thermo frequency: %i\n", w->thermo.nstat);
     printf("\t# Ghost Newton: %i\n", w->ghost_newton);
     printf("\t# Use intrinsics: %i\n", 0);
-    printf("\t# Do safe exchange: %i\n", 0);
+    printf("\t# Do safe exchange: %i\n", w->safe_exchange);
     printf("\t# Size of float: %i\n\n", (int)sizeof(real));
   }
   return w;

@@ -91,12 +91,46 @@ def sim(out, args, precision, rccl=False):
     s.close()
 
 
+def exchange_all(out, args, precision):
+    """GPU, ranks share the visible GPU(s), gloo host transport: after Sim.initial() every rank pushes some of its atoms two
+    sub-domains away (every 5th up, every 5th+1 down, in the last dimension of the grid), then runs Comm::exchange with the
+    safe-exchange option (Comm::exchange_all, ref/comm.cpp:599-689). Rank 0 writes every rank's owned positions, in order."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    tr = GlooTransport()
+    api.sim_set_host_transport(tr.sendrecv, tr.allreduce, precision)
+    s = minimd_amd.Sim(args, precision=precision)
+    s.initial()
+    h = s.handle
+    d = h.download()
+    nl = d["nlocal"]
+    prd, lo, hi = h.get_box()
+    info = h.comm_info()
+    dim = int(np.argmax(info["procgrid"]))
+    x = d["x"][:nl].copy()
+    w = hi[dim] - lo[dim]
+    idx = np.arange(nl)
+    x[idx % 5 == 0, dim] += 2 * w
+    x[idx % 5 == 1, dim] -= 2 * w
+    h.upload(x, d["v"], d["type"][:nl], d["tag"])
+    h.set_option("safe_exchange", int(os.environ.get("MMD_TEST_SAFE", "1")))
+    h.exchange()
+    e = h.download()
+    mine = {"x": e["x"][:e["nlocal"]].tolist(), "v": e["v"].tolist(), "dim": dim, "need": info["need"].tolist(), "procgrid": info["procgrid"].tolist()}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    if rank == 0:
+        json.dump(allr, open(out, "w"))
+    s.close()
+
+
 if __name__ == "__main__":
     mode, out = sys.argv[1], sys.argv[2]
     dist.init_process_group(backend="gloo")
     try:
         if mode == "geometry":
             geometry(out)
+        elif mode == "exchall":
+            exchange_all(out, sys.argv[4:], sys.argv[3])
         else:
             sim(out, sys.argv[4:], sys.argv[3], rccl=(mode == "simrccl"))
         dist.barrier()

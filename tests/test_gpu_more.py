@@ -988,3 +988,50 @@ def test_reference_program_runs_on_the_plugin(prec, lists):
             assert abs(a[k] - b[k]) <= tol * max(1.0, abs(b[k])), (a, b)
     assert ref_pass_rule(ref, rows, 4000, 8 if prec == "dp" else 4)[0]
     assert "ForceHIP:" not in r.stderr                   # (the plugin reports C-ABI errors there)
+
+
+@pytest.mark.gpu
+def test_exchange_all_moves_atoms_two_subdomains_like_the_oracle(port, tmp_path):
+    """Comm::exchange_all (ref/comm.cpp:599-689, `--safe_exchange`): 4 ranks in a 1x1x4 grid of sub-domains thinner than the
+    cutoff (need = 2); two fifths of every rank's atoms are pushed TWO sub-domains up / down before the exchange. Every rank must
+    end up owning exactly the atoms, in exactly the order, the oracle's virtual ranks own after the same displacement; the plain
+    exchange (offers leavers to the direct neighbours only) loses them."""
+    import ctypes
+    args = ["-nx", "3", "-ny", "3", "-nz", "6", "--sort", "0", "-n", "20", "--half_neigh", "0"]
+    out = str(tmp_path / "ex.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "exchall", out, "dp"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res[0]["procgrid"] == [1, 1, 4] and res[0]["need"][2] == 2 and res[0]["dim"] == 2
+    o = Oracle(args + ["--safe_exchange"], nprocs=4)
+    o.initial()
+    for p_ in range(4):
+        nl = o.nlocal(p_)
+        xv = np.ctypeslib.as_array(o.lib.orc_x(o.w, p_), shape=(3 * nl,)).reshape(nl, 3)       # (a view: written in place)
+        box = o.box(p_)
+        w = box["zhi"] - box["zlo"] if isinstance(box, dict) else box[8] - box[7]
+        idx = np.arange(nl)
+        xv[idx % 5 == 0, 2] += 2 * w
+        xv[idx % 5 == 1, 2] -= 2 * w
+    o.lib.orc_exchange(o.w)
+    total = 0
+    for p_ in range(4):
+        nl = o.nlocal(p_)
+        total += nl
+        assert len(res[p_]["x"]) == nl, (p_, len(res[p_]["x"]), nl)
+        assert np.array_equal(np.array(res[p_]["x"]), o.x(p_)[:nl])
+        # (velocities: the centre-of-mass removal of create_velocity sums over the ranks in a different order — last digits only)
+        assert np.allclose(np.array(res[p_]["v"]), o.v(p_), rtol=1e-12, atol=1e-13)
+    assert total == o.natoms()
+    o.close()
+    # the plain exchange on the same displaced system loses the far movers (that is what the option is for)
+    env["MMD_TEST_SAFE"] = "0"
+    out2 = str(tmp_path / "ex0.json")
+    cmd[cmd.index(out)] = out2
+    cmd[cmd.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert sum(len(q["x"]) for q in json.load(open(out2))) < total

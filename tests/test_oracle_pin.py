@@ -211,3 +211,20 @@ def test_virtual_ranks_match_single_rank(nprocs):
         assert a[0] == b[0]
         for k in (1, 2, 3):
             assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+
+
+def test_oracle_exchange_all_equals_exchange_on_a_healthy_run():
+    """Comm::exchange_all (ref/comm.cpp:599-689) offers the leavers of a dimension to every rank within `need` sub-domains; while
+    no atom moves further than one sub-domain between two re-neighborings every rank keeps exactly the atoms, in the order, the
+    plain Comm::exchange gives it — rows, per-rank counts and positions of the two oracle runs are identical (4 virtual ranks,
+    1x1x4 grid of sub-domains thinner than the cutoff, need = 2, and a 2x2x2 grid with need = 1)."""
+    for args, nprocs in ((["-nx", "3", "-ny", "3", "-nz", "6", "-n", "60", "--half_neigh", "0"], 4), (["-s", "6", "-n", "60", "--half_neigh", "1"], 8)):
+        a = Oracle(args, nprocs=nprocs)
+        b = Oracle(args + ["--safe_exchange"], nprocs=nprocs)
+        for o in (a, b):
+            o.initial(); o.run()
+        assert a.rows() == b.rows()
+        for p in range(nprocs):
+            assert a.nlocal(p) == b.nlocal(p) and a.nghost(p) == b.nghost(p)
+            assert np.array_equal(a.x(p), b.x(p))
+        a.close(); b.close()
