@@ -72,6 +72,23 @@ extern "C" int mmd_neighbor_setup(mmd_handle* h, const int nbin[3], mmd_float cu
   return 0;
 }
 
+// coord -> (ix,iy,iz) exactly as Neighbor::coord2bin (ref/neighbor.cpp:274-297), packed 10 bits each (the reference-rule half
+// build k_build<3> compares bins of the REFERENCE grid; mbin <= 1023 per dimension is checked by its caller)
+__device__ __forceinline__ int ref_bin3(const BinGeom& g, real x, real y, real z)
+{
+  int ix, iy, iz;
+  if(x >= g.prd[0]) ix = (int)((x - g.prd[0]) * g.bininv[0]) + g.nbin[0] - g.mbinlo[0];
+  else if(x >= (real)0.0) ix = (int)(x * g.bininv[0]) - g.mbinlo[0];
+  else ix = (int)(x * g.bininv[0]) - g.mbinlo[0] - 1;
+  if(y >= g.prd[1]) iy = (int)((y - g.prd[1]) * g.bininv[1]) + g.nbin[1] - g.mbinlo[1];
+  else if(y >= (real)0.0) iy = (int)(y * g.bininv[1]) - g.mbinlo[1];
+  else iy = (int)(y * g.bininv[1]) - g.mbinlo[1] - 1;
+  if(z >= g.prd[2]) iz = (int)((z - g.prd[2]) * g.bininv[2]) + g.nbin[2] - g.mbinlo[2];
+  else if(z >= (real)0.0) iz = (int)(z * g.bininv[2]) - g.mbinlo[2];
+  else iz = (int)(z * g.bininv[2]) - g.mbinlo[2] - 1;
+  return (ix & 1023) | ((iy & 1023) << 10) | ((iz & 1023) << 20);
+}
+
 // coord -> (ix,iy,iz) exactly as Neighbor::coord2bin (ref/neighbor.cpp:274-297), then block-major id
 __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
 {
@@ -235,6 +252,11 @@ int mmd_bin_atoms(mmd_handle* h, int count)
 // MODE 0: full list (every j != i).  MODE 1: half, no ghost newton (keep j > i; ghosts always, ref :171).
 // MODE 2: half with ghost newton: every pair stored once globally — owned j: j > i; ghost j (periodic image or another
 //         rank's atom alike): (z,y,x) lexicographic order of the positions as ref/neighbor.cpp:155-157.
+// MODE 3: half with ghost newton, the REFERENCE's own partition (ref/neighbor.cpp:143-182 with the half stencil of :424-441): a
+//         partner in the atom's own bin is kept when j > i (owned) / when it is not below the atom in (z,y,x) order (ghost, :150-157);
+//         a partner in another bin is kept when that bin lies in the upper half of the stencil (dk > 0, or dk == 0 and (dj > 0 or
+//         (dj == 0 and di > 0))), whoever owns it. Used by mmd_neighbor_download only: the force kernels work on the positional
+//         partition of the tile build, a downloaded list is the reference's list (rows as sets).
 //
 // Work decomposition (one wavefront per 2x2x2-bin block):
 //   * the ~27 blocks x ~57 atoms of candidates are loaded ONCE into REGISTERS, transposed: lane l holds
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
           cx[c] = p.x; cy[c] = p.y; cz[c] = p.z;
           unsigned info = 1;
           if(MODE == 1) info = j >= nlocal ? 1 : 3;
-          if(MODE == 2) {
+          if(MODE == 2 || MODE == 3) {
             info = j < nlocal ? 3 : 2;                       // ghosts: (z,y,x) order of the positions decides (ref/neighbor.cpp:155-157)
           }
           cw[c] = (unsigned)j | (info << 29);
@@ -330,6 +352,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
         if(i >= nlocal) continue;                            // ghosts get no row
         const real4 xi = x[i];                               // uniform address: scalar load
         const real xix = xi.x, xiy = xi.y, xiz = xi.z;
+        const int bin_i = MODE == 3 ? ref_bin3(g, xix, xiy, xiz) : 0;
         int n = cnt[a - ab];
         const size_t rowbase = ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63);
 #pragma unroll
@@ -339,13 +362,25 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
             const real rsq = dx * dx + dy * dy + dz * dz;
             const int j = (int)(cw[c] & NB_IDX_MASK);
             bool keep = rsq <= cutneighsq && j != i;
-            if(MODE != 0) {
+            if(MODE != 0 && MODE != 3) {
               const unsigned info = cw[c] >> 29;
               bool ok = info == 1;
               if(info == 3) ok = j > i;
               if(MODE == 2 && info == 2)
                 ok = !(cz[c] < xiz || (cz[c] == xiz && cy[c] < xiy) || (cz[c] == xiz && cy[c] == xiy && cx[c] < xix));
               keep = keep && ok;
+            }
+            if(MODE == 3 && keep) {                          // (only the few candidates inside the cutoff pay for their bin)
+              const int bin_j = ref_bin3(g, cx[c], cy[c], cz[c]);
+              bool ok;
+              if(bin_j == bin_i) {
+                ok = (cw[c] >> 29) == 3 ? j > i
+                                        : !(cz[c] < xiz || (cz[c] == xiz && cy[c] < xiy) || (cz[c] == xiz && cy[c] == xiy && cx[c] < xix));
+              } else {
+                const int di = (bin_j & 1023) - (bin_i & 1023), dj = ((bin_j >> 10) & 1023) - ((bin_i >> 10) & 1023), dk = (bin_j >> 20) - (bin_i >> 20);
+                ok = dk > 0 || (dk == 0 && (dj > 0 || (dj == 0 && di > 0)));
+              }
+              keep = ok;
             }
             const unsigned long long m = __ballot(keep);
             if(m) {
@@ -1417,8 +1452,42 @@ __global__ void k_rows_from_ref(const int* __restrict__ in, const int* __restric
 extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneighs, int* numneigh)
 {
   if(!h || h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_neighbor_download: no neighbor list for the current atoms"); return -1; }
-  MMD_TRY(mmd_ensure_rows(h));
   const int n = h->nlocal;
+  if(h->halfneigh && h->ghost_newton && n && h->tiles_ready) {
+    // half lists with ghost newton: the device list partitions the pairs by the (z,y,x) order of the two positions, the reference by
+    // its half stencil of bins + the same-bin rules (ref/neighbor.cpp:143-182, :424-441). What crosses the boundary is the REFERENCE's
+    // list: rebuilt here from the same binned atoms with the reference's rule (k_build<3>), rows equal the oracle's as sets.
+    const BinGeom& g = h->bg;
+    if(g.mbin[0] > 1023 || g.mbin[1] > 1023 || g.mbin[2] > 1023) { mmd_set_error("mmd_neighbor_download: more than 1023 bins per dimension"); return -1; }
+    const int nwaves = div_up(n, 64), nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
+    DevArr<int> rows, cnt, tmp;
+    MMD_TRY(cnt.ensure((size_t)n + 64, false, h->stream));
+    int stride = 2 * h->maxneighs;
+    for(int attempt = 0; ; attempt++) {
+      MMD_TRY(rows.ensure((size_t)nwaves * stride * 64 + 64, false, h->stream));
+      HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
+      hipLaunchKernelGGL(k_build<3>, dim3(xcd_grid(nblocks)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p, h->ghost_image.p, g, n,
+                         h->cutneighsq, stride, rows.p, cnt.p, h->d_flags);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(mmd_stream_sync(h));
+      if(h->h_flags[0] < stride) break;
+      if(attempt == 4) { mmd_set_error("mmd_neighbor_download: rows keep overflowing"); return -1; }
+      stride = (int)(h->h_flags[0] * 1.2) + 8;
+    }
+    if(neighbors && h->h_flags[0] > maxneighs) { mmd_set_error("mmd_neighbor_download: a row holds %d entries, the stride is %d", h->h_flags[0], maxneighs); return -1; }
+    if(numneigh) HIP_TRY(hipMemcpyAsync(numneigh, cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if(neighbors) {
+      MMD_TRY(tmp.ensure((size_t)n * maxneighs, false, h->stream));
+      hipLaunchKernelGGL(k_rows_to_ref, dim3(n), dim3(64), 0, h->stream, rows.p, cnt.p, n, stride, tmp.p, maxneighs);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(neighbors, tmp.p, (size_t)n * maxneighs * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(mmd_stream_sync(h));
+    rows.release(); cnt.release(); tmp.release();
+    return 0;
+  }
+  MMD_TRY(mmd_ensure_rows(h));
   if(h->halfneigh && n) {
     DevArr<int> tmp, cnt;
     MMD_TRY(cnt.ensure((size_t)n + 1, false, h->stream));

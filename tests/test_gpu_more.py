@@ -197,10 +197,8 @@ def test_half_gn1_device_list_pairs_once(build):
         h.set_option("build", build)
     h.exchange(); h.borders(); h.neighbor_build()
     assert h.neighbor_info()["total"] * 2 == int(o.numneigh().sum())
-    nb, nn = h.neighbor_download()                    # the downloaded rows: owned partners on the smaller index, same total
+    nb, nn = h.neighbor_download()                    # the downloaded rows hold every pair once, too (tile builds: in the reference's partition)
     assert int(nn.sum()) * 2 == int(o.numneigh().sum())
-    nl = o.nlocal()
-    assert all((nb[i, :nn[i]] > i).all() for i in range(nl))
     eng, vir = h.force_compute(1)
     h.reverse_communicate()
     f = h.download(halfneigh=True)["f"][: o.nlocal()]

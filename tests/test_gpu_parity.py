@@ -213,6 +213,48 @@ def test_neighbor_build_half_gn0_equals_oracle():
     h.close(); o.close()
 
 
+def test_neighbor_build_half_gn1_download_equals_oracle():
+    """half lists WITH ghost newton: the device list partitions the pairs by position order, the reference by its half stencil of
+    bins and the same-bin rules (ref/neighbor.cpp:143-182, :424-441). What crosses the C-ABI is the reference's list:
+    mmd_neighbor_download rebuilds the rows with the reference's rule (k_build<3>) — counts and rows (as sets) equal the oracle's."""
+    o = Oracle(["-s", 6, "-n", 20, "--half_neigh", 1, "-gn", 1])
+    o.initial(); o.run()
+    h = handle_from_oracle(o)
+    h.neighbor_build()
+    assert h.neighbor_info()["total"] == int(o.numneigh().sum())
+    nb, nn = h.neighbor_download()
+    np.testing.assert_array_equal(nn, o.numneigh())
+    rows = o.neighbor_rows()
+    for i in range(len(nn)):
+        np.testing.assert_array_equal(np.sort(nb[i, :nn[i]]), np.sort(rows[i]))
+    h.close(); o.close()
+
+
+@pytest.mark.parametrize("state", ["s0pre", "s1pre"])
+def test_neighbor_half_gn1_download_equals_the_reference_arrays(state):
+    """the same against the unmodified reference's OWN arrays (tests/golden/arrays_lj_s4_half_gn1.npz, dumped by oracle/ref_dump.cpp
+    from the reference's Neighbor object): its owned + ghost atoms uploaded as they are, our build, our download — the reference's
+    rows as sets. s0pre is the perfect lattice (whole planes share z and y: the equality branches of ref/neighbor.cpp:155-157),
+    s1pre the system after the run."""
+    d = np.load(os.path.join(GOLD, "arrays_lj_s4_half_gn1.npz"))
+    nl, ng = int(d[state + ".nlocal"][0]), int(d[state + ".nghost"][0])
+    x = d[state + ".x"].reshape(-1, 3)[: nl + ng]
+    m = mm()
+    h = m.Handle()
+    h.set_box(d["prd"])
+    h.set_mass(1.0)
+    h.upload(x, np.zeros((nl, 3)), d[state + ".type"][: nl + ng], None, nlocal=nl)
+    h.neighbor_setup(d["nbin"], float(d["cutneigh"][0]), 1, 1, int(d["ntypes"][0]))
+    h.neighbor_build()
+    nb, nn = h.neighbor_download()
+    ref_nn = d[state + ".numneigh"]
+    ref_rows = np.split(d[state + ".neighbors"], np.cumsum(ref_nn)[:-1])          # (the fixture stores the rows back to back)
+    np.testing.assert_array_equal(nn, ref_nn)
+    for i in range(nl):
+        np.testing.assert_array_equal(np.sort(nb[i, :nn[i]]), np.sort(ref_rows[i]))
+    h.close()
+
+
 def test_neighbor_overflow_regrow():
     """rows longer than maxneighs trigger the reference's grow-and-retry protocol (ref/neighbor.cpp:186-208)"""
     o = Oracle(["-s", 5, "-n", 1, "--half_neigh", 0])
