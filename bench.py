@@ -219,7 +219,7 @@ def main():
     # per-rank view of the timed region (max over ranks of every phase, rank 0's own next to it): with these a SCALE line is
     # diagnosable from the record alone — where the time went, how often the host stalled the GPU, how many bytes the halos moved
     mine = {"phases_s": {k: tm[k] for k in ("total", "comm", "force", "neigh", "extra")}, "host_syncs": rs["host_syncs"],
-            "bytes_sent": rs["bytes_sent"], "nlocal": nlocal, "nghost": nghost}
+            "transport_syncs": rs["transport_syncs"], "bytes_sent": rs["bytes_sent"], "nlocal": nlocal, "nghost": nghost}
     per_rank = [mine]
     if dist is not None:
         per_rank = [None] * world
@@ -289,6 +289,8 @@ def main():
         "phases_s_max": {k: max(r["phases_s"][k] for r in per_rank) for k in ("total", "comm", "force", "neigh", "extra")},
         "host_syncs_per_step": max(r["host_syncs"] for r in per_rank) / max(args.steps, 1),
         "host_syncs_per_rebuild": max(r["host_syncs"] for r in per_rank) / max(args.steps // 20, 1),
+        # waits of the host-staged test transport (ranks sharing a GPU): staging of messages through host memory, absent with RCCL
+        "host_transport_syncs_per_step": max(r["transport_syncs"] for r in per_rank) / max(args.steps, 1),
         "halo_bytes_per_step": {"sum_over_ranks": sum(r["bytes_sent"] for r in per_rank) / max(args.steps, 1),
                                 "max_rank": max(r["bytes_sent"] for r in per_rank) / max(args.steps, 1)},
         "atoms_per_rank": {"owned_min": min(r["nlocal"] for r in per_rank), "owned_max": max(r["nlocal"] for r in per_rank),

@@ -157,8 +157,9 @@ int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int thermo_nsta
 int mmd_timers(mmd_handle* h, double out5[5], double* force_kernel_ms, int* force_kernel_launches);
 /* diagnostics of the last mmd_integrate_run on this rank: how often the host blocked on the GPU stream (count handshakes of
  * exchange / borders, list-size read-backs, thermo rows) and how many bytes it sent to OTHER ranks (halos, migrating atoms,
- * ghost lists, handshakes). bench.py reports both per step so that a multi-GPU line is diagnosable from the record alone. */
-int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* bytes_sent);
+ * ghost lists, handshakes). transport_syncs counts, apart from host_syncs, the waits of the host-staged TEST transport (staging a message
+ * through host memory; RCCL has none). bench.py reports them per step so that a multi-GPU line is diagnosable from the record alone. */
+int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* bytes_sent, long long* transport_syncs);
 /* time `nrep` launches of one hot kernel with hipEvents on the handle's compute stream.
  * which: 0 = force (current style, evflag=0), 1 = neighbor build, 2 = initial integrate, 3 = final integrate */
 int mmd_profile_kernel(mmd_handle* h, int which, int nrep, double* avg_ms);

@@ -75,7 +75,7 @@ def load_library(precision="dp"):
         "mmd_comm_reverse_communicate": [P], "mmd_comm_download_lists": [P, I, ip],
         "mmd_integrate_setup": [P, creal, creal, I, I], "mmd_integrate_initial": [P], "mmd_integrate_final": [P],
         "mmd_thermo_temperature": [P, dp], "mmd_integrate_mark_positions": [P], "mmd_integrate_max_move": [P, dp], "mmd_integrate_run": [P, I, I, I, P, P],
-        "mmd_timers": [P, dp, dp, ip], "mmd_run_stats": [P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "mmd_profile_kernel": [P, I, I, dp], "mmd_set_option": [P, C.c_char_p, I],
+        "mmd_timers": [P, dp, dp, ip], "mmd_run_stats": [P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "mmd_profile_kernel": [P, I, I, dp], "mmd_set_option": [P, C.c_char_p, I],
         "mmd_sync": [P],
         "mmd_input_read": [P, C.c_char_p], "mmd_create_box": [I, I, I, D, rp],
         "mmd_create_atoms": [I, I, I, D, rp, rp, I, rp, rp, ip, ip, ip],
@@ -361,9 +361,9 @@ class Handle:
         return {"total": t[0], "comm": t[1], "force": t[2], "neigh": t[3], "extra": t[4], "force_kernel_ms": ms.value, "force_launches": n.value}
 
     def run_stats(self):
-        a, b = C.c_longlong(), C.c_longlong()
-        self._chk(self.L.mmd_run_stats(self.h, C.byref(a), C.byref(b)))
-        return {"host_syncs": a.value, "bytes_sent": b.value}
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        self._chk(self.L.mmd_run_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"host_syncs": a.value, "bytes_sent": b.value, "transport_syncs": c.value}
 
     def profile_kernel(self, which, nrep=20):
         ms = C.c_double()

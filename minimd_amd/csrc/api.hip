@@ -61,7 +61,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->tile_cand.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
   for(auto& s : h->swaps) s.sendlist.release();
-  h->buf_send.release(); h->buf_recv.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->partials.release();
+  h->buf_send.release(); h->buf_recv.release(); h->est.release(); h->ex_list.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if(h->ev_x_ready) { (void)hipEventDestroy(h->ev_x_ready); (void)hipEventDestroy(h->ev_halo_done); }
   h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release(); h->tile_words.release(); h->tile_kcore.release(); h->xbuild.release(); h->core_words.release();
@@ -232,7 +232,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   for(int i = 0; i < 5; i++) h->timer[i] = 0;
   h->force_ms = 0; h->comm_ms = 0; h->force_launches = 0; h->force_calls = 0; h->ev_used = 0;
   h->force_ms_all = 0; h->force_launches_all = 0;
-  h->host_syncs = 0; h->halo_bytes = 0;
+  h->host_syncs = 0; h->halo_bytes = 0; h->transport_syncs = 0;
   // the step loop steers the kernels through transient flags of the handle; whatever way this function is left (an overflowing
   // build, a transport error), they are cleared, so a later call on the same handle never waits on a stale event or skips a halo
   struct TransientGuard {
@@ -418,11 +418,12 @@ extern "C" int mmd_timers(mmd_handle* h, double out5[5], double* force_kernel_ms
   return 0;
 }
 
-extern "C" int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* bytes_sent)
+extern "C" int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* bytes_sent, long long* transport_syncs)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
   if(host_syncs) *host_syncs = h->host_syncs;
   if(bytes_sent) *bytes_sent = h->halo_bytes;
+  if(transport_syncs) *transport_syncs = h->transport_syncs;
   return 0;
 }
 

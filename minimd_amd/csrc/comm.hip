@@ -198,11 +198,11 @@ int mmd_transport_sendrecv(mmd_handle* h, const void* dsend, size_t nsend, int d
     if(h->stage_send.size() < nsend + 8) h->stage_send.resize(nsend + 8);
     if(h->stage_recv.size() < nrecv + 8) h->stage_recv.resize(nrecv + 8);
     if(nsend) HIP_TRY(hipMemcpyAsync(h->stage_send.data(), dsend, nsend, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(mmd_stream_sync(h));
+    HIP_TRY(mmd_stream_sync_transport(h));
     const long long got = h->host_sr(h->host_ctx, h->stage_send.data(), (long long)nsend, dest, h->stage_recv.data(), (long long)nrecv, src);
     if(got != (long long)nrecv) { mmd_set_error("host transport: expected %zu bytes from rank %d, got %lld", nrecv, src, got); return -1; }
     if(nrecv) HIP_TRY(hipMemcpyAsync(drecv, h->stage_recv.data(), nrecv, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(mmd_stream_sync(h));
+    HIP_TRY(mmd_stream_sync_transport(h));
     return 0;
   }
   mmd_set_error("rank %d has a remote partner but no transport is attached (mmd_comm_init_rccl / mmd_comm_set_host_transport)", h->me);
@@ -543,12 +543,225 @@ __global__ __launch_bounds__(256) void k_unpack_exchange(const ExchRec* __restri
   tag[i] = r.tag;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Comm::exchange on several ranks without count handshakes: the leavers of a dimension travel in ONE message of fixed size — a
+// 64-byte header holding the count, then cap ExchRec records, cap = f(count at the previous re-neighboring), derived alike by the
+// sender (from what it sent) and the receiver (from what it got) — and every count (leavers, hole fillers, arrivals kept, the
+// running nlocal) stays in device memory (`est`) until ONE read-back at the end of the three dimensions. est layout (ints):
+//   [0] nlocal now  [1] overflow  [2] leavers of the current dimension  [4+d] leavers of dimension d  [10+2d+dir] records received
+// An overflow (a message or the atom arrays too small for what arrived: more than 4x the previous migration + 4096 atoms) cannot
+// be repaired after the fact — atoms would be lost — and is reported as an error naming the option that switches this path off.
+// ---------------------------------------------------------------------------------------------------
+#define EST_NLOCAL 0
+#define EST_OVF 1
+#define EST_NSEND 2
+#define EST_SEND_D 4
+#define EST_RECV 10
+#define EMSG_HEADER 64
+static inline int exch_msg_cap(int prev) { return 4 * prev + 4096; }
+static inline size_t exch_msg_bytes(int cap) { return ((size_t)EMSG_HEADER + (size_t)cap * sizeof(ExchRec) + 63) & ~(size_t)63; }
+
+__global__ __launch_bounds__(256) void k_ex_count(const real4* __restrict__ x, const int* __restrict__ est, int dim, real lo, real hi, int* __restrict__ cnt)
+{
+  __shared__ int lds[17];
+  const int n = est[EST_NLOCAL];
+  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) if(base + k < n) { const real4 p = x[base + k]; const real v = dim == 0 ? p.x : (dim == 1 ? p.y : p.z); c += (v < lo || v >= hi) ? 1 : 0; }
+  int tot;
+  block_incl_scan(c, lds, &tot);
+  if(threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+// ascending list of the leavers + Atom::pack_exchange (ref/atom.cpp:228-239) of each into the message
+__global__ __launch_bounds__(256) void k_ex_leavers(const real4* __restrict__ x, const real* __restrict__ v, const int* __restrict__ tag,
+                                                    int* __restrict__ est, int dim, real lo, real hi, const int* __restrict__ cnt,
+                                                    int* __restrict__ leavers, unsigned char* __restrict__ msg, int cap, int d_index, int grid_atoms)
+{
+  __shared__ int lds[17];
+  const int n = est[EST_NLOCAL];
+  const int off = block_prefix_total(cnt, blockIdx.x, lds);
+  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  bool fl[4];
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) {
+    fl[k] = false;
+    if(base + k < n) { const real4 p = x[base + k]; const real q = dim == 0 ? p.x : (dim == 1 ? p.y : p.z); fl[k] = q < lo || q >= hi; }
+    c += fl[k] ? 1 : 0;
+  }
+  int tot;
+  const int inc = block_incl_scan(c, lds, &tot);
+  int pos = off + inc - c;
+  ExchRec* __restrict__ rec = (ExchRec*)(msg + EMSG_HEADER);
+#pragma unroll
+  for(int k = 0; k < 4; k++) {
+    if(fl[k]) {
+      if(pos < cap) {
+        const int i = base + k;
+        leavers[pos] = i;
+        const real4 p = x[i];
+        ExchRec r;
+        r.x = p.x; r.y = p.y; r.z = p.z; r.w = p.w;
+        r.vx = v[3 * (size_t)i + 0]; r.vy = v[3 * (size_t)i + 1]; r.vz = v[3 * (size_t)i + 2];
+        r.tag = tag[i]; r.pad = 0;
+        rec[pos] = r;
+      }
+      pos++;
+    }
+  }
+  if(blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const int nsend = off + tot;
+    est[EST_NSEND] = nsend; est[EST_SEND_D + d_index] = nsend;
+    *(int*)msg = nsend;
+    if(nsend > cap || n > grid_atoms) est[EST_OVF] = 1;       // (more leavers than the message holds / more atoms than the launch covers)
+  }
+}
+// the k-th hole (leaver below the new end) takes the k-th stayer of the tail: Atom::copy (ref/comm.cpp:491-509). One workgroup:
+// the tail is as long as the leaver list (a few thousand atoms)
+__global__ __launch_bounds__(1024) void k_ex_fill(real4* __restrict__ x, real* __restrict__ v, int* __restrict__ type, int* __restrict__ tag,
+                                                  int* __restrict__ est, int dim, real lo, real hi, const int* __restrict__ leavers, int cap)
+{
+  __shared__ int lds[17];
+  const int n = est[EST_NLOCAL], nsend = min(est[EST_NSEND], cap);
+  const int t0 = n - nsend;
+  int done = 0;                                   // stayers of the tail seen so far (uniform)
+  for(int b = 0; b < nsend; b += 1024) {
+    const int i = t0 + b + (int)threadIdx.x;
+    bool stay = false;
+    real4 p = real4{0, 0, 0, 0};
+    if(b + (int)threadIdx.x < nsend) { p = x[i]; const real q = dim == 0 ? p.x : (dim == 1 ? p.y : p.z); stay = !(q < lo || q >= hi); }
+    int tot;
+    const int inc = block_incl_scan(stay ? 1 : 0, lds, &tot);
+    if(stay) {
+      const int dst = leavers[done + inc - 1];    // (ascending leavers: the holes below the new end are its first entries)
+      x[dst] = p;
+      v[3 * (size_t)dst + 0] = v[3 * (size_t)i + 0]; v[3 * (size_t)dst + 1] = v[3 * (size_t)i + 1]; v[3 * (size_t)dst + 2] = v[3 * (size_t)i + 2];
+      type[dst] = type[i];
+      tag[dst] = tag[i];
+    }
+    done += tot;
+    __syncthreads();
+  }
+  if(threadIdx.x == 0) est[EST_NLOCAL] = t0;
+}
+// arrivals that fall inside my box in this dimension are appended in message order (ref/comm.cpp:566-571, Atom::unpack_exchange
+// ref/atom.cpp:241-254); message 0 first, then message 1 (grids wider than 2 receive from both sides). One workgroup.
+__global__ __launch_bounds__(1024) void k_ex_arrive(real4* __restrict__ x, real* __restrict__ v, int* __restrict__ type, int* __restrict__ tag,
+                                                    int* __restrict__ est, int dim, real lo, real hi, const unsigned char* __restrict__ m0, int cap0,
+                                                    const unsigned char* __restrict__ m1, int cap1, int cap_atoms, int d_index)
+{
+  __shared__ int lds[17];
+  int n = est[EST_NLOCAL];
+  for(int q = 0; q < 2; q++) {
+    const unsigned char* __restrict__ m = q ? m1 : m0;
+    if(m == nullptr) continue;
+    const int cap = q ? cap1 : cap0, raw = *(const int*)m, cnt = min(max(raw, 0), cap);
+    const ExchRec* __restrict__ rec = (const ExchRec*)(m + EMSG_HEADER);
+    for(int b = 0; b < cnt; b += 1024) {
+      const int k = b + (int)threadIdx.x;
+      bool keep = false;
+      ExchRec r;
+      if(k < cnt) { r = rec[k]; const real c = dim == 0 ? r.x : (dim == 1 ? r.y : r.z); keep = c >= lo && c < hi; }
+      int tot;
+      const int inc = block_incl_scan(keep ? 1 : 0, lds, &tot);
+      if(keep) {
+        const int i = n + inc - 1;
+        if(i < cap_atoms) {
+          x[i] = real4{r.x, r.y, r.z, r.w};
+          v[3 * (size_t)i + 0] = r.vx; v[3 * (size_t)i + 1] = r.vy; v[3 * (size_t)i + 2] = r.vz;
+          type[i] = (int)r.w;
+          tag[i] = r.tag;
+        }
+      }
+      n += tot;
+      __syncthreads();
+    }
+    if(threadIdx.x == 0) { est[EST_RECV + 2 * d_index + q] = raw; if(raw > cap) est[EST_OVF] = 1; }
+  }
+  if(threadIdx.x == 0) { if(n > cap_atoms) est[EST_OVF] = 1; est[EST_NLOCAL] = min(n, cap_atoms); }
+}
+__global__ void k_ex_init(int* __restrict__ est, int nlocal)
+{
+  if(threadIdx.x < 32) est[threadIdx.x] = threadIdx.x == EST_NLOCAL ? nlocal : 0;
+}
+
+// returns 1 = done, 0 = not applicable (the caller runs the handshake path), < 0 error
+static int exchange_multi_fast(mmd_handle* h)
+{
+  if(h->nprocs == 1 || h->opt_safe_exchange || !h->opt_async_counts || !h->ex_prev_valid || !(h->rccl || h->host_sr)) return 0;
+  int cap_s[3] = {0, 0, 0}, cap_r[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  int arrivals_max = 0;
+  for(int d = 0; d < 3; d++) {
+    if(h->procgrid[d] == 1) continue;
+    cap_s[d] = exch_msg_cap(h->ex_prev_send[d]);
+    cap_r[d][0] = exch_msg_cap(h->ex_prev_recv[d][0]);
+    cap_r[d][1] = h->procgrid[d] > 2 ? exch_msg_cap(h->ex_prev_recv[d][1]) : 0;
+    arrivals_max += cap_r[d][0] + cap_r[d][1];
+  }
+  const int nl0 = h->nlocal;
+  MMD_TRY(mmd_ensure_atoms(h, nl0 + arrivals_max + 1, true));
+  MMD_TRY(h->est.ensure(64, false, h->stream));
+  hipLaunchKernelGGL(k_ex_init, dim3(1), dim3(64), 0, h->stream, h->est.p, nl0);
+  int bound = nl0;                                           // host-side bound of nlocal (grids, capacities)
+  for(int d = 0; d < 3; d++) {
+    if(h->procgrid[d] == 1) continue;
+    const real lo = h->lo[d], hi = h->hi[d];
+    const int nt = div_up(std::max(bound, 1), CP_TILE);
+    const size_t bs = exch_msg_bytes(cap_s[d]), br0 = exch_msg_bytes(cap_r[d][0]), br1 = cap_r[d][1] ? exch_msg_bytes(cap_r[d][1]) : 0;
+    MMD_TRY(h->flag_tmp.ensure((size_t)nt + 8, false, h->stream));
+    MMD_TRY(h->ex_list.ensure((size_t)cap_s[d] + 8, false, h->stream));
+    MMD_TRY(h->buf_send.ensure(bs / sizeof(real) + 16, false, h->stream));
+    MMD_TRY(h->buf_recv.ensure((br0 + br1) / sizeof(real) + 16, false, h->stream));
+    unsigned char* smsg = (unsigned char*)h->buf_send.p;
+    unsigned char* rmsg0 = (unsigned char*)h->buf_recv.p;
+    unsigned char* rmsg1 = br1 ? rmsg0 + br0 : nullptr;
+    hipLaunchKernelGGL(k_ex_count, dim3(nt), dim3(256), 0, h->stream, h->x.p, h->est.p, d, lo, hi, h->flag_tmp.p);
+    hipLaunchKernelGGL(k_ex_leavers, dim3(nt), dim3(256), 0, h->stream, h->x.p, h->v.p, h->tag.p, h->est.p, d, lo, hi, h->flag_tmp.p, h->ex_list.p, smsg,
+                       cap_s[d], d, nt * CP_TILE);
+    hipLaunchKernelGGL(k_ex_fill, dim3(1), dim3(1024), 0, h->stream, h->x.p, h->v.p, h->type.p, h->tag.p, h->est.p, d, lo, hi, h->ex_list.p, cap_s[d]);
+    HIP_TRY(hipGetLastError());
+    if(br1) {
+      const void* ds[2] = {smsg, smsg};
+      void* dr[2] = {rmsg0, rmsg1};
+      const size_t nsb[2] = {bs, bs}, nrb[2] = {br0, br1};
+      const int dest[2] = {h->procneigh[d][0], h->procneigh[d][1]}, src[2] = {h->procneigh[d][1], h->procneigh[d][0]};
+      MMD_TRY(mmd_transport_sendrecv_pair(h, ds, nsb, dest, dr, nrb, src));
+    } else
+      MMD_TRY(mmd_transport_sendrecv(h, smsg, bs, h->procneigh[d][0], rmsg0, br0, h->procneigh[d][1]));
+    hipLaunchKernelGGL(k_ex_arrive, dim3(1), dim3(1024), 0, h->stream, h->x.p, h->v.p, h->type.p, h->tag.p, h->est.p, d, lo, hi,
+                       (const unsigned char*)rmsg0, cap_r[d][0], (const unsigned char*)rmsg1, cap_r[d][1], h->nmax, d);
+    HIP_TRY(hipGetLastError());
+    bound += cap_r[d][0] + cap_r[d][1];
+  }
+  HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->est.p, 32 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(mmd_stream_sync(h));
+  const int* e = h->h_flags_big;
+  if(e[EST_OVF]) {
+    mmd_set_error("Comm::exchange: more atoms migrated than the fixed-size messages of the handshake-free path hold (4x the previous "
+                  "re-neighboring's count + 4096); run with mmd_set_option(h, \"async_counts\", 0)");
+    return -1;
+  }
+  h->nlocal = e[EST_NLOCAL];
+  for(int d = 0; d < 3; d++) {
+    if(h->procgrid[d] == 1) continue;
+    h->ex_prev_send[d] = e[EST_SEND_D + d];
+    h->ex_prev_recv[d][0] = e[EST_RECV + 2 * d];
+    h->ex_prev_recv[d][1] = e[EST_RECV + 2 * d + 1];
+  }
+  return 1;
+}
+
 extern "C" int mmd_comm_exchange(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
   MMD_TRY(mmd_atom_pbc(h));
   h->nghost = 0;                       // ghost slots are reused by arrivals; borders() rebuilds them next
+  {
+    const int rc = exchange_multi_fast(h);
+    if(rc != 0) return rc < 0 ? rc : 0;
+  }
   static_assert(sizeof(ExchRec) % sizeof(real) == 0, "ExchRec must be a whole number of reals");
   const size_t rec_reals = sizeof(ExchRec) / sizeof(real);
   DevArr<int> leavers, fillers, keep;
@@ -617,6 +830,7 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
                                      (size_t)nrecv1 * sizeof(ExchRec), h->procneigh[d][1]));
     }
     const int nrecv = nrecv1 + nrecv2;
+    h->ex_prev_send[d] = nsend; h->ex_prev_recv[d][0] = nrecv1; h->ex_prev_recv[d][1] = nrecv2;      // (size the next exchange's fixed messages)
     int nkeep = 0;
     MMD_TRY(compact(h, ArrivePred{(const ExchRec*)h->buf_recv.p, d, lo, hi}, 0, nrecv, keep, &nkeep));
     if(nkeep) {
@@ -629,6 +843,7 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
   }
   if(h->nprocs > 1) HIP_TRY(mmd_stream_sync(h));     // (the scratch arrays below are only allocated when a dimension is split)
   leavers.release(); fillers.release(); keep.release();
+  if(!h->opt_safe_exchange) h->ex_prev_valid = true;
   return 0;
 }
 
@@ -698,7 +913,18 @@ __global__ __launch_bounds__(256) void k_ghost_types(const real4* __restrict__ x
 #define BST_NB 0
 #define BST_OVF 1
 #define BST_SEND 4
+#define BST_RECV 12
 #define BST_GHOSTS 30
+// Several ranks: a dimension whose partners are other ranks runs the same count / scatter pair, but the selection goes into one
+// MESSAGE per swap — a 64-byte header holding the count, then cap {x+shift, type} records, then cap image codes — of a FIXED size
+// cap = f(count of this swap at the previous re-neighboring) that both sides derive alike (the sender from its previous sendnum,
+// the receiver from its previous recvnum: the same number), so no count handshake and no host synchronisation is needed to post
+// the receive; k_border_unpack appends min(count, cap) ghosts behind the running ghost count in bst and records recvnum
+// ([BST_RECV+s]). A count beyond its cap raises the overflow flag, which is max-reduced over the ranks before anybody reads it:
+// then every rank redoes the borders swap by swap (borders_general).
+#define BMSG_HEADER 64
+static inline int border_msg_cap(int prev) { return prev + prev / 16 + 2048; }
+static inline size_t border_msg_bytes(int cap) { return ((size_t)BMSG_HEADER + (size_t)cap * (sizeof(real4) + sizeof(int)) + 63) & ~(size_t)63; }
 struct SlabSet { real lo[6], hi[6]; int dim[6]; int n; };
 
 __device__ __forceinline__ bool in_any_slab(const real4 p, const SlabSet& S)
@@ -706,15 +932,6 @@ __device__ __forceinline__ bool in_any_slab(const real4 p, const SlabSet& S)
   bool in = false;
   for(int s = 0; s < S.n; s++) { const real c = S.dim[s] == 0 ? p.x : (S.dim[s] == 1 ? p.y : p.z); in = in || (c >= S.lo[s] && c <= S.hi[s]); }
   return in;
-}
-// sum of cnt[0..upto) by the whole workgroup (256 threads); every thread gets the result
-__device__ __forceinline__ int block_prefix_total(const int* __restrict__ cnt, int upto, int* lds /* >= 17 */)
-{
-  int v = 0;
-  for(int t = threadIdx.x; t < upto; t += 256) v += cnt[t];
-  int tot;
-  block_incl_scan(v, lds, &tot);
-  return tot;
 }
 
 __global__ __launch_bounds__(256) void k_bnd_count(const real4* __restrict__ x, int nlocal, SlabSet S, int* __restrict__ cnt, int* __restrict__ bst)
@@ -730,7 +947,7 @@ __global__ __launch_bounds__(256) void k_bnd_count(const real4* __restrict__ x, 
   if(threadIdx.x == 0) cnt[blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(256) void k_bnd_scatter(const real4* __restrict__ x, int nlocal, SlabSet S, const int* __restrict__ cnt,
-                                                     int* __restrict__ bnd, int* __restrict__ bst)
+                                                     int* __restrict__ bnd, int* __restrict__ bst, int est_nb)
 {
   __shared__ int lds[17];
   const int off = block_prefix_total(cnt, blockIdx.x, lds);
@@ -744,11 +961,15 @@ __global__ __launch_bounds__(256) void k_bnd_scatter(const real4* __restrict__ x
   int pos = off + inc - c;
 #pragma unroll
   for(int k = 0; k < 4; k++) if(fl[k]) bnd[pos++] = base + k;
-  if(blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bst[BST_NB] = off + tot;
+  if(blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    bst[BST_NB] = off + tot;
+    if(off + tot > est_nb) bst[BST_OVF] = 1;        // (the swap kernels' grids were sized for est_nb boundary atoms)
+  }
 }
 // The two swaps of a dimension (sw0 towards -1, sw0+1 towards +1) select from the same atoms — owned boundary atoms and the
 // ghosts of the EARLIER dimensions — so one launch serves both (blockIdx.y = which of the two).
-struct SwapPair { real lo[2], hi[2], sx[2], sy[2], sz[2]; int pbc_any[2], px[2], py[2], pz[2]; int cap_list[2]; int* sendlist[2]; };
+struct SwapPair { real lo[2], hi[2], sx[2], sy[2], sz[2]; int pbc_any[2], px[2], py[2], pz[2]; int cap_list[2]; int* sendlist[2];
+                  unsigned char* msg[2]; int cap_msg[2]; };      // (remote partners: the outgoing messages and their record capacity)
 
 __global__ __launch_bounds__(256) void k_swap_count(const real4* __restrict__ x, const int* __restrict__ bnd, const int* __restrict__ bst,
                                                     int nlocal, int sw0, int dim, SwapPair P, int* __restrict__ cnt, int ncnt)
@@ -772,6 +993,7 @@ __global__ __launch_bounds__(256) void k_swap_count(const real4* __restrict__ x,
   block_incl_scan(c, lds, &tot);
   if(threadIdx.x == 0) cnt[y * ncnt + blockIdx.x] = tot;
 }
+template <bool REMOTE>
 __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, const int* __restrict__ bnd, int* __restrict__ bst, int nlocal,
                                                       int sw0, int dim, SwapPair P, const int* __restrict__ cnt, int ncnt,
                                                       int cap_atoms, int cap_ghost, int* __restrict__ ghost_image, int* __restrict__ ghost_root,
@@ -785,8 +1007,10 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
   if((long long)blockIdx.x * CP_TILE >= n && !last) return;
   // ghosts in front of this swap's: those of the earlier dimensions, plus ALL of the pair's first swap for the second
   int nghost = bst[BST_GHOSTS + sw0];
-  if(y == 1) nghost += block_prefix_total(cnt, ncnt, lds);
+  if(!REMOTE && y == 1) nghost += block_prefix_total(cnt, ncnt, lds);
   const int nall = nlocal + nghost;
+  real4* __restrict__ m_rec = REMOTE ? (real4*)(P.msg[y] + BMSG_HEADER) : nullptr;
+  int* __restrict__ m_img = REMOTE ? (int*)(P.msg[y] + BMSG_HEADER + (size_t)P.cap_msg[y] * sizeof(real4)) : nullptr;
   const int off = block_prefix_total(cnt + y * ncnt, blockIdx.x, lds);
   const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
   bool fl[4];
@@ -813,6 +1037,16 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
 #pragma unroll
   for(int k = 0; k < 4; k++) {
     if(fl[k]) {
+      if(REMOTE) {                              // Atom::pack_border (ref/atom.cpp:197-214) into the message of this swap
+        if(pos < P.cap_list[y] && pos < P.cap_msg[y]) {
+          const int i = idx[k];
+          real4 p = pp[k];
+          if(P.pbc_any[y]) { p.x += P.sx[y]; p.y += P.sy[y]; p.z += P.sz[y]; }
+          sendlist[pos] = i;
+          m_rec[pos] = p;
+          m_img[pos] = image_add(i < nlocal ? IMAGE_NONE : ghost_image[i - nlocal], P.px[y], P.py[y], P.pz[y]);
+        } else ovf = true;
+      } else
       if(pos < P.cap_list[y] && nall + pos < cap_atoms && nghost + pos < cap_ghost) {
         const int i = idx[k];
         real4 p = pp[k];
@@ -830,7 +1064,41 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
   if(ovf) bst[BST_OVF] = 1;
   if(last) {                                  // (its prefix covers every other tile: off + tot is the swap's total)
     if((long long)gridDim.x * CP_TILE < n) bst[BST_OVF] = 1;        // the launch was sized for fewer candidates than there are
-    if(threadIdx.x == 0) { bst[BST_SEND + sw0 + y] = off + tot; if(y == 1) bst[BST_GHOSTS + sw0 + 2] = nghost + off + tot; }
+    if(threadIdx.x == 0) {
+      bst[BST_SEND + sw0 + y] = off + tot;
+      if(REMOTE) *(int*)P.msg[y] = off + tot;                 // header of the message: how many records follow
+      else { bst[BST_RECV + sw0 + y] = off + tot; if(y == 1) bst[BST_GHOSTS + sw0 + 2] = nghost + off + tot; }
+    }
+  }
+}
+
+// Atom::unpack_border (ref/atom.cpp:216-226) for the two messages a rank receives in one dimension: ghosts of swap sw0 first, those
+// of swap sw0+1 behind them (the order the swap-by-swap path appends them in)
+__global__ __launch_bounds__(256) void k_border_unpack(real4* __restrict__ x, int* __restrict__ bst, int nlocal, int sw0,
+                                                       const unsigned char* __restrict__ rmsg0, const unsigned char* __restrict__ rmsg1,
+                                                       int cap0, int cap1, int cap_atoms, int cap_ghost, int* __restrict__ ghost_image,
+                                                       int* __restrict__ type)
+{
+  const int y = blockIdx.y;
+  const int raw0 = *(const int*)rmsg0, raw1 = *(const int*)rmsg1;
+  const int c0 = min(max(raw0, 0), cap0), c1 = min(max(raw1, 0), cap1);
+  const int base = bst[BST_GHOSTS + sw0] + (y ? c0 : 0), cnt = y ? c1 : c0, cap = y ? cap1 : cap0;
+  const unsigned char* __restrict__ m = y ? rmsg1 : rmsg0;
+  const real4* __restrict__ rec = (const real4*)(m + BMSG_HEADER);
+  const int* __restrict__ img = (const int*)(m + BMSG_HEADER + (size_t)cap * sizeof(real4));
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k < cnt) {
+    if(nlocal + base + k < cap_atoms && base + k < cap_ghost) {
+      const real4 p = rec[k];
+      x[nlocal + base + k] = p;
+      ghost_image[base + k] = img[k];
+      type[nlocal + base + k] = (int)p.w;
+    } else bst[BST_OVF] = 1;
+  }
+  if(blockIdx.x == 0 && threadIdx.x == 0) {
+    if((y ? raw1 : raw0) > cap) bst[BST_OVF] = 1;             // the sender selected more atoms than the message holds
+    bst[BST_RECV + sw0 + y] = cnt;
+    if(y == 1) bst[BST_GHOSTS + sw0 + 2] = bst[BST_GHOSTS + sw0] + c0 + c1;
   }
 }
 
@@ -839,8 +1107,16 @@ static int borders_fast_finish(mmd_handle* h);
 
 static int borders_one_rank_fast(mmd_handle* h, bool defer)
 {
-  if(!h->opt_borders_fast || h->nprocs != 1 || h->opt_force_transport || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0 || h->nlocal <= 4096) return 0;
-  for(auto& s : h->swaps) if(s.sendproc != h->me) return 0;
+  if(!h->opt_borders_fast || h->opt_force_transport || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0) return 0;
+  if(h->nprocs == 1 && h->nlocal <= 4096) return 0;
+  bool any_remote = false;
+  for(int q = 0; q < 6; q += 2) {
+    const bool r0 = h->swaps[q].sendproc != h->me, r1 = h->swaps[q + 1].sendproc != h->me;
+    if(r0 != r1) return 0;                      // (a dimension is either all-self or all-remote)
+    any_remote = any_remote || r0;
+  }
+  if(any_remote && !(h->rccl || h->host_sr)) return 0;
+  if(any_remote && !h->opt_async_counts) return 0;
   const int nlocal = h->nlocal;
   // (opt_borders_est: per cent of the previous counts the arrays are sized for; tests shrink it to force the overflow fallback)
   const int est_ghost = h->opt_borders_est >= 100 ? (int)((long long)h->prev_nghost * h->opt_borders_est / 100) + 4096 : (int)((long long)h->prev_nghost * h->opt_borders_est / 100);
@@ -865,22 +1141,61 @@ static int borders_one_rank_fast(mmd_handle* h, bool defer)
   S.n = 6;
   for(int q = 0; q < 6; q++) { S.lo[q] = h->swaps[q].slablo; S.hi[q] = h->swaps[q].slabhi; S.dim[q] = h->swaps[q].dim; }
   hipLaunchKernelGGL(k_bnd_count, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bstate.p);
-  hipLaunchKernelGGL(k_bnd_scatter, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bnd_list.p, h->bstate.p);
+  hipLaunchKernelGGL(k_bnd_scatter, dim3(nt_own > 0 ? nt_own : 1), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bnd_list.p, h->bstate.p, est_nb);
   for(int q = 0; q < 6; q += 2) {
+    const bool remote = h->swaps[q].sendproc != h->me;
     SwapPair P;
+    int cap_s[2] = {0, 0}, cap_r[2] = {0, 0};
+    size_t off_s[2] = {0, 0}, off_r[2] = {0, 0}, bytes_s[2] = {0, 0}, bytes_r[2] = {0, 0};
+    if(remote) {
+      // fixed-size messages: both sides derive the capacity of a swap's message from its count at the previous re-neighboring
+      for(int y = 0; y < 2; y++) {
+        cap_s[y] = border_msg_cap(h->swaps[q + y].sendnum); cap_r[y] = border_msg_cap(h->swaps[q + y].recvnum);
+        bytes_s[y] = border_msg_bytes(cap_s[y]); bytes_r[y] = border_msg_bytes(cap_r[y]);
+      }
+      off_s[1] = bytes_s[0]; off_r[1] = bytes_r[0];
+      MMD_TRY(h->buf_send.ensure((bytes_s[0] + bytes_s[1]) / sizeof(real) + 16, false, h->stream));
+      MMD_TRY(h->buf_recv.ensure((bytes_r[0] + bytes_r[1]) / sizeof(real) + 16, false, h->stream));
+    }
     for(int y = 0; y < 2; y++) {
       Swap& sw = h->swaps[q + y];
       P.lo[y] = sw.slablo; P.hi[y] = sw.slabhi;
       P.sx[y] = sw.pbc[0] * h->prd[0]; P.sy[y] = sw.pbc[1] * h->prd[1]; P.sz[y] = sw.pbc[2] * h->prd[2];
       P.pbc_any[y] = sw.pbc_any; P.px[y] = sw.pbc[0]; P.py[y] = sw.pbc[1]; P.pz[y] = sw.pbc[2];
       P.cap_list[y] = cap_list[q + y]; P.sendlist[y] = sw.sendlist.p;
+      P.msg[y] = remote ? (unsigned char*)h->buf_send.p + off_s[y] : nullptr; P.cap_msg[y] = cap_s[y];
     }
     const int dim = h->swaps[q].dim;
     hipLaunchKernelGGL(k_swap_count, dim3(nt_sw, 2), dim3(256), 0, h->stream, h->x.p, h->bnd_list.p, h->bstate.p, nlocal, q, dim, P, h->flag_tmp.p, nt_sw);
-    hipLaunchKernelGGL(k_swap_scatter, dim3(nt_sw, 2), dim3(256), 0, h->stream, h->x.p, h->bnd_list.p, h->bstate.p, nlocal, q, dim, P,
+    if(!remote) {
+      hipLaunchKernelGGL(k_swap_scatter<false>, dim3(nt_sw, 2), dim3(256), 0, h->stream, h->x.p, h->bnd_list.p, h->bstate.p, nlocal, q, dim, P,
+                         h->flag_tmp.p, nt_sw, cap_atoms, cap_ghost, h->ghost_image.p, h->ghost_root.p, h->type.p);
+      continue;
+    }
+    hipLaunchKernelGGL(k_swap_scatter<true>, dim3(nt_sw, 2), dim3(256), 0, h->stream, h->x.p, h->bnd_list.p, h->bstate.p, nlocal, q, dim, P,
                        h->flag_tmp.p, nt_sw, cap_atoms, cap_ghost, h->ghost_image.p, h->ghost_root.p, h->type.p);
+    HIP_TRY(hipGetLastError());
+    const void* dsend[2] = {P.msg[0], P.msg[1]};
+    void* drecv[2] = {(unsigned char*)h->buf_recv.p + off_r[0], (unsigned char*)h->buf_recv.p + off_r[1]};
+    const int dest[2] = {h->swaps[q].sendproc, h->swaps[q + 1].sendproc}, src[2] = {h->swaps[q].recvproc, h->swaps[q + 1].recvproc};
+    MMD_TRY(mmd_transport_sendrecv_pair(h, dsend, bytes_s, dest, drecv, bytes_r, src));
+    hipLaunchKernelGGL(k_border_unpack, dim3(div_up(std::max(std::max(cap_r[0], cap_r[1]), 1), 256), 2), dim3(256), 0, h->stream, h->x.p, h->bstate.p, nlocal, q,
+                       (const unsigned char*)drecv[0], (const unsigned char*)drecv[1], cap_r[0], cap_r[1], cap_atoms, cap_ghost, h->ghost_image.p, h->type.p);
   }
   HIP_TRY(hipGetLastError());
+  if(any_remote) {
+    // the overflow flag is made global before anybody reads it: either every rank keeps these ghosts or every rank redoes the
+    // borders swap by swap (the general path is a sequence of matched sends and receives)
+    if(h->rccl) NCCL_TRY(ncclAllReduce(h->bstate.p + BST_OVF, h->bstate.p + BST_OVF, 1, ncclInt, ncclMax, (ncclComm_t)h->rccl, h->stream));
+    else {
+      HIP_TRY(hipMemcpyAsync(h->h_flags + 14, h->bstate.p + BST_OVF, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(mmd_stream_sync_transport(h));
+      double v = h->h_flags[14] ? 1.0 : 0.0;
+      MMD_TRY(mmd_transport_allreduce(h, &v, 1));
+      h->h_flags[14] = v > 0.0 ? 1 : 0;
+      HIP_TRY(hipMemcpyAsync(h->bstate.p + BST_OVF, h->h_flags + 14, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+  }
   static_assert(BST_GHOSTS + 6 < 40, "bst read-back window");
   h->bf_est_nb = est_nb;
   if(defer) {
@@ -904,17 +1219,20 @@ static int borders_fast_finish(mmd_handle* h)
   const int* hf = h->h_flags_big;
   if(hf[BST_OVF] || hf[BST_NB] > h->bf_est_nb) return 0;        // estimates too small: general path (it grows the arrays)
   int nall = nlocal;
+  bool all_self = true;
   for(int q = 0; q < 6; q++) {
     Swap& s = h->swaps[q];
-    s.sendnum = s.recvnum = hf[BST_SEND + q];
+    s.sendnum = hf[BST_SEND + q];
+    s.recvnum = hf[BST_RECV + q];
     s.firstrecv = nall;
-    nall += s.sendnum;
+    nall += s.recvnum;
+    all_self = all_self && s.sendproc == h->me;
   }
   h->nghost = hf[BST_GHOSTS + 6];
   if(nall != nlocal + h->nghost) { mmd_set_error("borders fast path: inconsistent ghost counts"); return -1; }
   h->prev_nb = hf[BST_NB];
   h->prev_nghost = h->nghost;
-  h->ghost_chain_ok = true;
+  h->ghost_chain_ok = all_self;
   return 1;
 }
 
@@ -975,7 +1293,7 @@ static int borders_general(mmd_handle* h)
   // one pass over the owned atoms keeps only those inside some send slab (~12% at -s 80); the per-swap
   // selections then scan that short list + the ghosts instead of every owned atom six times
   int nb = -1;
-  if(h->swaps.size() <= 6 && h->nlocal > 4096) {
+  if(h->swaps.size() <= 6 && (h->nlocal > 4096 || h->nprocs > 1)) {
     AnySlabPred ap;
     ap.x = h->x.p; ap.n = (int)h->swaps.size();
     for(int q = 0; q < ap.n; q++) { ap.lo[q] = h->swaps[q].slablo; ap.hi[q] = h->swaps[q].slabhi; ap.dim[q] = h->swaps[q].dim; }

@@ -142,6 +142,16 @@ __device__ __forceinline__ int block_incl_scan(int v, int* lds /* >= 17 ints */,
   return s;
 }
 
+// sum of cnt[0..upto) by the whole workgroup (256 threads); every thread gets the result
+__device__ __forceinline__ int block_prefix_total(const int* __restrict__ cnt, int upto, int* lds /* >= 17 */)
+{
+  int v = 0;
+  for(int t = threadIdx.x; t < upto; t += 256) v += cnt[t];
+  int tot;
+  block_incl_scan(v, lds, &tot);
+  return tot;
+}
+
 // XCD-aware work order. Workgroup b of a launch is observed to run on XCD b % 8 (MI355X_MICROARCH.md, "for speed
 // only"); mapping b -> (b % 8) * ceil(n/8) + b / 8 hands every XCD one CONTIGUOUS eighth of a spatially sorted
 // work list, so the atoms its workgroups gather stay in that XCD's private 4 MiB L2 instead of being streamed by

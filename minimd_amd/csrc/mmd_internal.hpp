@@ -215,6 +215,9 @@ struct mmd_handle {
   void* host_ctx = nullptr;
   std::vector<char> stage_send, stage_recv;
   DevArr<int> flag_tmp, bnd_list, bstate;
+  DevArr<int> est, ex_list;            // handshake-free Comm::exchange (comm.hip): device-resident counts / leaver list
+  int ex_prev_send[3] = {0, 0, 0}, ex_prev_recv[3][2] = {{0, 0}, {0, 0}, {0, 0}};     // migration counts of the last exchange (size the fixed messages)
+  bool ex_prev_valid = false;
   bool big_bins = false;       // some bin holds more than NB_BIGBIN atoms: binning runs the grid-wide rank sort too
   bool in_reneighbor = false;  // inside Integrate::run's re-neighboring: Comm::borders follows Atom::sort, ghosts need not ride along
   // one-rank LJ full-list steps: the tile kernel stages ghosts from their owners, no per-step Comm::communicate. 1 = where it
@@ -264,6 +267,7 @@ struct mmd_handle {
   // diagnostics of the last Integrate::run (mmd_run_stats): host synchronisations (hipStreamSynchronize / blocking copies issued by
   // the step loop and everything below it) and bytes this rank sent to OTHER ranks (halo, exchange, borders payloads + handshakes)
   long long host_syncs = 0, halo_bytes = 0;
+  long long transport_syncs = 0;       // waits that belong to the host-staged TEST transport (device<->host staging of a message), not to the algorithm
   bool time_force_events = true;
   // ---- options
   int opt_exact_div = 0;
@@ -299,5 +303,7 @@ double mmd_wall();
 
 // every blocking wait on the handle's stream goes through here, so that a run can report how often the host stalled the GPU
 static inline hipError_t mmd_stream_sync(mmd_handle* h) { h->host_syncs++; return hipStreamSynchronize(h->stream); }
+// (waits of the host-staged test transport — staging a message through host memory — are counted apart: RCCL has none of them)
+static inline hipError_t mmd_stream_sync_transport(mmd_handle* h) { h->transport_syncs++; return hipStreamSynchronize(h->stream); }
 
 static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }

@@ -1111,6 +1111,51 @@ __global__ __launch_bounds__(1024) void k_tile_reduce(const int* __restrict__ ti
   }
 }
 
+// interior tiles (no ghost among their candidates: they can run while this step's halo is in flight) first, boundary tiles behind
+// them, each group in ascending order: count / scatter pair over blocks of 1024 tiles whose prefix every scatter block sums itself
+// (no scan launch). The number of interior tiles goes to flags[13] and returns to the host with the build's other results.
+__global__ __launch_bounds__(256) void k_tile_order_count(const int* __restrict__ tile_ghost, int ntiles, const int* __restrict__ ntiles_dev,
+                                                          int* __restrict__ cnt)
+{
+  __shared__ int lds[17];
+  if(ntiles_dev) ntiles = min(ntiles, *ntiles_dev);
+  const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) if(base + k < ntiles) c += tile_ghost[base + k] == 0 ? 1 : 0;
+  int tot;
+  block_incl_scan(c, lds, &tot);
+  if(threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_tile_order_scatter(const int* __restrict__ tile_ghost, int ntiles, const int* __restrict__ ntiles_dev,
+                                                            const int* __restrict__ cnt, int* __restrict__ order, int* __restrict__ flags)
+{
+  __shared__ int lds[17];
+  if(ntiles_dev) ntiles = min(ntiles, *ntiles_dev);
+  int before = 0, total = 0;
+  for(int t = threadIdx.x; t < (int)gridDim.x; t += 256) { const int v = cnt[t]; total += v; if(t < (int)blockIdx.x) before += v; }
+  int tb, tt;
+  block_incl_scan(before, lds, &tb);
+  block_incl_scan(total, lds, &tt);
+  const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+  bool in[4];
+  int c = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) { in[k] = base + k < ntiles && tile_ghost[base + k] == 0; c += in[k] ? 1 : 0; }
+  int tot;
+  const int inc = block_incl_scan(c, lds, &tot);
+  int pos_int = tb + inc - c;                       // interior tiles in front of this thread's first item
+#pragma unroll
+  for(int k = 0; k < 4; k++) {
+    const int t = base + k;
+    if(t < ntiles) {
+      if(in[k]) order[pos_int++] = t;
+      else order[tt + (t - pos_int)] = t;           // boundary tiles in front of t = t - (interior tiles in front of t)
+    }
+  }
+  if(blockIdx.x == 0 && threadIdx.x == 0) flags[13] = tt;
+}
+
 // reference-style rows from the tile form: neigh[((i>>6)*maxneighs + k)*64 + (i&63)] = tile_cand[slot]
 __global__ __launch_bounds__(64) void k_tiles_to_rows(int nlocal, int maxneighs, int cstride, const int* __restrict__ binned,
                                                       const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
@@ -1256,6 +1301,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags, nt,
                        h->x.p, nlocal, h->nghost, h->nghost_dev);
     HIP_TRY(hipGetLastError());
+    bool order_here = false;
     for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
       MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 16 * 64, false, h->stream));   // (+ prefetch overrun of the last tile)
       if(h->opt_build != 1) {             // (the production kernel needs no zeroing: k_tile_fill / k_tile_reduce write every flag)
@@ -1281,6 +1327,14 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
         if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         hipLaunchKernelGGL(k_tile_reduce, dim3(1), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
                            h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr);
+        order_here = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport) && h->ntiles > 0;
+        if(order_here) {                  // several ranks: the interior-first order of the halo overlap, no extra host synchronisation
+          const int nb_o = div_up(h->ntiles, 1024);
+          MMD_TRY(h->tile_order.ensure((size_t)h->ntiles + 8, false, h->stream));
+          MMD_TRY(h->flag_tmp.ensure((size_t)nb_o + 8, false, h->stream));
+          hipLaunchKernelGGL(k_tile_order_count, dim3(nb_o), dim3(256), 0, h->stream, h->tile_ghost.p, h->ntiles, nt_dev, h->flag_tmp.p);
+          hipLaunchKernelGGL(k_tile_order_scatter, dim3(nb_o), dim3(256), 0, h->stream, h->tile_ghost.p, h->ntiles, nt_dev, h->flag_tmp.p, h->tile_order.p, h->d_flags);
+        }
       } else if(lds > 64 * 1024) {        // the candidate-per-lane form keeps maxneighs x 64 raw slots in LDS
         want_tiles = false;
         break;
@@ -1327,7 +1381,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       h->tiles_ready = true;
       h->ntiles_hint = h->ntiles;
       h->neigh_nlocal = nlocal;
-      h->ntiles_interior = -1;              // interior/boundary order is derived on demand (multi-rank overlap)
+      h->ntiles_interior = order_here ? h->h_flags[13] : -1;    // (-1: the interior/boundary order is derived on demand, mmd_order_tiles)
       return 0;
     }
     if(want_tiles) { mmd_set_error("mmd_neighbor_build: neighbor rows keep overflowing (maxneighs=%d)", h->maxneighs); return -1; }

@@ -86,8 +86,10 @@ def sim(out, args, precision, rccl=False):
     nl, ng, _ = s.handle.counts()
     counts = [None] * world
     dist.all_gather_object(counts, (nl, ng, s.handle.neighbor_info()["total"]))
+    stats = [None] * world
+    dist.all_gather_object(stats, s.handle.run_stats())          # of Integrate::run (the last mmd_integrate_run of Sim.run)
     if rank == 0:
-        json.dump({"rows": s.rows(), "counts": counts, "natoms": s.natoms()}, open(out, "w"))
+        json.dump({"rows": s.rows(), "counts": counts, "natoms": s.natoms(), "stats": stats}, open(out, "w"))
     s.close()
 
 

@@ -298,6 +298,12 @@ def test_four_and_eight_ranks_match_one_rank(nprocs, size, half, port, tmp_path)
     assert [o.nlocal(r_) for r_ in range(nprocs)] == [c[0] for c in res["counts"]]
     assert [o.nghost(r_) for r_ in range(nprocs)] == [c[1] for c in res["counts"]]
     o.close()
+    # re-neighboring on several ranks without count handshakes (fixed-size messages sized by the previous counts, counts left on the
+    # device): the host waits for the GPU twice per re-neighboring — the new nlocal after Comm::exchange, the build's results — plus once
+    # per thermo row; the waits of the host-staged test transport are counted apart (RCCL has none). 100 steps = 5 re-neighborings.
+    for st in res["stats"]:
+        assert st["host_syncs"] <= 2 * 5 + 2, res["stats"]
+        assert st["bytes_sent"] > 0 and st["transport_syncs"] > 0
 
 
 @pytest.mark.parametrize("prec,deck,nprocs", [("dp", "in.eam.miniMD", 2), ("sp", "in.lj.miniMD", 4), ("dp", "in.eam.miniMD", 8)])
