@@ -1107,11 +1107,13 @@ static int borders_fast_finish(mmd_handle* h);
 
 static int borders_one_rank_fast(mmd_handle* h, bool defer)
 {
-  if(!h->opt_borders_fast || h->opt_force_transport || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0) return 0;
-  if(h->nprocs == 1 && h->nlocal <= 4096) return 0;
+  if(!h->opt_borders_fast || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0) return 0;
+  if(h->nprocs == 1 && !h->opt_force_transport && h->nlocal <= 4096) return 0;
+  // (force_transport, a test option: periodic self swaps take the message path too — the RCCL calls of this function run on one GPU)
+  const bool forced = h->opt_force_transport != 0;
   bool any_remote = false;
   for(int q = 0; q < 6; q += 2) {
-    const bool r0 = h->swaps[q].sendproc != h->me, r1 = h->swaps[q + 1].sendproc != h->me;
+    const bool r0 = forced || h->swaps[q].sendproc != h->me, r1 = forced || h->swaps[q + 1].sendproc != h->me;
     if(r0 != r1) return 0;                      // (a dimension is either all-self or all-remote)
     any_remote = any_remote || r0;
   }
@@ -1143,7 +1145,7 @@ static int borders_one_rank_fast(mmd_handle* h, bool defer)
   hipLaunchKernelGGL(k_bnd_count, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bstate.p);
   hipLaunchKernelGGL(k_bnd_scatter, dim3(nt_own > 0 ? nt_own : 1), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bnd_list.p, h->bstate.p, est_nb);
   for(int q = 0; q < 6; q += 2) {
-    const bool remote = h->swaps[q].sendproc != h->me;
+    const bool remote = forced || h->swaps[q].sendproc != h->me;
     SwapPair P;
     int cap_s[2] = {0, 0}, cap_r[2] = {0, 0};
     size_t off_s[2] = {0, 0}, off_r[2] = {0, 0}, bytes_s[2] = {0, 0}, bytes_r[2] = {0, 0};
@@ -1226,7 +1228,7 @@ static int borders_fast_finish(mmd_handle* h)
     s.recvnum = hf[BST_RECV + q];
     s.firstrecv = nall;
     nall += s.recvnum;
-    all_self = all_self && s.sendproc == h->me;
+    all_self = all_self && s.sendproc == h->me && !h->opt_force_transport;
   }
   h->nghost = hf[BST_GHOSTS + 6];
   if(nall != nlocal + h->nghost) { mmd_set_error("borders fast path: inconsistent ghost counts"); return -1; }
@@ -1293,7 +1295,7 @@ static int borders_general(mmd_handle* h)
   // one pass over the owned atoms keeps only those inside some send slab (~12% at -s 80); the per-swap
   // selections then scan that short list + the ghosts instead of every owned atom six times
   int nb = -1;
-  if(h->swaps.size() <= 6 && (h->nlocal > 4096 || h->nprocs > 1)) {
+  if(h->swaps.size() <= 6 && (h->nlocal > 4096 || h->nprocs > 1 || h->opt_force_transport)) {
     AnySlabPred ap;
     ap.x = h->x.p; ap.n = (int)h->swaps.size();
     for(int q = 0; q < ap.n; q++) { ap.lo[q] = h->swaps[q].slablo; ap.hi[q] = h->swaps[q].slabhi; ap.dim[q] = h->swaps[q].dim; }
