@@ -83,6 +83,8 @@ int mmd_neighbor_info(mmd_handle* h, int* maxneighs, int* mbins, long long* tota
 /* diagnostics of the device tile form of the list (full or half): out = {tiles, largest candidate union, sum of
  * candidate unions, sum of padded row counts, sum of atoms in tiles, longest padded row}; zeros when no tiles exist */
 int mmd_neighbor_tile_stats(mmd_handle* h, long long out[6]);
+/* diagnostics: histograms (nb bins of `width`, the last one open-ended) of the tiles' candidate-union sizes and padded row counts */
+int mmd_neighbor_tile_histogram(mmd_handle* h, int nb, int width, long long* hist_ncand, long long* hist_rows);
 /* rows in REFERENCE layout neighbors[i*maxneighs + k] (ref/neighbor.cpp:128); maxneighs = caller's stride */
 int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneighs, int* numneigh);
 int mmd_neighbor_upload(mmd_handle* h, const int* neighbors, int maxneighs, const int* numneigh, int nlocal);

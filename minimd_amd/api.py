@@ -62,7 +62,7 @@ def load_library(precision="dp"):
         "mmd_atom_upload_f": [P, rp, I], "mmd_atom_counts": [P, ip, ip, ip], "mmd_atom_pbc": [P], "mmd_atom_sort": [P],
         "mmd_neighbor_setup": [P, ip, creal, I, I, I], "mmd_neighbor_build": [P],
         "mmd_neighbor_geometry": [P, ip, ip, ip, ip],
-        "mmd_neighbor_info": [P, ip, ip, C.POINTER(C.c_longlong), ip], "mmd_neighbor_tile_stats": [P, C.POINTER(C.c_longlong)], "mmd_neighbor_download": [P, ip, I, ip],
+        "mmd_neighbor_info": [P, ip, ip, C.POINTER(C.c_longlong), ip], "mmd_neighbor_tile_stats": [P, C.POINTER(C.c_longlong)], "mmd_neighbor_tile_histogram": [P, I, I, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "mmd_neighbor_download": [P, ip, I, ip],
         "mmd_neighbor_upload": [P, ip, I, ip, I],
         "mmd_force_lj_setup": [P, I, rp, rp, rp],
         "mmd_force_eam_setup": [P, I, I, I, I, I, creal, creal, rp, rp, rp, rp],
@@ -229,6 +229,11 @@ class Handle:
         self._chk(self.L.mmd_neighbor_tile_stats(self.h, out))
         keys = ("tiles", "max_candidates", "sum_candidates", "sum_padded_rows", "sum_atoms", "max_padded_row")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def neighbor_tile_histogram(self, nb=64, width=16):
+        a, b = (C.c_longlong * nb)(), (C.c_longlong * nb)()
+        self._chk(self.L.mmd_neighbor_tile_histogram(self.h, nb, width, a, b))
+        return [int(v) for v in a], [int(v) for v in b]
 
     def neighbor_download(self):
         nl = self.counts()[0]

@@ -104,6 +104,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "time_force_sample")) h->opt_time_sample = value;
   else if(!strcmp(name, "fold_reverse")) h->opt_fold_reverse = value;
   else if(!strcmp(name, "eam_half_rows")) h->opt_eam_half_rows = value;
+  else if(!strcmp(name, "eam_fold_fp")) h->opt_eam_fold_fp = value;
   else if(!strcmp(name, "async_counts")) h->opt_async_counts = value;
   else if(!strcmp(name, "lj_original")) h->opt_lj_original = value;
   else if(!strcmp(name, "core_pct")) h->opt_core_pct = value;

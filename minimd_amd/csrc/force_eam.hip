@@ -406,6 +406,9 @@ __device__ __forceinline__ float rsqrt_fast(float a)
 #define EAM_FU 4              // pairs per trip of the force sweep (+ one trip of EAM_TU where 4 rows remain)
 #endif
 #define EAM_STAGE 4
+#ifndef EAM_RD
+#define EAM_RD (MMD_PRECISION == 2 ? 1 : 0)      // DP: the three position reads of a pair stay separate ds_read_b64 (ds_read2_b64 runs at half the LDS rate: -1.7 %)
+#endif
 
 // dynamic LDS of both kernels (nothing static precedes it, see tile_lds.hpp):
 //   [{x,y,z} records of the candidates: eam_pos_bytes(cmax)] [force sweep only: fp of the candidates] [spline knots] [partials] [16 doubles]
@@ -498,12 +501,13 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     for(int u = 0; u < EAM_TU; u++) sl[u] = np[u * 64];
   }
   __syncthreads();
+  drain_loads();                                      // (see tile_lds.hpp: lets the slot prefetch of the pair loop really overlap)
   real rhoi = 0;
   for(int k = k0; k < k1; k += EAM_TU) {
     real xj[EAM_TU], yj[EAM_TU], zj[EAM_TU];
     unsigned sc[EAM_TU];
 #pragma unroll
-    for(int u = 0; u < EAM_TU; u++) { sc[u] = (unsigned)sl[u]; lds_read3<0>((unsigned)sl[u], xj[u], yj[u], zj[u]); }
+    for(int u = 0; u < EAM_TU; u++) { sc[u] = (unsigned)sl[u]; lds_read3<EAM_RD>((unsigned)sl[u], xj[u], yj[u], zj[u]); }
     np += EAM_TU * 64;
     if(k + EAM_TU < k1) {                               // the next trip's slots travel under this trip's arithmetic
 #pragma unroll
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
     double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, int mlo,
-    const unsigned short* __restrict__ tile_self, EamCore C)
+    const unsigned short* __restrict__ tile_self, EamCore C, const int* __restrict__ fp_root)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_FW;
@@ -620,7 +624,13 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     real4 pp[EAM_STAGE];
     real ff[EAM_STAGE];
 #pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) { pp[u] = x[jj[u]]; ff[u] = fp[jj[u]]; }
+    for(int u = 0; u < EAM_STAGE; u++) {
+      pp[u] = x[jj[u]];
+      // one rank: a ghost is an image of an owned atom, its fp is its owner's (ForceEAM::communicate, ref/force_eam.cpp:851-913, folded
+      // into the staging: no fp halo launch between the two sweeps)
+      const int jf = (fp_root != nullptr && jj[u] >= nlocal && jj[u] < nall) ? fp_root[jj[u] - nlocal] : jj[u];
+      ff[u] = fp[jf];
+    }
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) {
       s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; s_fp[tt[u]] = ff[u];
@@ -646,6 +656,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     for(int u = 0; u < EAM_FU; u++) sl[u] = np[u * 64];
   }
   __syncthreads();
+  drain_loads();
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
   // one trip = U pairs of every lane, written without branches so that the U independent chains (position read -> 1/r -> knot ->
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
     unsigned sc[U];
 #pragma unroll
     for(int u = 0; u < U; u++) {
-      lds_read3<0>((unsigned)sl[u], xj[u], yj[u], zj[u]);
+      lds_read3<EAM_RD>((unsigned)sl[u], xj[u], yj[u], zj[u]);
       sc[u] = (unsigned)sl[u] / (3u * (unsigned)sizeof(real));
       fpj[u] = s_fp[sc[u]];
     }
@@ -899,6 +910,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   const int nlocal = h->nlocal, nall = nlocal + h->nghost;
   if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
   MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
+  h->fp_ghosts_stale = false;
   if(eam_half_tiles_available(h) && !h->opt_eam_half_rows) {
     // ---- ForceEAM::compute_halfneigh (ref/force_eam.cpp:94-270) on the tile lists: the partner's share of every pair is summed in
     // LDS, one global atomic per owned candidate and tile (k_eam_density_tile<.,1>, k_eam_force_tile<.,0,1>)
@@ -933,7 +945,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define FH(EVv) hipLaunchKernelGGL((k_eam_force_tile<EVv, 0, 1>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p, h->tile_first.p, \
                        h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,   \
                        h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr, h->tile_cmax, h->rdr, h->fp.p, h->f.p, p_pair,          \
-                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p, EamCore{})
+                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p, EamCore{}, (const int*)nullptr)
     if(evflag) FH(1); else FH(0);
 #undef FH
     HIP_TRY(hipGetLastError());
@@ -1028,7 +1040,10 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define FT(EVv, Fv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv, 0>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p,       \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
-                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr, core)
+                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr, core, fp_root)
+    // one rank: the force sweep reads a ghost's fp through its owner (no fp halo launch); mmd_force_eam_download_fp completes the array
+    const bool fold_fp = h->opt_eam_fold_fp && (h->opt_eam_fold_fp >= 2 || nt <= 8192) && !h->halo_pending && h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport;
+    const int* fp_root = fold_fp ? (const int*)h->ghost_root.p : (const int*)nullptr;
     auto density = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) DT(1, list, cnt); else DT(0, list, cnt); } };
     auto force = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) FT(1, 0, list, cnt); else if(h->fuse_now) FT(0, 1, list, cnt); else FT(0, 0, list, cnt); } };
     if(h->halo_pending) {
@@ -1055,7 +1070,8 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     } else {
       density(nullptr, nt);
       HIP_TRY(hipGetLastError());
-      MMD_TRY(eam_fp_halo(h));
+      if(!fold_fp) MMD_TRY(eam_fp_halo(h));
+      h->fp_ghosts_stale = fold_fp;
       force(nullptr, nt);
     }
     h->core.tracked_last = core.words_write != nullptr && !evflag;       // (the launch that just went out advanced the atoms and recorded how far they are from the build)
@@ -1114,6 +1130,7 @@ extern "C" int mmd_force_eam_download_fp(mmd_handle* h, mmd_float* fp)
   if(!h || !fp) { mmd_set_error("mmd_force_eam_download_fp: bad arguments"); return -1; }
   const int nall = h->nlocal + h->nghost;
   if(h->fp.cap < (size_t)nall) { mmd_set_error("mmd_force_eam_download_fp: no EAM force has been computed"); return -1; }
+  if(h->fp_ghosts_stale) { MMD_TRY(eam_fp_halo(h)); h->fp_ghosts_stale = false; }      // (the force sweep read the ghosts' fp through their owners)
   HIP_TRY(hipMemcpyAsync(fp, h->fp.p, (size_t)nall * sizeof(real), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(mmd_stream_sync(h));
   return 0;

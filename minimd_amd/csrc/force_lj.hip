@@ -57,6 +57,13 @@ __device__ __forceinline__ float recip(float a)
   return __builtin_fmaf(e, r, r);
 }
 
+// f(integral_constant<0>), f(integral_constant<STEP>), ... below N: a compile-time loop (the group index feeds an s_waitcnt immediate)
+template <int N, int STEP, int I = 0, class F>
+__device__ __forceinline__ void static_for_groups(F&& f)
+{
+  if constexpr(I < N) { f(std::integral_constant<int, I>{}); static_for_groups<N, STEP, I + STEP>(f); }
+}
+
 struct LJTables {       // general (non-uniform) case: per type-pair tables staged in LDS by the kernel
   const real* cutforcesq;
   const real* sigma6;
@@ -65,6 +72,9 @@ struct LJTables {       // general (non-uniform) case: per type-pair tables stag
 };
 
 #define LJ_MAX_TYPES2 64
+#ifndef LJH_RD
+#define LJH_RD (MMD_PRECISION == 2 ? 1 : 0)      // half-list tile kernel, DP: three separate ds_read_b64 per pair (ds_read2_b64 runs at half the LDS rate: -2.5 %)
+#endif
 #define LJ_UNR 4                 // unroll of the global-gather kernels (rows are padded to MMD_UNROLL >= this)
 
 // ---- full neighbor list: compute_fullneigh<EVFLAG> (ref/force_lj.cpp:366-449) -------------------------
@@ -229,6 +239,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   real vx0 = 0, vy0 = 0, vz0 = 0;          // FUSE: the velocity travels under the pair loop (wave 0 integrates)
   if(FUSE && wv == 0 && i >= 0) { vx0 = v[3 * (size_t)i + 0]; vy0 = v[3 * (size_t)i + 1]; vz0 = v[3 * (size_t)i + 2]; }
   __syncthreads();
+  drain_loads();
 
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
@@ -252,8 +263,8 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     // pairs are worked off in groups of four (register pressure: the second group's positions wait in their LDS-read registers)
     constexpr bool BATCH = RD == 2 && !EXACT && (U % 4) == 0 && sizeof(real) == 8;
     constexpr int GRP = BATCH ? 4 : 1;
-#pragma unroll
-    for(int g0 = 0; g0 < U; g0 += GRP) {
+    static_for_groups<U, GRP>([&](auto g0c) {
+      constexpr int g0 = decltype(g0c)::value;
       real dx[GRP], dy[GRP], dz[GRP], rsq[GRP], sr2[GRP];
 #pragma unroll
       for(int q = 0; q < GRP; q++) {
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
           v_acc = __builtin_fma((double)rsq[q], (double)fs, v_acc);
         }
       }
-    }
+    });
   };
   int k = k0;
   for(; k + UNR <= k1; k += UNR) trip(std::integral_constant<int, UNR>{}, k);
@@ -463,6 +474,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   __syncthreads();
+  drain_loads();
 
   real fx = 0, fy = 0, fz = 0;
   double e_acc = 0, v_acc = 0;
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     real xj[U], yj[U], zj[U];
     int sc[U];
 #pragma unroll
-    for(int u = 0; u < U; u++) { sc[u] = s[u]; lds_read3<0>((unsigned)s[u], xj[u], yj[u], zj[u]); }
+    for(int u = 0; u < U; u++) { sc[u] = s[u]; lds_read3<LJH_RD>((unsigned)s[u], xj[u], yj[u], zj[u]); }
     np += U * 64;
     if(k + U < k1) {
 #pragma unroll

@@ -226,6 +226,9 @@ struct mmd_handle {
   // one-rank half-list LJ steps with ghost newton: the tile kernel adds a ghost's share to its owner (no Comm::reverse_communicate)
   int opt_fold_reverse = 1;
   bool fold_reverse_now = false;
+  int opt_eam_fold_fp = 1;             // one rank, EAM full lists: ghosts' fp read through their owners in the force sweep, no fp halo launch
+                                       // (1: small systems, where the saved launch shows — no difference at -s 64; 2: always; 0: never)
+  bool fp_ghosts_stale = false;
   int opt_eam_half_rows = 0;           // 1: EAM half lists on the global-atomic row kernels even where the tile kernels apply
   bool eam_half_attr_set = false;
   const int* nghost_dev = nullptr;     // != nullptr: one-rank borders enqueued, ghost count still on the device (nghost holds a bound)

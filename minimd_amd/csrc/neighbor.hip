@@ -1465,6 +1465,24 @@ extern "C" int mmd_neighbor_tile_stats(mmd_handle* h, long long out[6])
   return 0;
 }
 
+// diagnostics: histograms (bins of `width`, `nb` bins, the last one open-ended) of the tiles' union sizes and padded row counts
+extern "C" int mmd_neighbor_tile_histogram(mmd_handle* h, int nb, int width, long long* hist_ncand, long long* hist_rows)
+{
+  if(!h || nb < 1 || width < 1 || !hist_ncand || !hist_rows) { mmd_set_error("mmd_neighbor_tile_histogram: bad arguments"); return -1; }
+  for(int q = 0; q < nb; q++) hist_ncand[q] = hist_rows[q] = 0;
+  if(!h->tiles_ready || h->ntiles <= 0) return 0;
+  HIP_TRY(hipSetDevice(h->device));
+  std::vector<int> nc(h->ntiles), mx(h->ntiles);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(nc.data(), h->tile_ncand.p, sizeof(int) * h->ntiles, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(mx.data(), h->tile_max.p, sizeof(int) * h->ntiles, hipMemcpyDeviceToHost));
+  for(int t = 0; t < h->ntiles; t++) {
+    hist_ncand[std::min(nc[t] / width, nb - 1)]++;
+    hist_rows[std::min(mx[t] / width, nb - 1)]++;
+  }
+  return 0;
+}
+
 // ---- layout conversion to/from the reference's row-major rows (ref/neighbor.cpp:128) ----------------
 __global__ void k_rows_to_ref(const int* __restrict__ neigh, const int* __restrict__ numneigh, int nlocal, int stride_dev,
                               int* __restrict__ out, int stride_ref)

@@ -33,6 +33,16 @@ __device__ __forceinline__ real mul_add_unfused(real a, real b, real c)
 }
 
 
+// Every load issued so far has landed (s_waitcnt vmcnt(0), as an intrinsic the compiler's wait-count pass sees). Placed in front of a
+// pair loop whose body prefetches the next trip's slots: without it the loop carries the "my atom's position may still be in flight"
+// state of its pre-header around the back edge, and since that load was issued AFTER the first trip's slot loads the only safe wait
+// for it is vmcnt(0) — in every trip, right behind the prefetch it was meant to overlap with.
+#ifndef MMD_NO_DRAIN
+__device__ __forceinline__ void drain_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), expcnt / lgkmcnt untouched
+#else
+__device__ __forceinline__ void drain_loads() {}
+#endif
+
 // One-rank runs: every ghost is a periodic image of an owned atom (Comm::borders recorded its root and image vector), so a tile
 // kernel can stage a ghost candidate straight from the owner's CURRENT position plus the box shift — the per-step
 // Comm::communicate (k_ghost_update, ref/comm.cpp:276-317 with self swaps) and its launch gap disappear from the step.

@@ -12,4 +12,7 @@ for label, n in (("step 0", 0), ("after 100 steps", 100)):
     st = s.handle.neighbor_tile_stats()
     info = s.handle.neighbor_info()
     print(label, st, "total", info["total"], flush=True)
+    hc, hr = s.handle.neighbor_tile_histogram(64, 16)
+    print("  union size histogram (bins of 16):", {16 * k: v for k, v in enumerate(hc) if v})
+    print("  padded rows histogram (bins of 4): ", {4 * k: v for k, v in enumerate(s.handle.neighbor_tile_histogram(64, 4)[1]) if v}, flush=True)
 s.close()
