@@ -543,7 +543,7 @@ def test_baseline_eam_s64():
     s.close()
 
 
-def test_config_e_full_size_sp_half_lists():
+def test_config_e_full_size_sp_half_lists_against_this_codes_own_dp_run():
     """BASELINE configs[4] at its real size: -s 160 (16 384 000 atoms), single precision, half neighbor lists with the
     third-law scatter, 100 steps. No SP row of the reference is pinned at this size (its float sums have lost their digits,
     DESIGN.md §6), so the run is judged by size-independent properties and against the DP half-list run of the same box:
