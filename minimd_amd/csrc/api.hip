@@ -57,7 +57,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->type.release(); h->type_alt.release(); h->tag.release(); h->tag_alt.release();
   h->bin_count.release(); h->bin_start.release(); h->binned.release(); h->scan_tmp.release(); h->atom_bin.release(); h->atom_rank.release();
   h->neigh.release(); h->numneigh.release(); h->wave_max.release(); h->ghost_image.release(); h->ghost_root.release();
-  h->tile_of_block.release(); h->tile_block.release(); h->tile_first.release(); h->tile_max.release();
+  h->tile_of_block.release(); h->pencil_range.release(); h->tile_block.release(); h->tile_first.release(); h->tile_max.release();
   h->tile_cand.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
   for(auto& s : h->swaps) s.sendlist.release();

@@ -151,6 +151,7 @@ struct mmd_handle {
   bool rows_ready = false;               // the wave-interleaved 32-bit rows (`neigh`, wave_max) are materialised
   int ntiles = 0, tile_tmax = 0;          // tile_tmax: largest candidate count of any block (LDS sizing)
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
+  DevArr<int> pencil_range;               // per pencil (row of blocks along x): [first, last) entry of binned[] between its first and last owned bin
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
   DevArr<unsigned short> tile_self;       // half lists: union slot of each tile atom itself (0xffff: not in the union)
   // Rows in two parts (full lists, one rank): pairs closer than `radius` = cutforce + margin at the build come first ("core"), the rest of

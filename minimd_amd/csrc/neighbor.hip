@@ -23,6 +23,10 @@
 #include <vector>
 
 #define NB_SMALL 1.0e-6
+#ifndef NB_XF
+#define NB_XF 4                // x-slices per reference bin (see fine_x_of)
+#endif
+#define NB_SUB (8 * NB_XF)     // device bins per block of 2x2x2 reference bins
 
 // ---------------------------------------------------------------------------------------------------
 // Neighbor::setup (ref/neighbor.cpp:318-452)
@@ -58,7 +62,7 @@ extern "C" int mmd_neighbor_setup(mmd_handle* h, const int nbin[3], mmd_float cu
     if(next * g.binsize[d] < cutneigh) next++;   // full coverage (the reference shaves 0.1% here, :405-415)
     g.reach[d] = (next + 1) >> 1;
   }
-  const long long mb = 8LL * g.nblk[0] * g.nblk[1] * g.nblk[2];
+  const long long mb = (long long)NB_SUB * g.nblk[0] * g.nblk[1] * g.nblk[2];
   if(mb > 2000000000LL) { mmd_set_error("mmd_neighbor_setup: too many bins"); return -1; }
   g.mbins = (int)mb;
   h->neigh_ready = true;
@@ -89,6 +93,26 @@ __device__ __forceinline__ int ref_bin3(const BinGeom& g, real x, real y, real z
   return (ix & 1023) | ((iy & 1023) << 10) | ((iz & 1023) << 20);
 }
 
+// The device orders atoms finer than the reference's bins along x: every reference bin is cut into NB_XF slices, a BLOCK = 2x2x2
+// reference bins = NB_SUB = 2*NB_XF x-slices of 2x2 (y,z) bins, numbered slice-major, so that along a row of blocks (a "pencil" of
+// 2x2 bins cross-section) `binned` is sorted by x to a quarter of a bin. The production tiles are the 64-atom pieces of a pencil
+// (k_pencil_tiles): full wavefronts of atoms in a compact x-range, instead of one 57-atom block per tile.
+
+// fine x index along a pencil: (shifted reference bin) * NB_XF + slice of the bin; monotone in x, the reference bin as coord2bin has it
+__device__ __forceinline__ int fine_x_of(const BinGeom& g, real x)
+{
+  int ix;
+  real y;                                          // position in units of bins, inside the branch coord2bin takes
+  if(x >= g.prd[0]) { y = (x - g.prd[0]) * g.bininv[0]; ix = (int)y + g.nbin[0] - g.mbinlo[0]; }
+  else if(x >= (real)0.0) { y = x * g.bininv[0]; ix = (int)y - g.mbinlo[0]; }
+  else { y = x * g.bininv[0]; ix = (int)y - g.mbinlo[0] - 1; }
+  real fr = y - (real)(int)y;                      // y >= 0: the fraction of the bin; y < 0: the bin is [trunc(y) - 1, trunc(y))
+  if(x < (real)0.0) fr += (real)1.0;
+  const int q = min(max((int)(fr * (real)NB_XF), 0), NB_XF - 1);
+  ix = min(max(ix, 0), g.mbin[0] - 1) + g.blkshift[0];
+  return ix * NB_XF + q;
+}
+
 // coord -> (ix,iy,iz) exactly as Neighbor::coord2bin (ref/neighbor.cpp:274-297), then block-major id
 __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
 {
@@ -107,7 +131,8 @@ __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
   iz = min(max(iz, 0), g.mbin[2] - 1);
   ix += g.blkshift[0]; iy += g.blkshift[1]; iz += g.blkshift[2];
   const int blk = ((iz >> 1) * g.nblk[1] + (iy >> 1)) * g.nblk[0] + (ix >> 1);
-  return blk * 8 + ((iz & 1) << 2 | (iy & 1) << 1 | (ix & 1));
+  const int fx = fine_x_of(g, x);                  // = ix * NB_XF + slice (same clamped, shifted ix)
+  return blk * NB_SUB + (fx & (2 * NB_XF - 1)) * 4 + ((iz & 1) << 1 | (iy & 1));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -287,7 +312,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
   const int lane = threadIdx.x;
   const int b = xcd_work_item(g.nblk[0] * g.nblk[1] * g.nblk[2]);
   if(b < 0) return;
-  const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
+  const int a0 = bin_start[b * NB_SUB], a1 = bin_start[b * NB_SUB + NB_SUB];
   if(a0 == a1) return;                                      // empty block (uniform exit)
   const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
 
@@ -304,8 +329,8 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
       if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
         const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
         const int row = (z * g.nblk[1] + y) * g.nblk[0];
-        start = bin_start[(row + x0) * 8];
-        len = bin_start[(row + x1) * 8 + 8] - start;
+        start = bin_start[(row + x0) * NB_SUB];
+        len = bin_start[(row + x1) * NB_SUB + NB_SUB] - start;
       }
     }
     const int incl = wave_incl_scan(len);
@@ -414,7 +439,7 @@ __global__ void k_tile_count(const int* __restrict__ binned, const int* __restri
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b >= nblocks) return;
-  const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
+  const int a0 = bin_start[b * NB_SUB], a1 = bin_start[b * NB_SUB + NB_SUB];
   bool owned = false;
   for(int a = a0; a < a1 && !owned; a++) owned = binned[a] < nlocal;
   ntile_of_block[b] = owned ? (a1 - a0 + 63) >> 6 : 0;
@@ -429,13 +454,56 @@ __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, cons
   if(b == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
   if(b >= nblocks) return;
   const int t0 = tile_of_block[b], t1 = tile_of_block[b + 1];
-  const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
+  const int a0 = bin_start[b * NB_SUB], a1 = bin_start[b * NB_SUB + NB_SUB];
   for(int t = t0; t < t1 && t < cap; t++) {                     // (cap: the arrays may be sized from the previous build's count)
     tile_block[t] = b;
     tile_first[t] = a0 + (t - t0) * 64;
     tile_cnt[t] = min(64, a1 - tile_first[t]);
   }
 }
+// ---------------------------------------------------------------------------------------------------
+// Production tiles ("pencil tiles", k_build_rows): a pencil = one row of blocks along x (2x2 reference bins in cross-section); its
+// entries of `binned` are sorted by x to a quarter of a bin (NB_XF). The stretch from the pencil's first to its last bin that holds an
+// owned atom is cut into pieces of 64 entries: every tile but the last of a pencil is a FULL wavefront of atoms within ~1.2 block
+// lengths of x (at LJ liquid density a block holds 57 atoms: one-block tiles leave 11 % of the lanes empty).
+// One wavefront per pencil; ntile_of_pencil is scanned by the caller, tile_block[] holds the pencil's first block.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_pencil_count(const int* __restrict__ binned, const int* __restrict__ bin_start, int npencils, int nblk0,
+                                                     int nlocal, int* __restrict__ ntile_of_pencil, int* __restrict__ pencil_range)
+{
+  const int p = blockIdx.x, lane = threadIdx.x;
+  if(p >= npencils) return;
+  const int b0 = p * nblk0 * NB_SUB, nb = nblk0 * NB_SUB;
+  unsigned lo = 0xffffffffu, hi = 0u;                      // first / last bin (+1) of the pencil that holds an owned atom
+  for(int q = lane; q < nb; q += 64) {
+    const int s0 = bin_start[b0 + q], s1 = bin_start[b0 + q + 1];
+    if(s1 > s0 && binned[s0] < nlocal) { lo = min(lo, (unsigned)q); hi = max(hi, (unsigned)q + 1u); }     // (a bin's entries ascend: owned atoms first)
+  }
+  lo = wave_min_u(lo); hi = wave_max_u(hi);
+  if(lane == 0) {
+    int a0 = 0, a1 = 0;
+    if(hi > 0u) { a0 = bin_start[b0 + (int)lo]; a1 = bin_start[b0 + (int)hi]; }
+    ntile_of_pencil[p] = (a1 - a0 + 63) >> 6;
+    pencil_range[2 * p] = a0; pencil_range[2 * p + 1] = a1;
+  }
+}
+__global__ void k_pencil_fill(const int* __restrict__ pencil_range, int npencils, int nblk0, const int* __restrict__ tile_of_pencil,
+                              int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags, int cap,
+                              real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if(p == 0) { flags[1] = 0; flags[3] = 0; flags[7] = 0; }     // (result flags of the build kernel that follows on the stream)
+  if(p == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};    // the dummy atom, see k_tile_fill
+  if(p >= npencils) return;
+  const int t0 = tile_of_pencil[p], t1 = tile_of_pencil[p + 1];
+  const int a0 = pencil_range[2 * p], a1 = pencil_range[2 * p + 1];
+  for(int t = t0; t < t1 && t < cap; t++) {
+    tile_block[t] = p * nblk0;
+    tile_first[t] = a0 + (t - t0) * 64;
+    tile_cnt[t] = min(64, a1 - tile_first[t]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fused tile build (full lists): same register-transposed test as k_build, but
 //   * hits go to an LDS row buffer rows[k][lane-of-atom] as raw candidate slots (ds_write_b16, no global
@@ -473,7 +541,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
   if(b >= nblocks) return;
   const int tile0 = tile_of_block[b], ntile_b = tile_of_block[b + 1] - tile0;
   if(ntile_b == 0) return;                                    // no owned atom in this block (uniform exit)
-  const int a0 = bin_start[b * 8], a1 = bin_start[b * 8 + 8];
+  const int a0 = bin_start[b * NB_SUB], a1 = bin_start[b * NB_SUB + NB_SUB];
   const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
   const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
   const int nr = min(ny * nz, 128);
@@ -486,8 +554,8 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
       if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
         const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
         const int row = (z * g.nblk[1] + y) * g.nblk[0];
-        start = bin_start[(row + x0) * 8];
-        len = bin_start[(row + x1) * 8 + 8] - start;
+        start = bin_start[(row + x0) * NB_SUB];
+        len = bin_start[(row + x1) * NB_SUB + NB_SUB] - start;
       }
     }
     const int incl = wave_incl_scan(len);
@@ -764,34 +832,43 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // the tile count may still be on its way to the host (ntiles = capacity of the arrays, *ntiles_dev = the count)
   const int tile = xcd_work_item(ntiles_dev ? min(ntiles, *ntiles_dev) : ntiles);
   if(tile < 0) return;
-  const int b = tile_block[tile];
+  const int b = tile_block[tile];                  // first block of the tile's pencil (pencil tiles) / the tile's block
   const int ta = tile_first[tile], tcn = tile_cnt[tile];
-  const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
-  // ---- candidate slices: for every (dz,dy) one contiguous run of blocks [bx-R, bx+R] in binned[]
-  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
-  const int nr = min(ny * nz, 128);
-  for(int r0 = 0; r0 < nr; r0 += 64) {
-    const int r = r0 + lane;
-    int len = 0, start = 0;
-    if(r < nr) {
-      const int z = bz + r / ny - g.reach[2], y = by + r % ny - g.reach[1];
-      if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
-        const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
-        const int row = (z * g.nblk[1] + y) * g.nblk[0];
-        start = bin_start[(row + x0) * 8];
-        len = bin_start[(row + x1) * 8 + 8] - start;
-      }
-      rng_start[r] = start; rng_len[r] = len;
-    }
-  }
-  s_self[lane] = (unsigned short)0xffff;
-  s_selfpos[lane] = (unsigned short)0xffff;
-  __syncthreads();
+  const int by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
   // ---- my atom
   const int ii = lane < tcn ? binned[ta + lane] : -1;
   const bool owned = ii >= 0 && ii < nlocal;
   const real4 pme = x[ii >= 0 ? ii : 0];
   const unsigned long long own_mask = __builtin_amdgcn_ballot_w64(owned);
+  // ---- candidate slices: for every (dz,dy) the stretch of that pencil whose x-slices can hold an atom within the cutoff of the
+  // tile's owned atoms — ONE contiguous run of binned[] (a pencil is sorted by x-slice): [slice(xmin - cutneigh), slice(xmax + cutneigh)]
+  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
+  const int nr = min(ny * nz, 128);
+  {
+    const real big = (real)3.0e38;
+    real xlo = owned ? pme.x : big, xhi = owned ? pme.x : -big;
+#pragma unroll
+    for(int o = 32; o > 0; o >>= 1) { xlo = fmin(xlo, __shfl_xor(xlo, o, 64)); xhi = fmax(xhi, __shfl_xor(xhi, o, 64)); }
+    const real reach_x = cutneigh * (real)1.0005 + (real)1.0e-4 * g.binsize[0];
+    const int fmaxx = 2 * NB_XF * g.nblk[0] - 1;
+    const int f0 = min(max(fine_x_of(g, xlo - reach_x), 0), fmaxx), f1 = min(max(fine_x_of(g, xhi + reach_x), 0), fmaxx);
+    for(int r0 = 0; r0 < nr; r0 += 64) {
+      const int r = r0 + lane;
+      int len = 0, start = 0;
+      if(r < nr) {
+        const int z = bz + r / ny - g.reach[2], y = by + r % ny - g.reach[1];
+        if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1] && own_mask != 0ull) {
+          const int row = (z * g.nblk[1] + y) * g.nblk[0] * NB_SUB;          // first bin of that pencil; slice f starts at bin row + 4 f
+          start = bin_start[row + 4 * f0];
+          len = bin_start[row + 4 * f1 + 4] - start;
+        }
+        rng_start[r] = start; rng_len[r] = len;
+      }
+    }
+  }
+  s_self[lane] = (unsigned short)0xffff;
+  s_selfpos[lane] = (unsigned short)0xffff;
+  __syncthreads();
   unsigned short* __restrict__ rowp = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
   const size_t cbase = (size_t)tile * cstride;
   if(own_mask == 0ull || (ablate & 32)) {                        // (second tile of a block that holds only ghosts)
@@ -1253,15 +1330,22 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   // ---- tile form: block-local 16-bit rows + per-tile candidate union, see k_build_tiles
   bool want_tiles = h->opt_tiles && nlocal > 0;
   if(want_tiles) {
+    // production build: pencil tiles (64-atom pieces of a row of blocks); the candidate-per-lane build keeps one tile per block
+    const bool pencil = h->opt_build == 1;
+    const int nunits = pencil ? g.nblk[1] * g.nblk[2] : nblocks;
     MMD_TRY(h->tile_of_block.ensure((size_t)nblocks + 2, false, h->stream));
+    if(pencil) {
+      MMD_TRY(h->pencil_range.ensure((size_t)2 * nunits + 2, false, h->stream));
+      hipLaunchKernelGGL(k_pencil_count, dim3(nunits), dim3(64), 0, h->stream, h->binned.p, h->bin_start.p, nunits, g.nblk[0], nlocal, h->tile_of_block.p, h->pencil_range.p);
+    } else
     hipLaunchKernelGGL(k_tile_count, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->binned.p, h->bin_start.p, nblocks, nlocal, h->tile_of_block.p);
     // the tile count sizes the lists. Once a build has succeeded the previous count (+3 %) does that and the count itself
     // comes back with the build's result flags: one host synchronisation less per re-neighboring
     int nt = 0;
     const bool nt_async = h->opt_build == 1 && h->opt_async_counts && h->ntiles_hint > 0;
-    MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nblocks, nt_async ? nullptr : &nt));
+    MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nunits, nt_async ? nullptr : &nt));
     if(nt_async) nt = h->ntiles_hint + h->ntiles_hint / 32 + 64;
-    const int* nt_dev = nt_async ? h->tile_of_block.p + nblocks : nullptr;
+    const int* nt_dev = nt_async ? h->tile_of_block.p + nunits : nullptr;
     h->ntiles = nt;
     MMD_TRY(h->tile_block.ensure((size_t)nt + 2, false, h->stream));
     MMD_TRY(h->tile_first.ensure((size_t)nt + 2, false, h->stream));
@@ -1298,6 +1382,10 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
+    if(pencil)
+      hipLaunchKernelGGL(k_pencil_fill, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
+                         h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev);
+    else
     hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags, nt,
                        h->x.p, nlocal, h->nghost, h->nghost_dev);
     HIP_TRY(hipGetLastError());
