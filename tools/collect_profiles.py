@@ -10,14 +10,15 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 dst = os.path.join(REPO, "profiles")
 names = {"bench_n1.json": "bench_n1.json", "configs.txt": "configs.txt", "kernel_stats_bench.md": "kernel_stats_bench_s80_full_dp.md",
          "kernel_stats_A.md": "kernel_stats_A_s32_full_dp.md", "kernel_stats_Bh.md": "kernel_stats_Bhalf_s80_half_dp.md",
          "kernel_stats_C.md": "kernel_stats_C_eam_s64_full_dp.md", "kernel_stats_Ch.md": "kernel_stats_Chalf_eam_s64_half_dp.md",
          "kernel_stats_E.md": "kernel_stats_E_s160_half_sp.md", "pmc_lj_full.txt": "pmc_k_lj_full_tile.txt", "pmc_lj_half.txt": "pmc_k_lj_half_tile.txt",
-         "pmc_eam.txt": "pmc_k_eam_tile.txt", "pmc_build.txt": "pmc_k_build_rows.txt"}
+         "pmc_eam.txt": "pmc_k_eam_tile.txt", "pmc_build.txt": "pmc_k_build_rows.txt",
+         "timeline_reneighboring_s80.txt": "timeline_reneighboring_s80.txt", "timeline_reneighboring_s32.txt": "timeline_reneighboring_s32.txt"}
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (tag, b)))

@@ -3,7 +3,7 @@
 #   bench line, kernel statistics of every BASELINE configuration, PMC passes of the hot kernels, configuration runs.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/prof_$R
 mkdir -p $O
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
@@ -24,6 +24,10 @@ bash tools/pmc_force.sh $O/pmc_lj_half  k_lj_half_tile   tools/prof_force.py --h
 bash tools/pmc_force.sh $O/pmc_eam      "k_eam_.*_tile"  tools/prof_force.py --deck in.eam.miniMD --size 64 --kernels 0 --reps 5 > $O/pmc_eam.txt 2>&1
 bash tools/pmc_force.sh $O/pmc_build    k_build_rows     tools/prof_force.py --steps 20 --kernels 1 > $O/pmc_build.txt 2>&1
 tail -30 $O/pmc_lj_full.txt
+# kernel timelines of one re-neighboring
+bash tools/gpu_timeline.sh 80 > $O/timeline_reneighboring_s80.txt 2>&1
+bash tools/gpu_timeline.sh 32 > $O/timeline_reneighboring_s32.txt 2>&1
+rm -rf gpurun_out/tl80 gpurun_out/tl32
 # keep the merge small: drop the raw rocprof trees, keep logs + summaries
 find $O -name "*.db" -delete; find $O -type d -name "kt_*" -exec rm -rf {} + 2>/dev/null; find $O -mindepth 1 -maxdepth 1 -type d -name "pmc_*" -exec rm -rf {} + 2>/dev/null
 ls -la $O
