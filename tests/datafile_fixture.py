@@ -26,15 +26,20 @@ CASES = {
     # name: (cells, lattice constant, position jitter / a, velocity scale, mass or None, seed)
     "lj_5x6x7": dict(cells=(5, 6, 7), a=1.6795962, jitter=0.04, vscale=1.9, mass=1.5, seed=20240917),
     "eam_4x5x5": dict(cells=(4, 5, 5), a=3.615, jitter=0.02, vscale=6.0, mass=None, seed=777),
+    # one cell compressed to 0.8 a along x: the box is thinner than half the neighbor cutoff (1.34 < 1.4), Comm::setup asks for THREE
+    # ghost layers in x (need = 3, ref/comm.cpp:150-152) and an atom sees up to three images of itself
+    "lj_thin_1x6x7": dict(cells=(1, 6, 7), a=1.6795962, jitter=0.02, vscale=1.2, mass=1.0, seed=4711, scale=(0.8, 1.0, 1.0)),
 }
 
 
-def make_arrays(cells, a, jitter, vscale, seed, **_):
+def make_arrays(cells, a, jitter, vscale, seed, scale=None, **_):
     """positions/velocities indexed by (file id - 1), box lengths"""
     nx, ny, nz = cells
     rng = _Lcg(seed)
     basis = ((0.0, 0.0, 0.0), (0.5, 0.5, 0.0), (0.5, 0.0, 0.5), (0.0, 0.5, 0.5))
     prd = (nx * a, ny * a, nz * a)
+    if scale is not None:                                # anisotropic cell (cases without `scale` keep their bytes)
+        return _make_arrays_scaled(cells, a, jitter, vscale, seed, scale)
     pos = []
     for k in range(nz):
         for j in range(ny):
@@ -59,6 +64,47 @@ def make_arrays(cells, a, jitter, vscale, seed, **_):
         for i in range(n):
             vel[i][d] -= m
     # shuffle: ids[k] = file id (1-based) of lattice atom k
+    ids = list(range(1, n + 1))
+    for k in range(n - 1, 0, -1):
+        r = int(rng.u() * (k + 1))
+        ids[k], ids[r] = ids[r], ids[k]
+    x = np.zeros((n, 3))
+    v = np.zeros((n, 3))
+    for k in range(n):
+        x[ids[k] - 1] = pos[k]
+        v[ids[k] - 1] = vel[k]
+    return x, v, np.array(prd)
+
+
+def _make_arrays_scaled(cells, a, jitter, vscale, seed, scale):
+    nx, ny, nz = cells
+    rng = _Lcg(seed)
+    basis = ((0.0, 0.0, 0.0), (0.5, 0.5, 0.0), (0.5, 0.0, 0.5), (0.0, 0.5, 0.5))
+    ad = (a * scale[0], a * scale[1], a * scale[2])
+    prd = (nx * ad[0], ny * ad[1], nz * ad[2])
+    pos = []
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                for b in basis:
+                    p = []
+                    for d, (c, off) in enumerate(zip((i, j, k), b)):
+                        q = (c + off) * ad[d] + (rng.u() - 0.5) * 2.0 * jitter * ad[d]
+                        if q < 0.0:
+                            q += prd[d]
+                        if q >= prd[d]:
+                            q -= prd[d]
+                        p.append(q)
+                    pos.append(p)
+    n = len(pos)
+    vel = [[(rng.u() - 0.5) * 2.0 * vscale for _ in range(3)] for _ in range(n)]
+    for d in range(3):
+        m = 0.0
+        for i in range(n):
+            m += vel[i][d]
+        m = m * (1.0 / n)
+        for i in range(n):
+            vel[i][d] -= m
     ids = list(range(1, n + 1))
     for k in range(n - 1, 0, -1):
         r = int(rng.u() * (k + 1))

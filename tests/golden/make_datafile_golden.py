@@ -23,6 +23,8 @@ RUNS = [
     ("lj_5x6x7", "dp", ["-i", "in.lj.miniMD", "-n", "100", "--half_neigh", "0", "-b", "4"]),
     ("lj_5x6x7", "sp", ["-i", "in.lj.miniMD", "-n", "200", "--half_neigh", "0"]),
     ("eam_4x5x5", "dp", ["-i", "in.eam.miniMD", "-n", "100", "--half_neigh", "0"]),
+    ("lj_thin_1x6x7", "dp", ["-i", "in.lj.miniMD", "-n", "100", "--half_neigh", "0"]),
+    ("lj_thin_1x6x7", "dp", ["-i", "in.lj.miniMD", "-n", "100", "--half_neigh", "1"]),
 ]
 
 

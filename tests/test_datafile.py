@@ -117,6 +117,10 @@ def test_run_from_data_file_matches_reference_rows(files, run):
     p = files[run["case"]][0]
     s = minimd_amd.Sim(run["args"] + ["-f", p], precision=run["precision"])
     assert s.natoms() == run["natoms"]
+    if "thin" in run["case"]:
+        # a box thinner than half the cutoff: three ghost layers in x (ref/comm.cpp:150-152). A ghost's image code holds at most +-2 box
+        # lengths, so the root + image shortcuts (one-kernel ghost update, ghosts staged from their owners) must stay off here
+        assert s.handle.comm_info()["need"].tolist() == [3, 1, 1]
     s.initial(); s.run()
     rows_close(s.rows(), run["rows"], 2e-6 if run["precision"] == "dp" else 2e-4)
     nl, ng, _ = s.handle.counts()
