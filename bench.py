@@ -186,7 +186,7 @@ def main():
         k, v = kv.split("=")
         sim.handle.set_option(k, int(v))
     # the force kernel's clock: every launch of a short timed region (<= 50 steps), every 3rd one of a long run (library default)
-    timed_every = 1 if args.steps <= 50 else 3
+    timed_every = 1 if (args.steps <= 50 or args.size >= 48) else 3
     sim.handle.set_option("time_force_sample", timed_every)
     sim.initial()
     if args.equil > 0:

@@ -187,7 +187,10 @@ static int force_compute_async(mmd_handle* h, int evflag, double* eng, double* v
   if(timed) {
     // the kernel clock is read on every `time_force_sample`-th call of a run (3: coprime with the re-neighboring and thermo
     // periods, so every kind of step is sampled in proportion); TIME_FORCE = mean of the timed calls x number of calls
-    timed = h->opt_time_sample <= 1 || h->force_calls % h->opt_time_sample == 0;
+    // (time_force_sample 0 = automatic: every call where a launch is long — the pair attached to a dispatch then costs nothing that
+    //  shows —, every 3rd call on small systems, where it is ~15 % of a step)
+    const int every = h->opt_time_sample > 0 ? h->opt_time_sample : (h->ntiles > 8192 || h->nlocal > 600000 ? 1 : 3);
+    timed = every <= 1 || h->force_calls % every == 0;
     h->force_calls++;
   }
   if(timed && h->time_force_events && h->style == 0 && !h->halfneigh && !h->halo_pending && mmd_lj_tiles_available(h)) {
