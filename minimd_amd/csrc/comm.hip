@@ -903,12 +903,13 @@ __global__ __launch_bounds__(256) void k_ghost_types(const real4* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------------
-// One-rank fast path of Comm::borders: every swap is a periodic self swap, so nothing but the final counts has to reach the
-// host. The six swaps run as count / scatter kernel pairs whose ranges, offsets and running ghost count live in device
-// memory (`bst`), sized by the previous re-neighboring's counts (+50 %); ONE synchronisation at the end reads the counts and an
-// overflow flag (then the general path below redoes the work with grown arrays). Same selections in the same order as
-// the general path => identical send lists and ghosts. bst layout (ints):
-//   [0] nb = owned atoms inside any send slab   [1] overflow flag   [4+s] sendnum of swap s   [30+s] ghosts before swap s
+// Device-resident Comm::borders (six swaps, need = 1 in every dimension): nothing but the final counts has to reach the host.
+// The swaps run as count / scatter kernel pairs whose ranges, offsets and running ghost count live in device memory (`bst`),
+// sized by the previous re-neighboring's counts (+50 %); ONE synchronisation at the end (or none: the neighbor build's own
+// read-back brings bst along) returns the counts and an overflow flag (then the swap-by-swap path below redoes the work with grown
+// arrays). A periodic self swap writes its ghosts in place, a swap with another rank goes through a fixed-size message (below).
+// Same selections in the same order as the swap-by-swap path => identical send lists and ghosts. bst layout (ints):
+//   [0] nb = owned atoms inside any send slab   [1] overflow flag   [4+s] sendnum of swap s   [12+s] recvnum   [30+s] ghosts before swap s
 // ---------------------------------------------------------------------------------------------------
 #define BST_NB 0
 #define BST_OVF 1
@@ -1105,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_border_unpack(real4* __restrict__ x, in
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
 static int borders_fast_finish(mmd_handle* h);
 
-static int borders_one_rank_fast(mmd_handle* h, bool defer)
+static int borders_device_resident(mmd_handle* h, bool defer)
 {
   if(!h->opt_borders_fast || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0) return 0;
   if(h->nprocs == 1 && !h->opt_force_transport && h->nlocal <= 4096) return 0;
@@ -1248,7 +1249,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   h->nghost_dev = nullptr;
   {
     const bool defer = h->in_reneighbor && h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && h->neigh_ready;
-    const int rc = borders_one_rank_fast(h, defer);
+    const int rc = borders_device_resident(h, defer);
     if(rc < 0) return rc;
     if(rc == 1) MMD_TRY(mmd_set_dummy(h));
     if(rc >= 1) {
