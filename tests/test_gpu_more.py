@@ -1039,3 +1039,24 @@ def test_exchange_all_moves_atoms_two_subdomains_like_the_oracle(port, tmp_path)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert sum(len(q["x"]) for q in json.load(open(out2))) < total
+
+
+@pytest.mark.gpu
+def test_pencil_tiles_are_full_wavefronts():
+    """the production tiles are 64-atom pieces of an x-sorted row of blocks: at LJ liquid density more than 60 of the 64
+    lanes of a tile hold an atom (one-block tiles: 57), every owned atom sits in exactly one tile, and the list is the oracle's"""
+    import minimd_amd
+    s = minimd_amd.Sim(["-s", "24", "-n", "40", "--half_neigh", "0"], quiet=True)
+    s.initial(); s.run()
+    st = s.handle.neighbor_tile_stats()
+    nl, ng, _ = s.handle.counts()
+    assert st["sum_atoms"] >= nl and st["sum_atoms"] <= nl + ng
+    assert st["sum_atoms"] / st["tiles"] >= 59.0, st          # (9 tiles per 564-atom pencil at this size; 63 at -s 80)
+    hc, hr = s.handle.neighbor_tile_histogram(64, 16)
+    assert sum(hc) == st["tiles"] == sum(hr)
+    o = Oracle(["-s", "24", "-n", "40", "--half_neigh", "0"])
+    o.initial(); o.run()
+    assert s.handle.neighbor_info()["total"] == int(o.numneigh().sum())
+    nb, nn = s.handle.neighbor_download()
+    assert int(nn.sum()) == int(o.numneigh().sum())
+    s.close(); o.close()
