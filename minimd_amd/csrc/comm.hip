@@ -935,34 +935,55 @@ __device__ __forceinline__ bool in_any_slab(const real4 p, const SlabSet& S)
   return in;
 }
 
+// (both kernels read x the way it lies in memory: wavefront w of a workgroup takes atoms [256 w, 256 w + 256) of the workgroup's 1024 in four
+//  rounds of 64 consecutive atoms — whole lines per load instruction — and orders its hits with ballots; four atoms per thread at a
+//  stride of 128 bytes between the lanes ran at 2.2 TB/s)
 __global__ __launch_bounds__(256) void k_bnd_count(const real4* __restrict__ x, int nlocal, SlabSet S, int* __restrict__ cnt, int* __restrict__ bst)
 {
-  __shared__ int lds[17];
+  __shared__ int s_w[4];
   if(blockIdx.x == 0 && threadIdx.x < 64) bst[threadIdx.x] = 0;          // the state words of this borders pass (first written by k_bnd_scatter)
-  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
   int c = 0;
 #pragma unroll
-  for(int k = 0; k < 4; k++) if(base + k < nlocal) c += in_any_slab(x[base + k], S) ? 1 : 0;
-  int tot;
-  block_incl_scan(c, lds, &tot);
-  if(threadIdx.x == 0) cnt[blockIdx.x] = tot;
+  for(int r = 0; r < 4; r++) {
+    const int i = base + r * 64;
+    const bool in = i < nlocal && in_any_slab(x[i < nlocal ? i : 0], S);
+    c += __popcll(__builtin_amdgcn_ballot_w64(in));
+  }
+  if(lane == 0) s_w[wave] = c;
+  __syncthreads();
+  if(threadIdx.x == 0) cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 __global__ __launch_bounds__(256) void k_bnd_scatter(const real4* __restrict__ x, int nlocal, SlabSet S, const int* __restrict__ cnt,
                                                      int* __restrict__ bnd, int* __restrict__ bst, int est_nb)
 {
   __shared__ int lds[17];
+  __shared__ int s_w[4];
   const int off = block_prefix_total(cnt, blockIdx.x, lds);
-  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
-  bool fl[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
+  unsigned long long m[4];
   int c = 0;
 #pragma unroll
-  for(int k = 0; k < 4; k++) { fl[k] = base + k < nlocal && in_any_slab(x[base + k], S); c += fl[k] ? 1 : 0; }
-  int tot;
-  const int inc = block_incl_scan(c, lds, &tot);
-  int pos = off + inc - c;
+  for(int r = 0; r < 4; r++) {
+    const int i = base + r * 64;
+    const bool in = i < nlocal && in_any_slab(x[i < nlocal ? i : 0], S);
+    m[r] = __builtin_amdgcn_ballot_w64(in);
+    c += __popcll(m[r]);
+  }
+  if(lane == 0) s_w[wave] = c;
+  __syncthreads();
+  int pos = off;
+  for(int w = 0; w < wave; w++) pos += s_w[w];
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-  for(int k = 0; k < 4; k++) if(fl[k]) bnd[pos++] = base + k;
+  for(int r = 0; r < 4; r++) {
+    if((m[r] >> lane) & 1ull) bnd[pos + __popcll(m[r] & below)] = base + r * 64;
+    pos += __popcll(m[r]);
+  }
   if(blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     bst[BST_NB] = off + tot;
     if(off + tot > est_nb) bst[BST_OVF] = 1;        // (the swap kernels' grids were sized for est_nb boundary atoms)
   }
@@ -979,20 +1000,26 @@ __global__ __launch_bounds__(256) void k_swap_count(const real4* __restrict__ x,
   const int y = blockIdx.y;
   const real lo = P.lo[y], hi = P.hi[y];
   const int nb = bst[BST_NB], n = nb + bst[BST_GHOSTS + sw0];
-  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  // (wavefront w takes candidates [256 w, 256 w + 256) of the workgroup's 1024 in four rounds of 64 consecutive ones, see k_bnd_count)
+  __shared__ int s_w[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
   int c = 0;
 #pragma unroll
-  for(int k = 0; k < 4; k++) {
-    const int q = base + k;
+  for(int r = 0; r < 4; r++) {
+    const int q = base + r * 64;
+    bool in = false;
     if(q < n) {
       const real4 p = x[q < nb ? bnd[q] : nlocal + (q - nb)];
       const real v = dim == 0 ? p.x : (dim == 1 ? p.y : p.z);
-      c += (v >= lo && v <= hi) ? 1 : 0;
+      in = v >= lo && v <= hi;
     }
+    c += __popcll(__builtin_amdgcn_ballot_w64(in));
   }
-  int tot;
-  block_incl_scan(c, lds, &tot);
-  if(threadIdx.x == 0) cnt[y * ncnt + blockIdx.x] = tot;
+  if(lane == 0) s_w[wave] = c;
+  __syncthreads();
+  if(threadIdx.x == 0) cnt[y * ncnt + blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  (void)lds;
 }
 template <bool REMOTE>
 __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, const int* __restrict__ bnd, int* __restrict__ bst, int nlocal,
@@ -1013,14 +1040,17 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
   real4* __restrict__ m_rec = REMOTE ? (real4*)(P.msg[y] + BMSG_HEADER) : nullptr;
   int* __restrict__ m_img = REMOTE ? (int*)(P.msg[y] + BMSG_HEADER + (size_t)P.cap_msg[y] * sizeof(real4)) : nullptr;
   const int off = block_prefix_total(cnt + y * ncnt, blockIdx.x, lds);
-  const int base = blockIdx.x * CP_TILE + threadIdx.x * 4;
+  __shared__ int s_w[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
   bool fl[4];
   int idx[4];
   real4 pp[4];
+  unsigned long long mk[4];
   int c = 0;
 #pragma unroll
   for(int k = 0; k < 4; k++) {
-    const int q = base + k;
+    const int q = base + k * 64;
     fl[k] = false; idx[k] = 0;
     if(q < n) {
       idx[k] = q < nb ? bnd[q] : nlocal + (q - nb);
@@ -1028,15 +1058,21 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
       const real v = dim == 0 ? pp[k].x : (dim == 1 ? pp[k].y : pp[k].z);
       fl[k] = v >= lo && v <= hi;
     }
-    c += fl[k] ? 1 : 0;
+    mk[k] = __builtin_amdgcn_ballot_w64(fl[k]);
+    c += __popcll(mk[k]);
   }
-  int tot;
-  const int inc = block_incl_scan(c, lds, &tot);
-  int pos = off + inc - c;
+  if(lane == 0) s_w[wave] = c;
+  __syncthreads();
+  const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  int wpos = off;
+  for(int w = 0; w < wave; w++) wpos += s_w[w];
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   bool ovf = false;
   int* __restrict__ sendlist = P.sendlist[y];
 #pragma unroll
   for(int k = 0; k < 4; k++) {
+    const int pos = wpos + __popcll(mk[k] & below);
+    wpos += __popcll(mk[k]);
     if(fl[k]) {
       if(REMOTE) {                              // Atom::pack_border (ref/atom.cpp:197-214) into the message of this swap
         if(pos < P.cap_list[y] && pos < P.cap_msg[y]) {
@@ -1059,7 +1095,6 @@ __global__ __launch_bounds__(256) void k_swap_scatter(real4* __restrict__ x, con
         ghost_root[nghost + pos] = i < nlocal ? i : ghost_root[i - nlocal];
         type[nall + pos] = (int)p.w;
       } else ovf = true;
-      pos++;
     }
   }
   if(ovf) bst[BST_OVF] = 1;
