@@ -449,7 +449,7 @@ __global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, cons
                             real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if(b == 0) { flags[1] = 0; flags[3] = 0; flags[7] = 0; }     // (result flags of the build kernel that follows on the stream)
+  if(b == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[7] = 0; }     // (result flags of the build kernel and accumulators of k_tile_reduce, which follow on the stream)
   // deferred one-rank borders: the dummy atom (far outside any cutoff, see k_set_dummy) goes behind the last ghost, whose number only the device knows yet
   if(b == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
   if(b >= nblocks) return;
@@ -492,7 +492,7 @@ __global__ void k_pencil_fill(const int* __restrict__ pencil_range, int npencils
                               real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if(p == 0) { flags[1] = 0; flags[3] = 0; flags[7] = 0; }     // (result flags of the build kernel that follows on the stream)
+  if(p == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[7] = 0; }     // (result flags of the build kernel and accumulators of k_tile_reduce, which follow on the stream)
   if(p == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};    // the dummy atom, see k_tile_fill
   if(p >= npencils) return;
   const int t0 = tile_of_pencil[p], t1 = tile_of_pencil[p + 1];
@@ -1172,19 +1172,21 @@ __global__ __launch_bounds__(1024) void k_tile_reduce(const int* __restrict__ ti
                                                       unsigned long long* __restrict__ total_out, const int* __restrict__ ntiles_dev,
                                                       const int* __restrict__ bst)
 {
+  // a few workgroups, one slice of the tiles each, three atomics per workgroup into words k_tile_fill / k_pencil_fill zeroed
+  // (one workgroup walking all 32 k tiles took 20 us)
   __shared__ int s_a[16], s_b[16];
-  if(bst && threadIdx.x < 40) flags[16 + threadIdx.x] = bst[threadIdx.x];          // deferred one-rank borders: its counts travel with the flags
-  if(ntiles_dev) { if(threadIdx.x == 0) flags[6] = *ntiles_dev; ntiles = min(ntiles, *ntiles_dev); }     // flags[6]: the count for the host
+  if(blockIdx.x == 0 && bst && threadIdx.x < 40) flags[16 + threadIdx.x] = bst[threadIdx.x];          // deferred one-rank borders: its counts travel with the flags
+  if(ntiles_dev) { if(blockIdx.x == 0 && threadIdx.x == 0) flags[6] = *ntiles_dev; ntiles = min(ntiles, *ntiles_dev); }     // flags[6]: the count for the host
   __shared__ long long s_c[16];
   int a = 0, b = 0;
   long long c = 0;
-  for(int t = threadIdx.x; t < ntiles; t += blockDim.x) { a = max(a, tile_rowmax[t]); b = max(b, tile_ncand[t]); c += tile_rowsum[t]; }
+  for(int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) { a = max(a, tile_rowmax[t]); b = max(b, tile_ncand[t]); c += tile_rowsum[t]; }
   a = wave_max_i(a); b = wave_max_i(b); c = wave_sum(c);
   if((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; s_c[threadIdx.x >> 6] = c; }
   __syncthreads();
   if(threadIdx.x == 0) {
     for(int w = 1; w < (int)(blockDim.x >> 6); w++) { a = max(a, s_a[w]); b = max(b, s_b[w]); c += s_c[w]; }
-    flags[0] = a; flags[2] = b; *total_out = (unsigned long long)c;
+    atomicMax(&flags[0], a); atomicMax(&flags[2], b); atomicAdd(total_out, (unsigned long long)c);
   }
 }
 
@@ -1392,7 +1394,8 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     bool order_here = false;
     for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
       MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 16 * 64, false, h->stream));   // (+ prefetch overrun of the last tile)
-      if(h->opt_build != 1) {             // (the production kernel needs no zeroing: k_tile_fill / k_tile_reduce write every flag)
+      if(h->opt_build == 1 && attempt > 0) HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));     // (a relaunch with longer rows: k_pencil_fill's zeroes are used up)
+      if(h->opt_build != 1) {             // (the production kernel needs no zeroing: k_tile_fill / k_pencil_fill zero what it and k_tile_reduce accumulate)
         HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
         HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
       }
@@ -1413,7 +1416,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
                      core_thr, h->xbuild.p, h->tile_kcore.p)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
-        hipLaunchKernelGGL(k_tile_reduce, dim3(1), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
+        hipLaunchKernelGGL(k_tile_reduce, dim3(std::min(32, std::max(1, div_up(h->ntiles, 1024)))), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
                            h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr);
         order_here = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport) && h->ntiles > 0;
         if(order_here) {                  // several ranks: the interior-first order of the halo overlap, no extra host synchronisation
