@@ -844,12 +844,13 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // tile's owned atoms — ONE contiguous run of binned[] (a pencil is sorted by x-slice): [slice(xmin - cutneigh), slice(xmax + cutneigh)]
   const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
   const int nr = min(ny * nz, 128);
+  // x-range of the tile's owned atoms (float keys, DPP ladder: the same reduction the bounding box below uses; the float rounding of
+  // a coordinate is far inside the margin of reach_x)
+  const unsigned kx = float_key((float)pme.x);
+  const float bx0 = key_float(wave_min_u(owned ? kx : 0xffffffffu)), bx1 = key_float(wave_max_u(owned ? kx : 0u));
   {
-    const real big = (real)3.0e38;
-    real xlo = owned ? pme.x : big, xhi = owned ? pme.x : -big;
-#pragma unroll
-    for(int o = 32; o > 0; o >>= 1) { xlo = fmin(xlo, __shfl_xor(xlo, o, 64)); xhi = fmax(xhi, __shfl_xor(xhi, o, 64)); }
-    const real reach_x = cutneigh * (real)1.0005 + (real)1.0e-4 * g.binsize[0];
+    const real xlo = (real)bx0, xhi = (real)bx1;
+    const real reach_x = cutneigh * (real)1.0005 + (real)1.0e-4 * g.binsize[0] + (real)1.0e-5 * (fabs((real)bx0) + fabs((real)bx1));
     const int fmaxx = 2 * NB_XF * g.nblk[0] - 1;
     const int f0 = min(max(fine_x_of(g, xlo - reach_x), 0), fmaxx), f1 = min(max(fine_x_of(g, xhi + reach_x), 0), fmaxx);
     for(int r0 = 0; r0 < nr; r0 += 64) {
@@ -877,8 +878,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     return;
   }
   // bounding box of the tile's owned atoms (float, conservative through the margin of `cull`)
-  const unsigned kx = float_key((float)pme.x), ky = float_key((float)pme.y), kz = float_key((float)pme.z);
-  const float bx0 = key_float(wave_min_u(owned ? kx : 0xffffffffu)), bx1 = key_float(wave_max_u(owned ? kx : 0u));
+  const unsigned ky = float_key((float)pme.y), kz = float_key((float)pme.z);
   const float by0 = key_float(wave_min_u(owned ? ky : 0xffffffffu)), by1 = key_float(wave_max_u(owned ? ky : 0u));
   const float bz0 = key_float(wave_min_u(owned ? kz : 0xffffffffu)), bz1 = key_float(wave_max_u(owned ? kz : 0u));
   const float cull = (float)cutneighsq * 1.001f + 1.0e-4f;
