@@ -81,6 +81,9 @@ def sim(out, args, precision, rccl=False):
         tr = GlooTransport()
         api.sim_set_host_transport(tr.sendrecv, tr.allreduce, precision)
     s = minimd_amd.Sim(args, precision=precision)
+    for kv in filter(None, os.environ.get("MMD_TEST_OPTIONS", "").split(",")):      # e.g. borders_est=60: undersized ghost arrays
+        k, v = kv.split("=")
+        s.handle.set_option(k, int(v))
     s.initial()
     s.run()
     nl, ng, _ = s.handle.counts()

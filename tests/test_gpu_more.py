@@ -1060,3 +1060,31 @@ def test_pencil_tiles_are_full_wavefronts():
     nb, nn = s.handle.neighbor_download()
     assert int(nn.sum()) == int(o.numneigh().sum())
     s.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_undersized_ghost_arrays_on_several_ranks_fall_back_together(port, tmp_path):
+    """the device-resident borders of several ranks with ghost arrays sized for 60 % of the previous count: the overflow flag is
+    raised on the device, max-reduced over the ranks, and EVERY rank redoes the borders swap by swap (a mix of paths would dead-lock
+    or mis-match messages). Rows and per-rank counts must be those of the normal run."""
+    args = ["-s", "8", "-n", "60", "--half_neigh", "0"]
+    base = sim_rows(args)
+    out = str(tmp_path / "mp.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MMD_TEST_OPTIONS="borders_est=60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "sim", out, "dp"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    rows = [tuple(x) for x in res["rows"]]
+    assert [r_[0] for r_ in rows] == [b[0] for b in base]
+    for a, b in zip(rows, base):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+    o = Oracle(args, nprocs=2)
+    o.initial(); o.run()
+    assert [o.nlocal(0), o.nlocal(1)] == [c[0] for c in res["counts"]]
+    assert [o.nghost(0), o.nghost(1)] == [c[1] for c in res["counts"]]
+    o.close()
+    # (every re-neighboring took the fall-back: the swap-by-swap path waits for its counts)
+    assert all(st["host_syncs"] > 3 * 6 for st in res["stats"]), res["stats"]
