@@ -124,7 +124,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # control plane only; a short timeout so that a rank that died does not park the others for the default half hour
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
+        # (gloo announces its connections on the C++ stdout: keep stdout for the ONE JSON line, send that chatter to stderr)
+        sys.stdout.flush()
+        _saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
+            dist.barrier()
+        finally:
+            os.dup2(_saved, 1)
+            os.close(_saved)
         ndev = max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank % ndev)
         if ndev < world and "MMD_BENCH_TRANSPORT" not in os.environ:
