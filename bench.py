@@ -64,6 +64,22 @@ def cpu_baseline(size, nsteps):
         return {"value": None, "unit": "Matom-steps/s", "cores": cores, "kind": kind, "sample": "failed: %r" % (e,)}
 
 
+class stdout_to_stderr:
+    """libraries that talk on the C stdout (gloo's connection report, RCCL's version banner) must not get in front of the ONE JSON
+    line: while this is active file descriptor 1 points at stderr"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def perf_summary_cold(size):
     """what a user of the drop-in executable sees: `miniMD_dp -i in.lj.miniMD -s <size> --half_neigh 0` as a fresh process (cold GPU clocks,
     no equilibration, no warm-up, the deck's 100 steps) and the value of its own PERF_SUMMARY line = natoms*ntimes/t_total of
@@ -125,15 +141,9 @@ def main():
         import datetime
         # control plane only; a short timeout so that a rank that died does not park the others for the default half hour
         # (gloo announces its connections on the C++ stdout: keep stdout for the ONE JSON line, send that chatter to stderr)
-        sys.stdout.flush()
-        _saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
             dist.barrier()
-        finally:
-            os.dup2(_saved, 1)
-            os.close(_saved)
         ndev = max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank % ndev)
         if ndev < world and "MMD_BENCH_TRANSPORT" not in os.environ:
@@ -169,7 +179,8 @@ def main():
     sim_args = ["-i", "in.lj.miniMD", "-nx", nx, "-ny", ny, "-nz", nz, "--half_neigh", "0", "-n", args.steps]
     sim, err = None, None
     try:
-        sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
+        with stdout_to_stderr():          # (ncclCommInitRank prints RCCL's version banner)
+            sim = minimd_amd.Sim(sim_args, precision="dp", quiet=True)
     except Exception as e:  # noqa: BLE001
         if dist is None or os.environ.get("MMD_BENCH_TRANSPORT") == "gloo":
             raise
