@@ -405,7 +405,12 @@ __device__ __forceinline__ float rsqrt_fast(float a)
 #ifndef EAM_FU
 #define EAM_FU 4              // pairs per trip of the force sweep (+ one trip of EAM_TU where 4 rows remain)
 #endif
-#define EAM_STAGE 4
+#ifndef EAM_STAGE
+#define EAM_STAGE 2              // candidates per thread and staging round: unions hold 300-500 candidates, a workgroup 256 threads (4: two all-dummy loads per thread and tile, +7 %)
+#endif
+#ifndef EAM_FWAVES
+#define EAM_FWAVES 3            // wavefronts per SIMD the force sweep is compiled for (<= 168 VGPRs): its DP variants need 162-182 registers, and the knot table lets
+#endif                        // 3 workgroups = 3 wavefronts per SIMD onto a CU anyway — a variant that ends at 170 would run with 2 (measured: 0.29 -> 0.37 ms per step)
 #ifndef EAM_RD
 #define EAM_RD (MMD_PRECISION == 2 ? 1 : 0)      // DP: the three position reads of a pair stay separate ds_read_b64 (ds_read2_b64 runs at half the LDS rate: -1.7 %)
 #endif
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
 // k_eam_density_tile); a ghost partner gets no force and the pair counts half in energy and virial (:244-257). f was zeroed
 // beforehand; partials = {sum phi, virial} per tile.
 template <int EV, int FUSE, int HALF>
-__global__ __launch_bounds__(64 * EAM_FW) void k_eam_force_tile(
+__global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HALF ? 2 : EAM_FWAVES))) void k_eam_force_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
