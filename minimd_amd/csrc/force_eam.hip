@@ -476,25 +476,16 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   if(witem >= ntiles) break;
   const int tile = tile_list ? tile_list[witem] : witem;
   __syncthreads();                                      // previous tile's readers are done with s_pos / s_part
-  const int ncand = tile_ncand[tile];
-  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int t0 = 0; t0 <= ncand && !(MMD_ABLATE(C.ablate) & 1); t0 += EAM_STAGE * NT) {  // branch-free: cl[ncand] holds the dummy atom's index
-    int tt[EAM_STAGE], jj[EAM_STAGE];
-#pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
-    real4 pp[EAM_STAGE];
-#pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) pp[u] = x[jj[u]];
-#pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) {
-      s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z;
-      if(HALF) { s_racc[tt[u]] = 0; s_idx[tt[u]] = jj[u]; }
-    }
-  }
-  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
-  if(i >= nlocal) i = -1;
-  const real4 xi = x[i >= 0 ? i : 0];
+  // The tile's loads in three round trips instead of six: header scalars; then candidate indices, own atom index and first slots
+  // together; then the positions. (2-3 workgroups per CU — the knot table bounds the occupancy — hide little of a longer chain.)
+  const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
+  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  const bool stage = !(MMD_ABLATE(C.ablate) & 1);
+  int tt[EAM_STAGE], jj[EAM_STAGE];
+#pragma unroll
+  for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = cl[tt[u]]; }     // branch-free: cl[ncand] holds the dummy atom's index
+  int i = lane < cnt ? binned[first + lane] : -1;
   const int per = ((kmax / EAM_TU + EAM_TW - 1) / EAM_TW) * EAM_TU;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
   const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
@@ -504,6 +495,24 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   if(k0 < k1) {
 #pragma unroll
     for(int u = 0; u < EAM_TU; u++) sl[u] = np[u * 64];
+  }
+  real4 pp[EAM_STAGE];
+#pragma unroll
+  for(int u = 0; u < EAM_STAGE; u++) pp[u] = x[jj[u]];
+  if(i >= nlocal) i = -1;
+  const real4 xi = x[i >= 0 ? i : 0];
+  if(stage) {
+#pragma unroll
+    for(int u = 0; u < EAM_STAGE; u++) {
+      s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z;
+      if(HALF) { s_racc[tt[u]] = 0; s_idx[tt[u]] = jj[u]; }
+    }
+    for(int t0 = EAM_STAGE * NT; t0 <= ncand; t0 += NT) {          // (a union beyond EAM_STAGE * NT candidates: rare)
+      const int t = min(t0 + tid, ncand), j = cl[t];
+      const real4 p = x[j];
+      s_pos[3 * t] = p.x; s_pos[3 * t + 1] = p.y; s_pos[3 * t + 2] = p.z;
+      if(HALF) { s_racc[t] = 0; s_idx[t] = j; }
+    }
   }
   __syncthreads();
   drain_loads();                                      // (see tile_lds.hpp: lets the slot prefetch of the pair loop really overlap)
@@ -620,34 +629,18 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   if(witem >= ntiles) break;
   const int tile = tile_list ? tile_list[witem] : witem;
   __syncthreads();
-  const int ncand = tile_ncand[tile];
-  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int t0 = 0; t0 <= ncand && !(MMD_ABLATE(C.ablate) & 1); t0 += EAM_STAGE * NT) {
-    int tt[EAM_STAGE], jj[EAM_STAGE];
-#pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
-    real4 pp[EAM_STAGE];
-    real ff[EAM_STAGE];
-#pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) {
-      pp[u] = x[jj[u]];
-      // one rank: a ghost is an image of an owned atom, its fp is its owner's (ForceEAM::communicate, ref/force_eam.cpp:851-913, folded
-      // into the staging: no fp halo launch between the two sweeps)
-      const int jf = (fp_root != nullptr && jj[u] >= nlocal && jj[u] < nall) ? fp_root[jj[u] - nlocal] : jj[u];
-      ff[u] = fp[jf];
-    }
-#pragma unroll
-    for(int u = 0; u < EAM_STAGE; u++) {
-      s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; s_fp[tt[u]] = ff[u];
-      if(HALF) { s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0; s_idx[tt[u]] = jj[u]; }
-      if(HALF && EV) s_gh[tt[u]] = jj[u] >= nlocal ? 1 : 0;
-    }
-  }
-  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
-  if(i >= nlocal) i = -1;
-  const real4 xi = x[i >= 0 ? i : 0];
-  const real fpi = fp[i >= 0 ? i : 0];
+  // three round trips (see k_eam_density_tile): header; indices + own atom + first slots; positions + fp
+  const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
+  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  const bool stage = !(MMD_ABLATE(C.ablate) & 1);
+  // one rank: a ghost is an image of an owned atom, its fp is its owner's (ForceEAM::communicate, ref/force_eam.cpp:851-913, folded
+  // into the staging: no fp halo launch between the two sweeps)
+  auto fp_index = [&](int j) { return (fp_root != nullptr && j >= nlocal && j < nall) ? fp_root[j - nlocal] : j; };
+  int tt[EAM_STAGE], jj[EAM_STAGE];
+#pragma unroll
+  for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
+  int i = lane < cnt ? binned[first + lane] : -1;
   // the rows (a multiple of 4) are dealt to the wavefronts two at a time: 52 rows = 14,14,12,12 instead of 16,16,16,4 — the slowest
   // wavefront is the tile's critical path
   const int hq = kmax >> 1, hbase = hq / EAM_FW, hrem = hq - hbase * EAM_FW;
@@ -659,6 +652,29 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   if(k0 < k1) {                                   // (a slice of 4 rows reads 4 entries past it: in bounds — nl16 ends with 16 spare rows — and unused)
 #pragma unroll
     for(int u = 0; u < EAM_FU; u++) sl[u] = np[u * 64];
+  }
+  real4 pp[EAM_STAGE];
+  real ff[EAM_STAGE];
+#pragma unroll
+  for(int u = 0; u < EAM_STAGE; u++) { pp[u] = x[jj[u]]; ff[u] = fp[fp_index(jj[u])]; }
+  if(i >= nlocal) i = -1;
+  const real4 xi = x[i >= 0 ? i : 0];
+  const real fpi = fp[i >= 0 ? i : 0];
+  if(stage) {
+#pragma unroll
+    for(int u = 0; u < EAM_STAGE; u++) {
+      s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; s_fp[tt[u]] = ff[u];
+      if(HALF) { s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0; s_idx[tt[u]] = jj[u]; }
+      if(HALF && EV) s_gh[tt[u]] = jj[u] >= nlocal ? 1 : 0;
+    }
+    for(int t0 = EAM_STAGE * NT; t0 <= ncand; t0 += NT) {          // (a union beyond EAM_STAGE * NT candidates: rare)
+      const int t = min(t0 + tid, ncand), j = cl[t];
+      const real4 p = x[j];
+      const real fj = fp[fp_index(j)];
+      s_pos[3 * t] = p.x; s_pos[3 * t + 1] = p.y; s_pos[3 * t + 2] = p.z; s_fp[t] = fj;
+      if(HALF) { s_acc[3 * t] = 0; s_acc[3 * t + 1] = 0; s_acc[3 * t + 2] = 0; s_idx[t] = j; }
+      if(HALF && EV) s_gh[t] = j >= nlocal ? 1 : 0;
+    }
   }
   __syncthreads();
   drain_loads();

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   const int witem = xcd_work_item(ntiles);
   if(witem < 0) return;                          // (grid is padded to a multiple of 8)
   const int tile = tile_list ? tile_list[witem] : witem;
-  const int ncand = tile_ncand[tile];
+  // The tile's loads are issued as three round trips — header scalars; candidate indices + own atom index + first slots; positions —
+  // not as the six a straight reading of the steps below would make (indices -> positions -> LDS, then atom index -> position, then slots).
+  const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];     // a tile never straddles pencils
+  const int kmax = (ablate & 2) ? 0 : tile_max[tile];
+  const bool ghosted = G.root != nullptr && G.tile_ghost[tile] != 0;       // (workgroup-uniform) boundary tile of a one-rank run: ghosts from their owners
   // ---- stage the positions of the tile's candidate union (+1 dummy slot) into LDS: {x,y,z} records of
   // 3 reals (stride 3 is coprime with the bank count: random slots spread over all banks, one address per pair)
   real* sp = (real*)s_raw;
@@ -203,24 +207,11 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   // Branch-free: the build stores the dummy atom's index at cl[ncand], lanes past the end clamp to that entry
   // and (re)write the same dummy record, so one pass of 512 records covers almost every tile (unions hold ~450 atoms at LJ liquid density).
   constexpr int STG = 512 / LJ_TILE_THREADS;
-  for(int t0 = 0; t0 <= ncand && !(ablate & 1); t0 += 512) {
-    int tt[STG], jj[STG];
+  int tt[STG], jj[STG];
 #pragma unroll
-    for(int u = 0; u < STG; u++) { tt[u] = min(t0 + u * LJ_TILE_THREADS + tid, ncand); jj[u] = cl[tt[u]]; }
-    real4 pp[STG];
-    if(G.root != nullptr && G.tile_ghost[tile] != 0) {       // (workgroup-uniform) boundary tile of a one-rank run: ghosts from their owners
-#pragma unroll
-      for(int u = 0; u < STG; u++) pp[u] = ghost_resolved(x, jj[u], nlocal, nall, G);
-    } else {
-#pragma unroll
-      for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
-    }
-#pragma unroll
-    for(int u = 0; u < STG; u++) { sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z; }
-  }
+  for(int u = 0; u < STG; u++) { tt[u] = min(u * LJ_TILE_THREADS + tid, ncand); jj[u] = cl[tt[u]]; }
   // ---- my atom and my slice of its neighbor row (wave w takes k in [k0,k1))
-  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;     // a tile never straddles blocks
-  const int kmax = (ablate & 2) ? 0 : tile_max[tile];
+  int i = lane < cnt ? binned[first + lane] : -1;
   // rows are padded to a multiple of 4 (NB_ROW_PAD): the wave slices are multiples of 4, run as trips of UNR pairs plus,
   // where 4 rows remain, one half trip
   constexpr int QR = 4;
@@ -234,8 +225,25 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
 #pragma unroll
     for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
   }
+  real4 pp[STG];
+  if(ghosted) {
+#pragma unroll
+    for(int u = 0; u < STG; u++) pp[u] = ghost_resolved(x, jj[u], nlocal, nall, G);
+  } else {
+#pragma unroll
+    for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
+  }
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
+  if(!(ablate & 1)) {
+#pragma unroll
+    for(int u = 0; u < STG; u++) { sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z; }
+    for(int t0 = 512; t0 <= ncand; t0 += LJ_TILE_THREADS) {        // (a union beyond 512 candidates: 2 % of the tiles at -s 80)
+      const int t = min(t0 + tid, ncand), j = cl[t];
+      const real4 p = ghosted ? ghost_resolved(x, j, nlocal, nall, G) : x[j];
+      sp[3 * t] = p.x; sp[3 * t + 1] = p.y; sp[3 * t + 2] = p.z;
+    }
+  }
   real vx0 = 0, vy0 = 0, vz0 = 0;          // FUSE: the velocity travels under the pair loop (wave 0 integrates)
   if(FUSE && wv == 0 && i >= 0) { vx0 = v[3 * (size_t)i + 0]; vy0 = v[3 * (size_t)i + 1]; vz0 = v[3 * (size_t)i + 2]; }
   __syncthreads();
@@ -441,25 +449,13 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   const int witem = xcd_work_item(ntiles);
   if(witem < 0) return;
   const int tile = tile_list ? tile_list[witem] : witem;
-  const int ncand = tile_ncand[tile];
+  // three round trips (see k_lj_full_tile): header scalars; candidate indices + own atom index + first slots; positions
+  const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile], kmax = tile_max[tile];
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
-  for(int t0 = 0; t0 <= ncand; t0 += STG * NT) {              // positions in, accumulators cleared
-    int tt[STG], jj[STG];
+  int tt[STG], jj[STG];
 #pragma unroll
-    for(int u = 0; u < STG; u++) { tt[u] = min(t0 + u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
-    real4 pp[STG];
-#pragma unroll
-    for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
-#pragma unroll
-    for(int u = 0; u < STG; u++) {
-      sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z;
-      s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0;
-      s_idx[tt[u]] = jj[u];
-      if(EV && !GN) s_ghost[tt[u]] = jj[u] >= nlocal ? 1 : 0;
-    }
-  }
-  int i = lane < tile_cnt[tile] ? binned[tile_first[tile] + lane] : -1;
-  const int kmax = tile_max[tile];
+  for(int u = 0; u < STG; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
+  int i = lane < cnt ? binned[first + lane] : -1;
   constexpr int QR = 4;                                     // rows are padded to 4: trips of UNR pairs + one half trip
   const int per = ((kmax / QR + 1) / 2) * QR;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
@@ -471,8 +467,26 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
 #pragma unroll
     for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
   }
+  real4 pp[STG];
+#pragma unroll
+  for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
+#pragma unroll
+  for(int u = 0; u < STG; u++) {                              // positions in, accumulators cleared
+    sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z;
+    s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0;
+    s_idx[tt[u]] = jj[u];
+    if(EV && !GN) s_ghost[tt[u]] = jj[u] >= nlocal ? 1 : 0;
+  }
+  for(int t0 = STG * NT; t0 <= ncand; t0 += NT) {             // (a union beyond STG * NT candidates: rare)
+    const int t = min(t0 + tid, ncand), j = cl[t];
+    const real4 p = x[j];
+    sp[3 * t] = p.x; sp[3 * t + 1] = p.y; sp[3 * t + 2] = p.z;
+    s_acc[3 * t] = 0; s_acc[3 * t + 1] = 0; s_acc[3 * t + 2] = 0;
+    s_idx[t] = j;
+    if(EV && !GN) s_ghost[t] = j >= nlocal ? 1 : 0;
+  }
   __syncthreads();
   drain_loads();
 
