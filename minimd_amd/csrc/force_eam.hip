@@ -475,7 +475,9 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   const int witem = (blockIdx.x & 7) * per_xcd + tq;          // ntiles = length of the work list (all tiles, or one part of them)
   if(witem >= ntiles) break;
   const int tile = tile_list ? tile_list[witem] : witem;
-  __syncthreads();                                      // previous tile's readers are done with s_pos / s_part
+  // Full lists: no barrier here. Everybody passed the barrier behind the pair loop, after which only wave 0 reads LDS (s_part), and the
+  // next writes to s_part lie behind the next tile's pre-loop barrier: waves 1.. start loading the next tile under wave 0's epilogue.
+  if(HALF) __syncthreads();                             // (half lists: the flush loop of the previous tile reads s_racc / s_idx)
   // The tile's loads in three round trips instead of six: header scalars; then candidate indices, own atom index and first slots
   // together; then the positions. (2-3 workgroups per CU — the knot table bounds the occupancy — hide little of a longer chain.)
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   const int witem = (blockIdx.x & 7) * per_xcd + tq;          // ntiles = length of the work list (all tiles, or one part of them)
   if(witem >= ntiles) break;
   const int tile = tile_list ? tile_list[witem] : witem;
-  __syncthreads();
+  if(HALF) __syncthreads();                             // (see k_eam_density_tile: full lists need no barrier here)
   // three round trips (see k_eam_density_tile): header; indices + own atom + first slots; positions + fp
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
@@ -761,6 +763,12 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
     if(k < k1) trip(std::integral_constant<int, 2>{}, k);            // (slices are even)
   }
   if(wv > 0) { real* d = s_f + 3 * 64 * (wv - 1); d[lane] = fx; d[64 + lane] = fy; d[128 + lane] = fz; }
+  real vx = 0, vy = 0, vz = 0;                        // FUSE: what wave 0's epilogue reads travels under the wait for the other waves
+  real4 xb = xi;
+  if(FUSE && wv == 0 && i >= 0) {
+    vx = v[3 * (size_t)i + 0]; vy = v[3 * (size_t)i + 1]; vz = v[3 * (size_t)i + 2];
+    if(C.words_write != nullptr) xb = C.xbuild[i];
+  }
   __syncthreads();
   if(wv == 0 && i >= 0) {
 #pragma unroll
@@ -772,14 +780,12 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
     }
     if(!FUSE && !HALF) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
     if(FUSE) {          // same operations, same order as k_final_initial_integrate (integrate.hip)
-      real vx = v[3 * (size_t)i + 0], vy = v[3 * (size_t)i + 1], vz = v[3 * (size_t)i + 2];
       vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
       vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
       v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
       const real4 xn = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
       xnew[i] = xn;
       if(C.words_write != nullptr) {                  // how far from its position at the build (rounded up: it gates the core rows)
-        const real4 xb = C.xbuild[i];
         const real ex = xn.x - xb.x, ey = xn.y - xb.y, ez = xn.z - xb.z;
         d2max = fmaxf(d2max, (float)(ex * ex + ey * ey + ez * ez) * 1.000001f + 1.0e-30f);
       }
