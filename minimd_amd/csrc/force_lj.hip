@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   constexpr int STG = 512 / LJ_TILE_THREADS;
   int tt[STG], jj[STG];
 #pragma unroll
-  for(int u = 0; u < STG; u++) { tt[u] = min(u * LJ_TILE_THREADS + tid, ncand); jj[u] = cl[tt[u]]; }
+  for(int u = 0; u < STG; u++) { tt[u] = min(u * LJ_TILE_THREADS + tid, ncand); jj[u] = stream_load(cl + tt[u]); }
   // ---- my atom and my slice of its neighbor row (wave w takes k in [k0,k1))
   int i = lane < cnt ? binned[first + lane] : -1;
   // rows are padded to a multiple of 4 (NB_ROW_PAD): the wave slices are multiples of 4, run as trips of UNR pairs plus,
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   for(int u = 0; u < UNR; u++) s[u] = 0;
   if(k0 < k1) {                                   // (a slice of 4 rows reads 4 rows of padding / of the next slice: in bounds, unused)
 #pragma unroll
-    for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
+    for(int u = 0; u < UNR; u++) s[u] = stream_load(np + u * 64);
   }
   real4 pp[STG];
   if(ghosted) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     np += U * 64;
     if(k + U < k1) {
 #pragma unroll
-      for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
+      for(int u = 0; u < UNR; u++) s[u] = stream_load(np + u * 64);
     }
     // every multiply-add is written as an explicit fma: with -ffp-contract=fast the compiler would otherwise be
     // free to pick WHICH product of a sum it fuses, and the instantiations of this template must round alike
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
   int tt[STG], jj[STG];
 #pragma unroll
-  for(int u = 0; u < STG; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
+  for(int u = 0; u < STG; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = stream_load(cl + tt[u]); }
   int i = lane < cnt ? binned[first + lane] : -1;
   constexpr int QR = 4;                                     // rows are padded to 4: trips of UNR pairs + one half trip
   const int per = ((kmax / QR + 1) / 2) * QR;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   for(int u = 0; u < UNR; u++) s[u] = 0;
   if(k0 < k1) {
 #pragma unroll
-    for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
+    for(int u = 0; u < UNR; u++) s[u] = stream_load(np + u * 64);
   }
   real4 pp[STG];
 #pragma unroll
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     np += U * 64;
     if(k + U < k1) {
 #pragma unroll
-      for(int u = 0; u < UNR; u++) s[u] = np[u * 64];
+      for(int u = 0; u < UNR; u++) s[u] = stream_load(np + u * 64);
     }
     // groups of four pairs share ONE reciprocal in double precision (see k_lj_full_tile)
     constexpr bool BATCH = sizeof(real) == 8;

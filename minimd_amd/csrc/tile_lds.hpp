@@ -43,6 +43,16 @@ __device__ __forceinline__ void drain_loads() { __builtin_amdgcn_s_waitcnt(0x0F7
 __device__ __forceinline__ void drain_loads() {}
 #endif
 
+// A load of data that is read ONCE per launch (a tile's rows, its candidate list): non-temporal, so that the stream does not push the
+// atom positions — which neighbouring tiles re-read — out of the XCD's L2 (LJ at -s 80: rows + lists are 420 MB per launch against 74 MB
+// of positions that were fetched three times over; +2.3 % for both LJ tile kernels). NOT for the EAM sweeps: the second sweep re-reads
+// the rows of the first (187 MB at -s 64, they survive in the 256 MB MALL), and a non-temporal load does not leave them there (-1 % / -3.6 %).
+#ifndef MMD_NO_NT
+template <typename T> __device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+#else
+template <typename T> __device__ __forceinline__ T stream_load(const T* p) { return *p; }
+#endif
+
 // One-rank runs: every ghost is a periodic image of an owned atom (Comm::borders recorded its root and image vector), so a tile
 // kernel can stage a ghost candidate straight from the owner's CURRENT position plus the box shift — the per-step
 // Comm::communicate (k_ghost_update, ref/comm.cpp:276-317 with self swaps) and its launch gap disappear from the step.
