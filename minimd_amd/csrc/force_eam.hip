@@ -411,6 +411,9 @@ __device__ __forceinline__ float rsqrt_fast(float a)
 #ifndef EAM_FWAVES
 #define EAM_FWAVES 3            // wavefronts per SIMD the force sweep is compiled for (<= 168 VGPRs): its DP variants need 162-182 registers, and the knot table lets
 #endif                        // 3 workgroups = 3 wavefronts per SIMD onto a CU anyway — a variant that ends at 170 would run with 2 (measured: 0.29 -> 0.37 ms per step)
+// rows / candidate list in the force sweep of full lists: non-temporal (their last use in the step; the density sweep before it loads them
+// normally so that they wait in the MALL). +1.2 %; half lists -1.6 %, so not there.
+#define EAM_F_LOAD(p) (HALF ? *(p) : stream_load(p))
 #ifndef EAM_RD
 #define EAM_RD (MMD_PRECISION == 2 ? 1 : 0)      // DP: the three position reads of a pair stay separate ds_read_b64 (ds_read2_b64 runs at half the LDS rate: -1.7 %)
 #endif
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   auto fp_index = [&](int j) { return (fp_root != nullptr && j >= nlocal && j < nall) ? fp_root[j - nlocal] : j; };
   int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
-  for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = cl[tt[u]]; }
+  for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = EAM_F_LOAD(cl + tt[u]); }
   int i = lane < cnt ? binned[first + lane] : -1;
   // the rows (a multiple of 4) are dealt to the wavefronts two at a time: 52 rows = 14,14,12,12 instead of 16,16,16,4 — the slowest
   // wavefront is the tile's critical path
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   for(int u = 0; u < EAM_FU; u++) sl[u] = 0;
   if(k0 < k1) {                                   // (a slice of 4 rows reads 4 entries past it: in bounds — nl16 ends with 16 spare rows — and unused)
 #pragma unroll
-    for(int u = 0; u < EAM_FU; u++) sl[u] = np[u * 64];
+    for(int u = 0; u < EAM_FU; u++) sl[u] = EAM_F_LOAD(np + u * 64);
   }
   real4 pp[EAM_STAGE];
   real ff[EAM_STAGE];
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
     np += U * 64;
     if(k + U < k1) {
 #pragma unroll
-      for(int u = 0; u < EAM_FU; u++) sl[u] = np[u * 64];
+      for(int u = 0; u < EAM_FU; u++) sl[u] = EAM_F_LOAD(np + u * 64);
     }
     real dx[U], dy[U], dz[U], rsq[U], recip[U], p[U];
     const real* c[U];
