@@ -1088,3 +1088,35 @@ def test_undersized_ghost_arrays_on_several_ranks_fall_back_together(port, tmp_p
     o.close()
     # (every re-neighboring took the fall-back: the swap-by-swap path waits for its counts)
     assert all(st["host_syncs"] > 3 * 6 for st in res["stats"]), res["stats"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style,half", [("eam", 0), ("eam", 1), ("lj", 0), ("lj", 1)])
+def test_unions_beyond_one_staging_round(style, half, tmp_path):
+    """The tile kernels stage the first 512 candidates of a tile's union in one batched round and the rest in a plain loop (DESIGN §4.1, §4.6);
+    at the EAM deck's density (unions of 300-480 atoms) that loop never runs, at the LJ deck's for 2 % of the tiles. Lattices compressed to 1.4x
+    (copper) / 1.25x (LJ) the density have unions of 530-700 atoms: the runs must still follow the oracle (ForceEAM::compute_fullneigh /
+    compute_halfneigh, ref/force_eam.cpp:94-449; ForceLJ::compute_fullneigh / compute_halfneigh, ref/force_lj.cpp:271-449)."""
+    deck = open(os.path.join(REPO, "data", "in.%s.miniMD" % style)).read()
+    old_rho, new_rho = ("0.07041125", "0.0985758 ") if style == "eam" else ("0.8442", "1.0552")
+    assert old_rho in deck and "100            thermo" in deck
+    deck = deck.replace(old_rho, new_rho).replace("100            thermo", "10             thermo")
+    if style == "lj" and half:                  # (half lists with ghost newton keep the upper half shell only: a wider skin as well)
+        assert "2.5 0.30" in deck
+        deck = deck.replace("2.5 0.30", "2.5 0.80")
+    p = str(tmp_path / ("in.%s_dense.miniMD" % style))
+    open(p, "w").write(deck)
+    args = ["-i", p, "-s", "8", "-n", "40", "--half_neigh", str(half)]
+    import minimd_amd
+    s = minimd_amd.Sim(args, quiet=True)
+    s.initial(); s.run()
+    st = s.handle.neighbor_tile_stats()
+    assert st["max_candidates"] > 512, st                  # (otherwise this test does not reach the loop it is for)
+    rows = s.rows()
+    s.close()
+    o = Oracle(args)
+    o.initial(); o.run()
+    ref = o.rows()
+    o.close()
+    assert len(rows) == len(ref) == 5
+    rows_close(rows, ref, 1e-9)
