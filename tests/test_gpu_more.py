@@ -1120,3 +1120,21 @@ def test_unions_beyond_one_staging_round(style, half, tmp_path):
     o.close()
     assert len(rows) == len(ref) == 5
     rows_close(rows, ref, 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [0, 1])
+def test_eam_single_precision_run_follows_the_oracle(half):
+    """ForceEAM in MMD_float (ref -DPRECISION=1): the SP library's tile sweeps (float knot tables, ds_read_b32 position records) against the
+    oracle's SP run of the same deck — thermo rows of 40 steps within float summation noise (5e-4 relative, the sums run in another order)."""
+    args = ["-i", "in.eam.miniMD", "-s", "6", "-n", "40", "--half_neigh", str(half)]
+    rows = sim_rows(args, precision="sp")
+    o = Oracle(args, precision="sp")
+    o.initial(); o.run()
+    ref = o.rows()
+    o.close()
+    assert len(rows) == len(ref) and len(rows) >= 2
+    rows_close(rows, ref, 5e-4)
+    dp = sim_rows(args, precision="dp")
+    for a, b in zip(rows, dp):
+        assert abs(a[2] - b[2]) <= 5e-4 * abs(b[2]), (a, b)          # and next to the DP library's run
