@@ -133,7 +133,8 @@ struct mmd_handle {
   bool neigh_ready = false;
   real cutneigh = 0, cutneighsq = 0;
   int halfneigh = 0, ghost_newton = 0, ntypes = 1;
-  BinGeom bg;
+  BinGeom bg;                // device bins (= the reference's unless those are too fine for the build kernels, mmd_neighbor_setup)
+  BinGeom bg_ref;            // the reference's bins (Neighbor::setup)
   DevArr<int> bin_count, bin_start, binned, scan_tmp, atom_bin;
   DevArr<int> atom_rank;       // arrival rank of each atom inside its bin (k_bin_count)
   int maxneighs = 100;       // row stride (multiple of MMD_UNROLL)

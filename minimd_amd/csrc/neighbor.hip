@@ -37,31 +37,44 @@ extern "C" int mmd_neighbor_setup(mmd_handle* h, const int nbin[3], mmd_float cu
   if(!h) { mmd_set_error("null handle"); return -1; }
   if(nbin[0] < 1 || nbin[1] < 1 || nbin[2] < 1 || !(cutneigh > 0)) { mmd_set_error("mmd_neighbor_setup: bad bins/cutoff"); return -1; }
   if(!(h->prd[0] > 0)) { mmd_set_error("mmd_neighbor_setup: box not set"); return -1; }
-  BinGeom& g = h->bg;
   h->cutneigh = cutneigh;
   h->cutneighsq = cutneigh * cutneigh;
   h->halfneigh = halfneigh;
   h->ghost_newton = ghost_newton;
   h->ntypes = ntypes;
-  for(int d = 0; d < 3; d++) {
-    g.prd[d] = h->prd[d];
-    g.nbin[d] = nbin[d];
-    g.binsize[d] = h->prd[d] / nbin[d];
-    g.bininv[d] = 1.0 / g.binsize[d];
-    real coord = h->lo[d] - cutneigh - NB_SMALL * h->prd[d];
-    int lo = static_cast<int>(coord * g.bininv[d]);
-    if(coord < 0.0) lo -= 1;
-    coord = h->hi[d] + cutneigh + NB_SMALL * h->prd[d];
-    int hi = static_cast<int>(coord * g.bininv[d]);
-    lo -= 1; hi += 1;                      // one extra bin each side, as the reference
-    g.mbinlo[d] = lo;
-    g.mbin[d] = hi - lo + 1;
-    g.blkshift[d] = (-g.mbinlo[d]) & 1;          // bin of coordinate 0 gets an even shifted index
-    g.nblk[d] = (g.mbin[d] + g.blkshift[d] + 1) >> 1;
-    int next = static_cast<int>(cutneigh * g.bininv[d]);
-    if(next * g.binsize[d] < cutneigh) next++;   // full coverage (the reference shaves 0.1% here, :405-415)
-    g.reach[d] = (next + 1) >> 1;
+  auto geometry = [&](const int nb[3], BinGeom& g) {
+    for(int d = 0; d < 3; d++) {
+      g.prd[d] = h->prd[d];
+      g.nbin[d] = nb[d];
+      g.binsize[d] = h->prd[d] / nb[d];
+      g.bininv[d] = 1.0 / g.binsize[d];
+      real coord = h->lo[d] - cutneigh - NB_SMALL * h->prd[d];
+      int lo = static_cast<int>(coord * g.bininv[d]);
+      if(coord < 0.0) lo -= 1;
+      coord = h->hi[d] + cutneigh + NB_SMALL * h->prd[d];
+      int hi = static_cast<int>(coord * g.bininv[d]);
+      lo -= 1; hi += 1;                      // one extra bin each side, as the reference
+      g.mbinlo[d] = lo;
+      g.mbin[d] = hi - lo + 1;
+      g.blkshift[d] = (-g.mbinlo[d]) & 1;          // bin of coordinate 0 gets an even shifted index
+      g.nblk[d] = (g.mbin[d] + g.blkshift[d] + 1) >> 1;
+      int next = static_cast<int>(cutneigh * g.bininv[d]);
+      if(next * g.binsize[d] < cutneigh) next++;   // full coverage (the reference shaves 0.1% here, :405-415)
+      g.reach[d] = (next + 1) >> 1;
+    }
+  };
+  // the reference's bins (reported by mmd_neighbor_geometry, compared by the reference-rule half build k_build<3>) ...
+  geometry(nbin, h->bg_ref);
+  h->bg = h->bg_ref;
+  // ... are also the device's, unless they are so fine that a tile would have to look at more rows of blocks than the build kernels hold
+  // (128 = a reach of 5 blocks in y and z, bins finer than cutneigh / 10; `-b` is free to ask for that): the device then bins at about
+  // cutneigh / 2 — the lists do not depend on the bins
+  if((2 * h->bg.reach[1] + 1) * (2 * h->bg.reach[2] + 1) > 128 || h->bg.reach[0] > 5) {
+    int nb[3];
+    for(int d = 0; d < 3; d++) nb[d] = h->bg.reach[d] > 2 ? std::max(1, std::min(nbin[d], (int)(2.0 * (double)h->prd[d] / (double)cutneigh))) : nbin[d];
+    geometry(nb, h->bg);
   }
+  BinGeom& g = h->bg;
   const long long mb = (long long)NB_SUB * g.nblk[0] * g.nblk[1] * g.nblk[2];
   if(mb > 2000000000LL) { mmd_set_error("mmd_neighbor_setup: too many bins"); return -1; }
   g.mbins = (int)mb;
@@ -305,7 +318,7 @@ template <int MODE>
 __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, const int* __restrict__ binned,
                                                  const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
                                                  BinGeom g, int nlocal, real cutneighsq, int maxneighs,
-                                                 int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags)
+                                                 int* __restrict__ neigh, int* __restrict__ numneigh, int* __restrict__ flags, BinGeom gref)
 {
   __shared__ int rng_start[128], rng_pref[130];
   __shared__ int cnt[NB_MAXA];
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
         if(i >= nlocal) continue;                            // ghosts get no row
         const real4 xi = x[i];                               // uniform address: scalar load
         const real xix = xi.x, xiy = xi.y, xiz = xi.z;
-        const int bin_i = MODE == 3 ? ref_bin3(g, xix, xiy, xiz) : 0;
+        const int bin_i = MODE == 3 ? ref_bin3(gref, xix, xiy, xiz) : 0;
         int n = cnt[a - ab];
         const size_t rowbase = ((size_t)(i >> 6) * maxneighs) * 64 + (i & 63);
 #pragma unroll
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
               keep = keep && ok;
             }
             if(MODE == 3 && keep) {                          // (only the few candidates inside the cutoff pay for their bin)
-              const int bin_j = ref_bin3(g, cx[c], cy[c], cz[c]);
+              const int bin_j = ref_bin3(gref, cx[c], cy[c], cz[c]);
               bool ok;
               if(bin_j == bin_i) {
                 ok = (cw[c] >> 29) == 3 ? j > i
@@ -1485,7 +1498,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     const int mode = !h->halfneigh ? 0 : (h->ghost_newton ? 2 : 1);
 #define LAUNCH_BUILD(M)                                                                                              \
   hipLaunchKernelGGL(k_build<M>, dim3(xcd_grid(nblocks)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,        \
-                     h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags)
+                     h->ghost_image.p, g, nlocal, h->cutneighsq, h->maxneighs, h->neigh.p, h->numneigh.p, h->d_flags, h->bg_ref)
     if(nlocal) {
       if(mode == 0) LAUNCH_BUILD(0);
       else if(mode == 1) LAUNCH_BUILD(1);
@@ -1517,8 +1530,8 @@ extern "C" int mmd_neighbor_geometry(mmd_handle* h, int mbin[3], int mbinlo[3], 
 {
   if(!h || !h->neigh_ready) { mmd_set_error("mmd_neighbor_geometry: call mmd_neighbor_setup first"); return -1; }
   for(int d = 0; d < 3; d++) {
-    if(mbin) mbin[d] = h->bg.mbin[d];
-    if(mbinlo) mbinlo[d] = h->bg.mbinlo[d];
+    if(mbin) mbin[d] = h->bg_ref.mbin[d];          // the reference's bins; blocks and reach are the device's
+    if(mbinlo) mbinlo[d] = h->bg_ref.mbinlo[d];
     if(nblk) nblk[d] = h->bg.nblk[d];
     if(reach) reach[d] = h->bg.reach[d];
   }
@@ -1621,7 +1634,7 @@ extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneigh
     // its half stencil of bins + the same-bin rules (ref/neighbor.cpp:143-182, :424-441). What crosses the boundary is the REFERENCE's
     // list: rebuilt here from the same binned atoms with the reference's rule (k_build<3>), rows equal the oracle's as sets.
     const BinGeom& g = h->bg;
-    if(g.mbin[0] > 1023 || g.mbin[1] > 1023 || g.mbin[2] > 1023) { mmd_set_error("mmd_neighbor_download: more than 1023 bins per dimension"); return -1; }
+    if(h->bg_ref.mbin[0] > 1023 || h->bg_ref.mbin[1] > 1023 || h->bg_ref.mbin[2] > 1023) { mmd_set_error("mmd_neighbor_download: more than 1023 bins per dimension"); return -1; }
     const int nwaves = div_up(n, 64), nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
     DevArr<int> rows, cnt, tmp;
     MMD_TRY(cnt.ensure((size_t)n + 64, false, h->stream));
@@ -1630,7 +1643,7 @@ extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneigh
       MMD_TRY(rows.ensure((size_t)nwaves * stride * 64 + 64, false, h->stream));
       HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
       hipLaunchKernelGGL(k_build<3>, dim3(xcd_grid(nblocks)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p, h->ghost_image.p, g, n,
-                         h->cutneighsq, stride, rows.p, cnt.p, h->d_flags);
+                         h->cutneighsq, stride, rows.p, cnt.p, h->d_flags, h->bg_ref);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(mmd_stream_sync(h));

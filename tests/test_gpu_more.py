@@ -688,12 +688,13 @@ def test_executable_reports_errors_like_the_reference():
 
 # ---- edge cases: tiny / ragged boxes, unusual bin counts, type counts ------------------------------------------
 @pytest.mark.parametrize("args", [["-s", 2], ["-s", 3], ["-nx", 2, "-ny", 5, "-nz", 3], ["-s", 6, "-b", 1], ["-s", 6, "-b", 2],
-                                  ["-s", 6, "-b", 20], ["-s", 5, "--ntypes", 1], ["-s", 5, "--ntypes", 8], ["-s", 4, "--sort", 0],
+                                  ["-s", 6, "-b", 20], ["-s", 6, "-b", 40], ["-s", 5, "-b", 64], ["-s", 5, "--ntypes", 1], ["-s", 5, "--ntypes", 8], ["-s", 4, "--sort", 0],
                                   ["-s", 4, "--sort", 7]])
 @pytest.mark.parametrize("half", [0, 1])
 def test_edge_case_runs_match_oracle(args, half):
     """same flags through the oracle and the device path; rows agree to summation order (1e-9) over 60 steps
-    (3 re-neighborings), counts of owned/ghost atoms and neighbor totals agree exactly"""
+    (3 re-neighborings), counts of owned/ghost atoms and neighbor totals agree exactly. `-b 40` / `-b 64` ask for bins of a fifteenth of the
+    cutoff and finer: the device then bins on its own coarser grid (mmd_neighbor_setup) — the lists do not depend on the bins."""
     full = [str(a) for a in args] + ["-n", "60", "--half_neigh", str(half)]
     o = Oracle(full)
     o.initial(); o.run()
