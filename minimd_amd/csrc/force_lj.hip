@@ -71,7 +71,7 @@ struct LJTables {       // general (non-uniform) case: per type-pair tables stag
   int ntypes;
 };
 
-#define LJ_MAX_TYPES2 64
+#define LJ_MAX_TYPES2 256            // 16 types with DIFFERENT parameters (tables in LDS); uniform tables — all the reference's CLI produces — have no limit
 #ifndef LJH_RD
 #define LJH_RD (MMD_PRECISION == 2 ? 1 : 0)      // half-list tile kernel, DP: three separate ds_read_b64 per pair (ds_read2_b64 runs at half the LDS rate: -2.5 %)
 #endif
@@ -614,7 +614,6 @@ extern "C" int mmd_force_lj_setup(mmd_handle* h, int ntypes, const mmd_float* cu
                                   const mmd_float* epsilon)
 {
   if(!h || ntypes < 1 || !cutforcesq || !sigma6 || !epsilon) { mmd_set_error("mmd_force_lj_setup: bad arguments"); return -1; }
-  if(ntypes * ntypes > LJ_MAX_TYPES2) { mmd_set_error("mmd_force_lj_setup: at most 8 atom types are supported"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
   h->style = 0;
   h->ntypes = ntypes;
@@ -622,6 +621,7 @@ extern "C" int mmd_force_lj_setup(mmd_handle* h, int ntypes, const mmd_float* cu
   h->lj_uniform = true;
   for(int i = 1; i < n2; i++)
     if(cutforcesq[i] != cutforcesq[0] || sigma6[i] != sigma6[0] || epsilon[i] != epsilon[0]) h->lj_uniform = false;
+  if(!h->lj_uniform && n2 > LJ_MAX_TYPES2) { mmd_set_error("mmd_force_lj_setup: at most 16 atom types with different parameters are supported"); return -1; }
   h->lj.cutforcesq = cutforcesq[0]; h->lj.sigma6 = sigma6[0]; h->lj.epsilon = epsilon[0];
   h->h_cutforcesq.assign(cutforcesq, cutforcesq + n2);
   MMD_TRY(h->lj_tables.ensure((size_t)3 * n2, false, h->stream));

@@ -688,7 +688,7 @@ def test_executable_reports_errors_like_the_reference():
 
 # ---- edge cases: tiny / ragged boxes, unusual bin counts, type counts ------------------------------------------
 @pytest.mark.parametrize("args", [["-s", 2], ["-s", 3], ["-nx", 2, "-ny", 5, "-nz", 3], ["-s", 6, "-b", 1], ["-s", 6, "-b", 2],
-                                  ["-s", 6, "-b", 20], ["-s", 6, "-b", 40], ["-s", 5, "-b", 64], ["-s", 5, "--ntypes", 1], ["-s", 5, "--ntypes", 8], ["-s", 4, "--sort", 0],
+                                  ["-s", 6, "-b", 20], ["-s", 6, "-b", 40], ["-s", 5, "-b", 64], ["-s", 5, "--ntypes", 1], ["-s", 5, "--ntypes", 8], ["-s", 5, "--ntypes", 40], ["-s", 4, "--sort", 0],
                                   ["-s", 4, "--sort", 7]])
 @pytest.mark.parametrize("half", [0, 1])
 def test_edge_case_runs_match_oracle(args, half):
