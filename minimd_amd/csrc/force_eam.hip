@@ -938,7 +938,17 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   if(h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_force_compute: neighbor list is stale (build or upload one first)"); return -1; }
   if(h->halfneigh && h->ghost_newton) { mmd_set_error("EAM needs half lists WITHOUT ghost newton (ref/ljs.cpp:219-223 forces -gn 0)"); return -1; }
   const int nlocal = h->nlocal, nall = nlocal + h->nghost;
-  if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
+  if(nlocal == 0) {
+    // a rank without atoms still takes part in the fp halo (ForceEAM::communicate: its neighbours send to it and receive from it)
+    if(h->halo_pending) { HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0)); h->halo_pending = false; }
+    MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
+    MMD_TRY(eam_fp_halo(h));
+    h->fp_ghosts_stale = false;
+    if(evflag) HIP_TRY(hipMemsetAsync(h->d_result, 0, 2 * sizeof(double), h->stream));
+    if(eng) *eng = 0;
+    if(vir) *vir = 0;
+    return 0;
+  }
   MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
   h->fp_ghosts_stale = false;
   if(eam_half_tiles_available(h) && !h->opt_eam_half_rows) {

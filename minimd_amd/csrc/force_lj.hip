@@ -742,7 +742,17 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   const int n2 = h->ntypes * h->ntypes;
   LJTables T{h->lj_tables.p, h->lj_tables.p + n2, h->lj_tables.p + 2 * n2, h->ntypes};
   MMD_TRY(h->partials.ensure((size_t)2 * nblocks + 8, false, h->stream));
-  if(nlocal == 0) { if(eng) *eng = 0; if(vir) *vir = 0; return 0; }
+  if(nlocal == 0) {
+    // a rank without atoms (tiny boxes on several ranks) computes nothing but still takes part in the step: the forces of its ghosts travel
+    // back through Comm::reverse_communicate (half lists with ghost newton) and must be zeros, its share of energy and virial is zero,
+    // and a halo launched under this call has to be waited for
+    if(h->halo_pending) { HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0)); h->halo_pending = false; }
+    if(h->halfneigh) MMD_TRY(mmd_zero_forces(h, h->nghost));
+    if(evflag) HIP_TRY(hipMemsetAsync(h->d_result, 0, 2 * sizeof(double), h->stream));
+    if(eng) *eng = 0;
+    if(vir) *vir = 0;
+    return 0;
+  }
   const int ev = evflag ? 1 : 0, uni = h->lj_uniform ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
   int nsum = nblocks;
   if(mmd_lj_tiles_available(h)) {

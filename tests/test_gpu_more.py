@@ -272,7 +272,10 @@ def test_two_ranks_match_one_rank(half, port, tmp_path):
 
 
 @pytest.mark.parametrize("nprocs,size,half", [(4, ["-nx", "8", "-ny", "9", "-nz", "10"], 0), (8, ["-s", "10"], 0),
-                                              (8, ["-s", "10"], 1)])
+                                              (8, ["-s", "10"], 1),
+                                              # 8 atoms on a 1x1x4 grid: one rank owns NO atom (it still relays ghost forces and takes part in
+                                              # every exchange), sub-boxes of 0.3 cutoffs need four ghost layers
+                                              (4, ["-nx", "1", "-ny", "1", "-nz", "2"], 0), (4, ["-nx", "1", "-ny", "1", "-nz", "2"], 1)])
 def test_four_and_eight_ranks_match_one_rank(nprocs, size, half, port, tmp_path):
     """the decompositions the 4- and 8-GPU runs use (2x2x1 / 2x2x2: both neighbours of a dimension are the same rank,
     corner ghosts travel through chained swaps, atoms migrate in every dimension), here with all ranks sharing this GPU
@@ -302,7 +305,8 @@ def test_four_and_eight_ranks_match_one_rank(nprocs, size, half, port, tmp_path)
     # device): the host waits for the GPU twice per re-neighboring — the new nlocal after Comm::exchange, the build's results — plus once
     # per thermo row; the waits of the host-staged test transport are counted apart (RCCL has none). 100 steps = 5 re-neighborings.
     for st in res["stats"]:
-        assert st["host_syncs"] <= 2 * 5 + 4, res["stats"]          # (+ thermo row, + a build that sized its lists again)
+        if res["natoms"] >= 1000:                                    # (sub-boxes thinner than half a cutoff take the swap-by-swap borders with their count handshakes)
+            assert st["host_syncs"] <= 2 * 5 + 4, res["stats"]          # (+ thermo row, + a build that sized its lists again)
         assert st["bytes_sent"] > 0 and st["transport_syncs"] > 0
 
 
