@@ -805,6 +805,7 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
 #define NB2_BUF 448            // LDS candidate buffer (slots); flushed between batches when fewer than 64*NB2_BATCH are free
 #define NB2_NE (4 * NB2_BUF / 64)   // list entries (non-empty hit words) per lane that fit the recycled candidate buffer
 #define NB2_NG 40              // groups of 32 tested candidates a tile may produce (more: the global-row build takes over)
+static_assert(NB2_NG <= 64, "a lane keeps its parked groups in a 64-bit mask");
 #define NB2_PF (MMD_PRECISION == 2)
 
 // bits = (bits << 1) | (my bit of m): one VALU instruction (carry-in = the compare mask)
@@ -836,11 +837,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
   __shared__ __align__(16) float s_buf[4 * NB2_BUF];
-  __shared__ unsigned char s_eg[NB2_NE * 64];         // group number of every list entry
-  __shared__ unsigned char s_own[NB2_BUF];            // which tile atom the candidate is (0xff: none)
+  // (the group number of a lane's list entries is not stored: bit g of the lane's gmask says "I parked a word for group g", entries are in group order)
+  __shared__ unsigned char s_own[MODE != 0 ? NB2_BUF : 8];      // half lists: which tile atom the candidate is (0xff: none)
   __shared__ unsigned short s_selfpos[64];            // buffer position of each tile atom's own candidate record (0xffff: not in this buffer)
   __shared__ uint2 s_gSU[NB2_NG];                     // per group of 32 buffered candidates: {first slot of its union members, which of the 32 are in the union}
-  __shared__ unsigned short s_self[64];               // final slot of each tile atom itself (0xffff: not in the union)
+  __shared__ unsigned short s_self[MODE != 0 ? 64 : 4];         // half lists: final slot of each tile atom itself (0xffff: not in the union)
   const int lane = threadIdx.x;
   // the tile count may still be on its way to the host (ntiles = capacity of the arrays, *ntiles_dev = the count)
   const int tile = xcd_work_item(ntiles_dev ? min(ntiles, *ntiles_dev) : ntiles);
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       }
     }
   }
-  s_self[lane] = (unsigned short)0xffff;
+  if(MODE != 0) s_self[lane] = (unsigned short)0xffff;
   s_selfpos[lane] = (unsigned short)0xffff;
   __syncthreads();
   unsigned short* __restrict__ rowp = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
@@ -915,16 +916,15 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
-  // scratch of this tile: NB2_NG x 64 words followed by NB2_NG x 64 group numbers (bytes); CORE: a second list of the same shape
-  constexpr int WSTRIDE = NB2_NG * 80 * (CORE ? 2 : 1);
+  // scratch of this tile: NB2_NG x 64 words; CORE: a second list of the same shape
+  constexpr int WSTRIDE = NB2_NG * 64 * (CORE ? 2 : 1);
   unsigned* __restrict__ ent_w = tile_words + (size_t)tile * WSTRIDE + lane;
-  unsigned char* __restrict__ ent_g = (unsigned char*)(tile_words + (size_t)tile * WSTRIDE + NB2_NG * 64) + lane;
+  unsigned long long gmask = 0, gmask2 = 0;       // groups I parked a word for (core part / rest)
   int n = 0;                               // my row length
   // CORE: the row is written in two parts, the entries closer than core_thr at the build first ("core"), the rest of the skin behind
   // them: a force kernel may stop after the core part for as long as no atom has moved further than half the margin between the
   // core radius and the force cutoff since the build (mmd_internal.hpp: CoreRows). The lists above hold the core part, these the rest.
-  unsigned* __restrict__ ent2_w = ent_w + NB2_NG * 80;
-  unsigned char* __restrict__ ent2_g = ent_g + (size_t)NB2_NG * 80 * 4;
+  unsigned* __restrict__ ent2_w = ent_w + NB2_NG * 64;
   int cnt2 = 0, n2 = 0;
   bool any_ghost = false;
 
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     if(lane < fill8 - fill) {
       s_buf[fill + lane] = 1.0e15f; s_buf[NB2_BUF + fill + lane] = 1.0e15f; s_buf[2 * NB2_BUF + fill + lane] = 1.0e15f;
       s_buf[3 * NB2_BUF + fill + lane] = __int_as_float((int)0x80000000);      // (an owned index as far as MODE 1 is concerned)
-      s_own[fill + lane] = (unsigned char)0xff;
+      if(MODE != 0) s_own[fill + lane] = (unsigned char)0xff;
     }
     __syncthreads();
     const int selfpos = MODE == 0 ? (int)s_selfpos[lane] : -1;
@@ -1038,12 +1038,12 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         if(CORE) {
           bits_c &= bits;
           const unsigned rest = bits & ~bits_c;
-          if(bits_c != 0u) { ent_w[(unsigned)cnt * 64u] = bits_c; ent_g[(unsigned)cnt * 64u] = (unsigned char)gcount; cnt++; }
-          if(rest != 0u) { ent2_w[(unsigned)cnt2 * 64u] = rest; ent2_g[(unsigned)cnt2 * 64u] = (unsigned char)gcount; cnt2++; }
+          if(bits_c != 0u) { ent_w[(unsigned)cnt * 64u] = bits_c; gmask |= 1ull << gcount; cnt++; }
+          if(rest != 0u) { ent2_w[(unsigned)cnt2 * 64u] = rest; gmask2 |= 1ull << gcount; cnt2++; }
           n2 += __popc(rest);
           bits = bits_c;                                         // (n counts the core part below)
         } else
-        if(bits != 0u) { ent_w[(unsigned)cnt * 64u] = bits; ent_g[(unsigned)cnt * 64u] = (unsigned char)gcount; cnt++; }
+        if(bits != 0u) { ent_w[(unsigned)cnt * 64u] = bits; gmask |= 1ull << gcount; cnt++; }
         if(lane == 0) s_gSU[gcount] = uint2{(unsigned)S, used};
       }
       gcount++;
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const unsigned short dummy = (unsigned short)(S * NB_SLOT_BYTES);
   bool maxcnt_over = false;
   // one part of the rows: entries of the lanes' list (src_w/src_g, mycnt of them) go to rows [kfirst, kfirst + krows)
-  auto expand = [&](const unsigned* __restrict__ src_w, const unsigned char* __restrict__ src_g, int mycnt, int kfirst, int krows) {
+  auto expand = [&](const unsigned* __restrict__ src_w, unsigned long long groups, int mycnt, int kfirst, int krows) {
     __syncthreads();
     // the lanes' lists come back from the scratch into LDS (the candidate buffer is free now), a few loads in flight at a time:
     // inside the loop a global load would put a full memory round trip into every round (s_waitcnt vmcnt(0) also waits for the
@@ -1132,22 +1132,24 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     maxcnt_over = maxcnt_over || wmax > NB2_NE;               // (a lane with more non-empty words than the LDS list holds)
     const int maxcnt = min(wmax, NB2_NE);
     for(int e0 = 0; e0 < maxcnt; e0 += 4) {
-      unsigned tw[4], tg[4];
+      unsigned tw[4];
 #pragma unroll
-      for(int u = 0; u < 4; u++) { tw[u] = 0; tg[u] = 0; if(e0 + u < mycnt) { tw[u] = src_w[(unsigned)(e0 + u) * 64u]; tg[u] = src_g[(unsigned)(e0 + u) * 64u]; } }
+      for(int u = 0; u < 4; u++) { tw[u] = 0; if(e0 + u < mycnt) tw[u] = src_w[(unsigned)(e0 + u) * 64u]; }
 #pragma unroll
-      for(int u = 0; u < 4; u++) if(e0 + u < NB2_NE) { s_ew[(e0 + u) * 64 + lane] = tw[u]; s_eg[(e0 + u) * 64 + lane] = (unsigned char)tg[u]; }
+      for(int u = 0; u < 4; u++) if(e0 + u < NB2_NE) s_ew[(e0 + u) * 64 + lane] = tw[u];
     }
     __syncthreads();
     const int cn = min(mycnt, NB2_NE);
     unsigned w0 = 0, b0 = 0, u0 = 0;
     int e = 0;                                   // list entry of w0
-    if(cn > 0) { w0 = s_ew[lane]; const uint2 su = s_gSU[s_eg[lane]]; b0 = su.x; u0 = su.y; }
+    // the group of the next entry = the lowest set bit of `groups` (entries were parked in group order)
+    if(cn > 0) { w0 = s_ew[lane]; const uint2 su = s_gSU[__builtin_ctzll(groups)]; groups &= groups - 1; b0 = su.x; u0 = su.y; }
     for(int k = 0; k < krows && !(ablate & 1); k++) {
       if(w0 == 0u && e + 1 < cn) {               // (entries are non-empty: one hop always lands on a set bit)
         e++;
         w0 = s_ew[e * 64 + lane];
-        const uint2 su = s_gSU[s_eg[e * 64 + lane]];
+        const uint2 su = s_gSU[__builtin_ctzll(groups)];
+        groups &= groups - 1;
         b0 = su.x; u0 = su.y;
       }
       const bool v = w0 != 0u;
@@ -1157,8 +1159,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       rowp[(unsigned)(kfirst + k) * 64u] = v ? (unsigned short)(slot * NB_SLOT_BYTES) : dummy;
     }
   };
-  expand(ent_w, ent_g, cnt, 0, kc);
-  if(CORE) expand(ent2_w, ent2_g, cnt2, kc, kr);
+  expand(ent_w, gmask, cnt, 0, kc);
+  if(CORE) expand(ent2_w, gmask2, cnt2, kc, kr);
   n += n2;
   if(CORE && owned) xbuild[ii] = pme;
   if(owned) numneigh[ii] = n;
@@ -1393,7 +1395,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       }
     }
     h->core.rows_built = false;
-    if(h->opt_build == 1) MMD_TRY(h->tile_words.ensure((size_t)nt * NB2_NG * 80 * (core_rows ? 2 : 1) + 64, false, h->stream));
+    if(h->opt_build == 1) MMD_TRY(h->tile_words.ensure((size_t)nt * NB2_NG * 64 * (core_rows ? 2 : 1) + 64, false, h->stream));
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
