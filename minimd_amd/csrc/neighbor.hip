@@ -27,6 +27,7 @@
 #define NB_XF 4                // x-slices per reference bin (see fine_x_of)
 #endif
 #define NB_SUB (8 * NB_XF)     // device bins per block of 2x2x2 reference bins
+#define NB_MAX_ROWS 64          // rows of blocks (pencils) around a tile that the production build holds: (2 reach_y + 1)(2 reach_z + 1)
 
 // ---------------------------------------------------------------------------------------------------
 // Neighbor::setup (ref/neighbor.cpp:318-452)
@@ -67,9 +68,9 @@ extern "C" int mmd_neighbor_setup(mmd_handle* h, const int nbin[3], mmd_float cu
   geometry(nbin, h->bg_ref);
   h->bg = h->bg_ref;
   // ... are also the device's, unless they are so fine that a tile would have to look at more rows of blocks than the build kernels hold
-  // (128 = a reach of 5 blocks in y and z, bins finer than cutneigh / 10; `-b` is free to ask for that): the device then bins at about
+  // (NB_MAX_ROWS = 64: a reach of 3 blocks in y and z, bins finer than cutneigh / 6; `-b` is free to ask for that): the device then bins at about
   // cutneigh / 2 — the lists do not depend on the bins
-  if((2 * h->bg.reach[1] + 1) * (2 * h->bg.reach[2] + 1) > 128 || h->bg.reach[0] > 5) {
+  if((2 * h->bg.reach[1] + 1) * (2 * h->bg.reach[2] + 1) > NB_MAX_ROWS || h->bg.reach[0] > 5) {
     int nb[3];
     for(int d = 0; d < 3; d++) nb[d] = h->bg.reach[d] > 2 ? std::max(1, std::min(nbin[d], (int)(2.0 * (double)h->prd[d] / (double)cutneigh))) : nbin[d];
     geometry(nb, h->bg);
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
 {
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   nall = deferred_count(nall, nlocal, nghost_dev);
-  __shared__ int rng_start[128], rng_len[128];
+  __shared__ int rng_start[NB_MAX_ROWS], rng_len[NB_MAX_ROWS];
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
   __shared__ __align__(16) float s_buf[4 * NB2_BUF];
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // ---- candidate slices: for every (dz,dy) the stretch of that pencil whose x-slices can hold an atom within the cutoff of the
   // tile's owned atoms — ONE contiguous run of binned[] (a pencil is sorted by x-slice): [slice(xmin - cutneigh), slice(xmax + cutneigh)]
   const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
-  const int nr = min(ny * nz, 128);
+  const int nr = min(ny * nz, NB_MAX_ROWS);          // (mmd_neighbor_setup keeps ny * nz <= NB_MAX_ROWS)
   // x-range of the tile's owned atoms (float keys, DPP ladder: the same reduction the bounding box below uses; the float rounding of
   // a coordinate is far inside the margin of reach_x)
   const unsigned kx = float_key((float)pme.x);
