@@ -36,6 +36,26 @@ def algorithmic_bytes_per_atom(kbar, ghost_ratio, real_bytes=8):
     return 4.0 * kbar + 4 + 3 * real_bytes + 4 + 3 * real_bytes + ghost_ratio * (3 * real_bytes + 4)
 
 
+def cpu_model():
+    """host CPU as /proc/cpuinfo names it + sockets x cores (the cpu_baseline figure varies by 2x between boxes: say which box)"""
+    try:
+        names, phys, cores = set(), set(), set()
+        pid = None
+        for l in open("/proc/cpuinfo"):
+            k, _, v = l.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                names.add(v)
+            elif k == "physical id":
+                pid = v
+                phys.add(v)
+            elif k == "core id":
+                cores.add((pid, v))
+        return "%s, %d socket(s), %d cores, %d hardware threads" % (" / ".join(sorted(names)) or "unknown CPU", max(len(phys), 1), len(cores) or (os.cpu_count() or 0), os.cpu_count() or 0)
+    except Exception:  # noqa: BLE001
+        return "unknown CPU, %d hardware threads" % (os.cpu_count() or 0)
+
+
 def cpu_baseline(size, nsteps):
     """rank 0, N=1 only: the UNMODIFIED reference (oracle/_ref/miniMD_ref_dp, built from /root/reference by
     oracle/Makefile) on this box's host cores, bounded sample of the same workload."""
@@ -57,11 +77,11 @@ def cpu_baseline(size, nsteps):
         r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=900, env=env)
         line = [l for l in r.stdout.splitlines() if "PERF_SUMMARY" in l and not l.startswith("#")][0].split()
         return {"value": float(line[9]) / 1e6, "unit": "Matom-steps/s", "cores": cores, "kind": kind,
-                "sample": "%s, in.lj.miniMD -s %d --half_neigh 0 DP, %s steps, t_total %.2f s" % (
-                    "ref/ MPI-stub + OpenMP -t %d" % cores if kind == "reference" else "oracle C restatement, 1 thread",
-                    size, line[2], float(line[4]))}
+                "sample": "%s, in.lj.miniMD -s %d --half_neigh 0 DP, %s steps, t_total %.2f s; host: %s" % (
+                    "ref/ MPI-stub + OpenMP -t %d (OMP_PROC_BIND=close; thread count = MMD_CPU_THREADS or min(32, hardware threads / 2))" % cores
+                    if kind == "reference" else "oracle C restatement, 1 thread", size, line[2], float(line[4]), cpu_model())}
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "Matom-steps/s", "cores": cores, "kind": kind, "sample": "failed: %r" % (e,)}
+        return {"value": None, "unit": "Matom-steps/s", "cores": cores, "kind": kind, "sample": "failed: %r; host: %s" % (e, cpu_model())}
 
 
 class stdout_to_stderr:
@@ -105,6 +125,8 @@ def main():
     ap.add_argument("--size", type=int, default=80, help="unit cells per GPU edge (BASELINE configs[1]: 80)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each, back to back: the FIRST is `value` (the contract's "
+                                                          "K steps), all of them are listed in `value_windows` so that a short window shows its spread")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold run of the drop-in executable (perf_summary_cold)")
     ap.add_argument("--equil", type=int, default=100, help="untimed equilibration steps before the warm-up (set-up, see the module docstring)")
     ap.add_argument("--clock-warm-ms", type=float, default=400.0,
@@ -135,6 +157,7 @@ def main():
     import minimd_amd
 
     dist = None
+    invalid_reason = None          # set when the line is NOT a figure of the production data path (debug transport): "valid": false
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -150,8 +173,11 @@ def main():
             # fewer GPUs than ranks: RCCL refuses two ranks on one device, so the halos fall back to the host-staged
             # transport (the JSON line says so: "transport": "host")
             os.environ["MMD_BENCH_TRANSPORT"] = "gloo"
+            invalid_reason = "%d ranks share %d GPU(s): halos are staged through host memory over gloo (debug transport), not RCCL over xGMI" % (world, ndev)
             if rank == 0:
                 print("bench.py: %d ranks on %d GPU(s): host-staged halos instead of RCCL" % (world, ndev), file=sys.stderr)
+        if os.environ.get("MMD_BENCH_TRANSPORT") == "gloo" and invalid_reason is None:
+            invalid_reason = "MMD_BENCH_TRANSPORT=gloo: halos are staged through host memory (debug transport), not RCCL over xGMI"
         if os.environ.get("MMD_BENCH_TRANSPORT") == "gloo":
             # debugging aid (e.g. two ranks sharing one GPU): host-staged halos over gloo instead of RCCL
             from minimd_amd import api
@@ -195,6 +221,9 @@ def main():
                 print("bench.py rank %d: RCCL path failed on some rank (%s); every rank falls back to host-staged halos" % (rank, err), file=sys.stderr)
             if sim is not None:
                 sim.close()
+            # a GPU per rank was there and RCCL still did not come up: whatever follows is a debug-transport number, and the line says so
+            invalid_reason = "RCCL communicator failed on some rank although %d GPU(s) serve %d ranks (%s): host-staged halos, NOT a scaling figure" % (
+                max(torch.cuda.device_count(), 1), world, str(err)[:200] if err is not None else "failure on another rank")
             os.environ["MMD_BENCH_TRANSPORT"] = "gloo"
             from minimd_amd import api
             from minimd_amd.transport import GlooTransport
@@ -235,6 +264,19 @@ def main():
 
     tm = sim.handle.timers()
     rs = sim.handle.run_stats()
+    # further windows of the same length, back to back (each fenced like the first; `value` is the first one alone)
+    window_s = [dt]
+    for _ in range(max(args.windows, 1) - 1):
+        fence()
+        tw0 = time.perf_counter()
+        sim.run_steps(args.steps)
+        fence()
+        tw = time.perf_counter() - tw0
+        if dist is not None:
+            t = torch.tensor([tw], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tw = float(t.item())
+        window_s.append(tw)
     nlocal, nghost, _ = sim.handle.counts()
     # per-rank view of the timed region (max over ranks of every phase, rank 0's own next to it): with these a SCALE line is
     # diagnosable from the record alone — where the time went, how often the host stalled the GPU, how many bytes the halos moved
@@ -284,6 +326,10 @@ def main():
         "metric": "Matom-steps/sec (LJ, full-neigh)", "value": natoms * args.steps / dt / 1e6, "unit": "Matom-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        # false = the halos did not travel over RCCL (ranks sharing a GPU, forced debug transport, or RCCL failed): not a scaling figure
+        "valid": invalid_reason is None, "reason": invalid_reason,
+        # consecutive timed windows of `steps` steps each (max over ranks); value == value_windows[0]
+        "value_windows": [natoms * args.steps / w / 1e6 for w in window_s],
         "config": {"workload": "in.lj.miniMD -s %d per GPU (global %dx%dx%d cells, %d atoms), full neighbor list, DP, "
                                "reneigh 20, thermo 100; set-up: %d untimed equilibration steps + %.0f ms of clock warm-up before the warm-up steps" % (args.size, nx, ny, nz, natoms, args.equil, args.clock_warm_ms),
                    "parallelism": "spatial %dx%dx%d, %s" % (dims + ({"rccl": "RCCL p2p halos over xGMI", "host": "host-staged halos (debug transport)",

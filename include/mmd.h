@@ -163,6 +163,10 @@ int mmd_timers(mmd_handle* h, double out5[5], double* force_kernel_ms, int* forc
  * ghost lists, handshakes). transport_syncs counts, apart from host_syncs, the waits of the host-staged TEST transport (staging a message
  * through host memory; RCCL has none). bench.py reports them per step so that a multi-GPU line is diagnosable from the record alone. */
 int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* bytes_sent, long long* transport_syncs);
+/* read-only diagnostic counters of a handle (since mmd_create): "exchange_fast" / "exchange_overflows" = Comm::exchange calls served by the
+ * handshake-free path / finished by the count-handshake path after a fixed-size message overflowed; "borders_fast" / "borders_general" =
+ * Comm::borders calls served by the device-resident path / the swap-by-swap path. No reference counterpart (the reference has one path). */
+int mmd_get_counter(mmd_handle* h, const char* name, long long* value);
 /* time `nrep` launches of one hot kernel with hipEvents on the handle's compute stream.
  * which: 0 = force (current style, evflag=0), 1 = neighbor build, 2 = initial integrate, 3 = final integrate */
 int mmd_profile_kernel(mmd_handle* h, int which, int nrep, double* avg_ms);

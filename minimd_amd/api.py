@@ -76,6 +76,7 @@ def load_library(precision="dp"):
         "mmd_integrate_setup": [P, creal, creal, I, I], "mmd_integrate_initial": [P], "mmd_integrate_final": [P],
         "mmd_thermo_temperature": [P, dp], "mmd_integrate_mark_positions": [P], "mmd_integrate_max_move": [P, dp], "mmd_integrate_run": [P, I, I, I, P, P],
         "mmd_timers": [P, dp, dp, ip], "mmd_run_stats": [P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "mmd_profile_kernel": [P, I, I, dp], "mmd_set_option": [P, C.c_char_p, I],
+        "mmd_get_counter": [P, C.c_char_p, C.POINTER(C.c_longlong)],
         "mmd_sync": [P],
         "mmd_input_read": [P, C.c_char_p], "mmd_create_box": [I, I, I, D, rp],
         "mmd_create_atoms": [I, I, I, D, rp, rp, I, rp, rp, ip, ip, ip],
@@ -369,6 +370,11 @@ class Handle:
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
         self._chk(self.L.mmd_run_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"host_syncs": a.value, "bytes_sent": b.value, "transport_syncs": c.value}
+
+    def counter(self, name):
+        v = C.c_longlong()
+        self._chk(self.L.mmd_get_counter(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def profile_kernel(self, which, nrep=20):
         ms = C.c_double()

@@ -110,6 +110,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "core_pct")) h->opt_core_pct = value;
   else if(!strcmp(name, "borders_fast")) h->opt_borders_fast = value;
   else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
+  else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) {
 #ifdef MMD_PROFILE
@@ -428,6 +429,17 @@ extern "C" int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* by
   if(host_syncs) *host_syncs = h->host_syncs;
   if(bytes_sent) *bytes_sent = h->halo_bytes;
   if(transport_syncs) *transport_syncs = h->transport_syncs;
+  return 0;
+}
+
+extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value)
+{
+  if(!h || !name || !value) { mmd_set_error("mmd_get_counter: bad arguments"); return -1; }
+  if(!strcmp(name, "exchange_overflows")) *value = h->ex_overflows;
+  else if(!strcmp(name, "exchange_fast")) *value = h->ex_fast;
+  else if(!strcmp(name, "borders_fast")) *value = h->borders_fast_runs;
+  else if(!strcmp(name, "borders_general")) *value = h->borders_general_runs;
+  else { mmd_set_error("mmd_get_counter: unknown counter '%s'", name); return -1; }
   return 0;
 }
 

@@ -548,17 +548,23 @@ __global__ __launch_bounds__(256) void k_unpack_exchange(const ExchRec* __restri
 // 64-byte header holding the count, then cap ExchRec records, cap = f(count at the previous re-neighboring), derived alike by the
 // sender (from what it sent) and the receiver (from what it got) — and every count (leavers, hole fillers, arrivals kept, the
 // running nlocal) stays in device memory (`est`) until ONE read-back at the end of the three dimensions. est layout (ints):
-//   [0] nlocal now  [1] overflow  [2] leavers of the current dimension  [4+d] leavers of dimension d  [10+2d+dir] records received
-// An overflow (a message or the atom arrays too small for what arrived: more than 4x the previous migration + 4096 atoms) cannot
-// be repaired after the fact — atoms would be lost — and is reported as an error naming the option that switches this path off.
+//   [0] nlocal now  [1] overflow (max over the ranks)  [2] leavers of the current dimension  [3] 1 + first dimension that was NOT applied
+//   [4+d] leavers of dimension d  [10+2d+dir] records received  [20] broken invariant (cannot happen by construction; fatal)
+// Overflow protocol (a rank has more leavers than its message holds: more than 4x the previous migration + 4096 atoms): the sender
+// sees that BEFORE anything is overwritten (k_ex_leavers only reads the atoms), the flag is max-reduced over the ranks on the stream
+// before the first kernel that moves atoms (k_ex_fill), and from then on every rank skips k_ex_fill / k_ex_arrive of this and the
+// following dimensions while the fixed-size messages keep flowing (matched sends and receives). The host then finds every rank in the
+// same state — dimensions below est[3]-1 applied, the others untouched — and finishes them with the count-handshake path.
 // ---------------------------------------------------------------------------------------------------
 #define EST_NLOCAL 0
 #define EST_OVF 1
 #define EST_NSEND 2
+#define EST_FAILD 3
 #define EST_SEND_D 4
 #define EST_RECV 10
+#define EST_FATAL 20
 #define EMSG_HEADER 64
-static inline int exch_msg_cap(int prev) { return 4 * prev + 4096; }
+static inline int exch_msg_cap(const mmd_handle* h, int prev) { return h->opt_exchange_cap > 0 ? h->opt_exchange_cap : 4 * prev + 4096; }
 static inline size_t exch_msg_bytes(int cap) { return ((size_t)EMSG_HEADER + (size_t)cap * sizeof(ExchRec) + 63) & ~(size_t)63; }
 
 __global__ __launch_bounds__(256) void k_ex_count(const real4* __restrict__ x, const int* __restrict__ est, int dim, real lo, real hi, int* __restrict__ cnt)
@@ -614,7 +620,8 @@ __global__ __launch_bounds__(256) void k_ex_leavers(const real4* __restrict__ x,
     const int nsend = off + tot;
     est[EST_NSEND] = nsend; est[EST_SEND_D + d_index] = nsend;
     *(int*)msg = nsend;
-    if(nsend > cap || n > grid_atoms) est[EST_OVF] = 1;       // (more leavers than the message holds / more atoms than the launch covers)
+    if(nsend > cap) est[EST_OVF] = 1;                         // more leavers than the message holds: nothing has been moved yet
+    if(n > grid_atoms) est[EST_FATAL] = 1;                    // (more atoms than the launch covers: the host sized the grid from a bound)
   }
 }
 // the k-th hole (leaver below the new end) takes the k-th stayer of the tail: Atom::copy (ref/comm.cpp:491-509). One workgroup:
@@ -623,6 +630,10 @@ __global__ __launch_bounds__(1024) void k_ex_fill(real4* __restrict__ x, real* _
                                                   int* __restrict__ est, int dim, real lo, real hi, const int* __restrict__ leavers, int cap)
 {
   __shared__ int lds[17];
+  if(est[EST_OVF]) {                              // (uniform: some rank's message overflowed — this and the later dimensions are left to the handshake path)
+    if(threadIdx.x == 0 && est[EST_FAILD] == 0) est[EST_FAILD] = dim + 1;
+    return;
+  }
   const int n = est[EST_NLOCAL], nsend = min(est[EST_NSEND], cap);
   const int t0 = n - nsend;
   int done = 0;                                   // stayers of the tail seen so far (uniform)
@@ -652,6 +663,7 @@ __global__ __launch_bounds__(1024) void k_ex_arrive(real4* __restrict__ x, real*
                                                     const unsigned char* __restrict__ m1, int cap1, int cap_atoms, int d_index)
 {
   __shared__ int lds[17];
+  if(est[EST_OVF]) return;
   int n = est[EST_NLOCAL];
   for(int q = 0; q < 2; q++) {
     const unsigned char* __restrict__ m = q ? m1 : m0;
@@ -677,26 +689,42 @@ __global__ __launch_bounds__(1024) void k_ex_arrive(real4* __restrict__ x, real*
       n += tot;
       __syncthreads();
     }
-    if(threadIdx.x == 0) { est[EST_RECV + 2 * d_index + q] = raw; if(raw > cap) est[EST_OVF] = 1; }
+    // (raw > cap: the sender would have raised the overflow flag before this kernel ran; n > cap_atoms: the arrays were sized for every cap)
+    if(threadIdx.x == 0) { est[EST_RECV + 2 * d_index + q] = raw; if(raw > cap) est[EST_FATAL] = 1; }
   }
-  if(threadIdx.x == 0) { if(n > cap_atoms) est[EST_OVF] = 1; est[EST_NLOCAL] = min(n, cap_atoms); }
+  if(threadIdx.x == 0) { if(n > cap_atoms) est[EST_FATAL] = 1; est[EST_NLOCAL] = min(n, cap_atoms); }
 }
 __global__ void k_ex_init(int* __restrict__ est, int nlocal)
 {
   if(threadIdx.x < 32) est[threadIdx.x] = threadIdx.x == EST_NLOCAL ? nlocal : 0;
 }
 
-// returns 1 = done, 0 = not applicable (the caller runs the handshake path), < 0 error
-static int exchange_multi_fast(mmd_handle* h)
+// a flag word in device memory becomes its maximum over the ranks, on the stream (RCCL) / through the host (test transport)
+static int reduce_flag_max(mmd_handle* h, int* dflag)
 {
+  if(h->rccl) { NCCL_TRY(ncclAllReduce(dflag, dflag, 1, ncclInt, ncclMax, (ncclComm_t)h->rccl, h->stream)); return 0; }
+  HIP_TRY(hipMemcpyAsync(h->h_flags + 14, dflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(mmd_stream_sync_transport(h));
+  double v = h->h_flags[14] ? 1.0 : 0.0;
+  MMD_TRY(mmd_transport_allreduce(h, &v, 1));
+  h->h_flags[14] = v > 0.0 ? 1 : 0;
+  HIP_TRY(hipMemcpyAsync(dflag, h->h_flags + 14, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+// returns 1 = done, 0 = the caller runs the handshake path from dimension *resume_dim on (0: path not applicable; d > 0: a
+// message overflowed in dimension d, the dimensions below it are done), < 0 error
+static int exchange_multi_fast(mmd_handle* h, int* resume_dim)
+{
+  *resume_dim = 0;
   if(h->nprocs == 1 || h->opt_safe_exchange || !h->opt_async_counts || !h->ex_prev_valid || !(h->rccl || h->host_sr)) return 0;
   int cap_s[3] = {0, 0, 0}, cap_r[3][2] = {{0, 0}, {0, 0}, {0, 0}};
   int arrivals_max = 0;
   for(int d = 0; d < 3; d++) {
     if(h->procgrid[d] == 1) continue;
-    cap_s[d] = exch_msg_cap(h->ex_prev_send[d]);
-    cap_r[d][0] = exch_msg_cap(h->ex_prev_recv[d][0]);
-    cap_r[d][1] = h->procgrid[d] > 2 ? exch_msg_cap(h->ex_prev_recv[d][1]) : 0;
+    cap_s[d] = exch_msg_cap(h, h->ex_prev_send[d]);
+    cap_r[d][0] = exch_msg_cap(h, h->ex_prev_recv[d][0]);
+    cap_r[d][1] = h->procgrid[d] > 2 ? exch_msg_cap(h, h->ex_prev_recv[d][1]) : 0;
     arrivals_max += cap_r[d][0] + cap_r[d][1];
   }
   const int nl0 = h->nlocal;
@@ -719,6 +747,8 @@ static int exchange_multi_fast(mmd_handle* h)
     hipLaunchKernelGGL(k_ex_count, dim3(nt), dim3(256), 0, h->stream, h->x.p, h->est.p, d, lo, hi, h->flag_tmp.p);
     hipLaunchKernelGGL(k_ex_leavers, dim3(nt), dim3(256), 0, h->stream, h->x.p, h->v.p, h->tag.p, h->est.p, d, lo, hi, h->flag_tmp.p, h->ex_list.p, smsg,
                        cap_s[d], d, nt * CP_TILE);
+    HIP_TRY(hipGetLastError());
+    MMD_TRY(reduce_flag_max(h, h->est.p + EST_OVF));           // (before the first kernel of this dimension that moves atoms)
     hipLaunchKernelGGL(k_ex_fill, dim3(1), dim3(1024), 0, h->stream, h->x.p, h->v.p, h->type.p, h->tag.p, h->est.p, d, lo, hi, h->ex_list.p, cap_s[d]);
     HIP_TRY(hipGetLastError());
     if(br1) {
@@ -737,18 +767,18 @@ static int exchange_multi_fast(mmd_handle* h)
   HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->est.p, 32 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(mmd_stream_sync(h));
   const int* e = h->h_flags_big;
-  if(e[EST_OVF]) {
-    mmd_set_error("Comm::exchange: more atoms migrated than the fixed-size messages of the handshake-free path hold (4x the previous "
-                  "re-neighboring's count + 4096); run with mmd_set_option(h, \"async_counts\", 0)");
-    return -1;
-  }
+  if(e[EST_FATAL]) { mmd_set_error("Comm::exchange: the handshake-free path broke its own sizing (message or atom capacity)"); return -1; }
+  const int d_end = e[EST_OVF] ? e[EST_FAILD] - 1 : 3;         // dimensions [0, d_end) were applied, on every rank alike
+  if(e[EST_OVF] && (d_end < 0 || d_end > 2)) { mmd_set_error("Comm::exchange: overflow flag without a dimension"); return -1; }
   h->nlocal = e[EST_NLOCAL];
-  for(int d = 0; d < 3; d++) {
+  for(int d = 0; d < d_end; d++) {
     if(h->procgrid[d] == 1) continue;
     h->ex_prev_send[d] = e[EST_SEND_D + d];
     h->ex_prev_recv[d][0] = e[EST_RECV + 2 * d];
     h->ex_prev_recv[d][1] = e[EST_RECV + 2 * d + 1];
   }
+  if(e[EST_OVF]) { *resume_dim = d_end; h->ex_overflows++; return 0; }
+  h->ex_fast++;
   return 1;
 }
 
@@ -758,14 +788,15 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
   HIP_TRY(hipSetDevice(h->device));
   MMD_TRY(mmd_atom_pbc(h));
   h->nghost = 0;                       // ghost slots are reused by arrivals; borders() rebuilds them next
+  int d_first = 0;                     // (> 0: the handshake-free path stopped at an overflowing dimension; finish from there)
   {
-    const int rc = exchange_multi_fast(h);
+    const int rc = exchange_multi_fast(h, &d_first);
     if(rc != 0) return rc < 0 ? rc : 0;
   }
   static_assert(sizeof(ExchRec) % sizeof(real) == 0, "ExchRec must be a whole number of reals");
   const size_t rec_reals = sizeof(ExchRec) / sizeof(real);
   DevArr<int> leavers, fillers, keep;
-  for(int d = 0; d < 3; d++) {
+  for(int d = d_first; d < 3; d++) {
     if(h->procgrid[d] == 1) continue;
     const real lo = h->lo[d], hi = h->hi[d];
     const int nlocal = h->nlocal;
@@ -843,7 +874,10 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
   }
   if(h->nprocs > 1) HIP_TRY(mmd_stream_sync(h));     // (the scratch arrays below are only allocated when a dimension is split)
   leavers.release(); fillers.release(); keep.release();
-  if(!h->opt_safe_exchange) h->ex_prev_valid = true;
+  // the fixed-size messages of the next exchange are sized from THIS one's counts — but only from an exchange inside a run: the one of
+  // the set-up (mmd_sim_initial) moves nobody, while at the first re-neighboring half a lattice plane may leave through every face
+  // (FCC atoms are created exactly on the sub-domain faces: ~2 ny nz atoms, far beyond 4 x 0 + 4096 at -s 80 per rank)
+  if(!h->opt_safe_exchange && h->in_reneighbor) h->ex_prev_valid = true;
   return 0;
 }
 
@@ -1143,7 +1177,11 @@ static int borders_fast_finish(mmd_handle* h);
 
 static int borders_device_resident(mmd_handle* h, bool defer)
 {
-  if(!h->opt_borders_fast || h->swaps.size() != 6 || h->prev_nghost <= 0 || h->prev_nb <= 0) return 0;
+  if(!h->opt_borders_fast || h->swaps.size() != 6) return 0;
+  // several ranks: every condition below is the same on all of them (options, topology, "a swap-by-swap borders has run before") — a
+  // rank that owned no boundary atom or got no ghost last time (prev_nb, prev_nghost = 0: empty or sparse sub-domain) must still post the
+  // fixed-size messages its partners wait for; its arrays get the +4096 floor of the estimates
+  if(h->nprocs > 1 ? !h->borders_general_done : (h->prev_nghost <= 0 || h->prev_nb <= 0)) return 0;
   if(h->nprocs == 1 && !h->opt_force_transport && h->nlocal <= 4096) return 0;
   // (force_transport, a test option: periodic self swaps take the message path too — the RCCL calls of this function run on one GPU)
   const bool forced = h->opt_force_transport != 0;
@@ -1178,7 +1216,7 @@ static int borders_device_resident(mmd_handle* h, bool defer)
   SlabSet S;
   S.n = 6;
   for(int q = 0; q < 6; q++) { S.lo[q] = h->swaps[q].slablo; S.hi[q] = h->swaps[q].slabhi; S.dim[q] = h->swaps[q].dim; }
-  hipLaunchKernelGGL(k_bnd_count, dim3(nt_own), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bstate.p);
+  hipLaunchKernelGGL(k_bnd_count, dim3(nt_own > 0 ? nt_own : 1), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bstate.p);
   hipLaunchKernelGGL(k_bnd_scatter, dim3(nt_own > 0 ? nt_own : 1), dim3(256), 0, h->stream, h->x.p, nlocal, S, h->flag_tmp.p, h->bnd_list.p, h->bstate.p, est_nb);
   for(int q = 0; q < 6; q += 2) {
     const bool remote = forced || h->swaps[q].sendproc != h->me;
@@ -1224,15 +1262,7 @@ static int borders_device_resident(mmd_handle* h, bool defer)
   if(any_remote) {
     // the overflow flag is made global before anybody reads it: either every rank keeps these ghosts or every rank redoes the
     // borders swap by swap (the general path is a sequence of matched sends and receives)
-    if(h->rccl) NCCL_TRY(ncclAllReduce(h->bstate.p + BST_OVF, h->bstate.p + BST_OVF, 1, ncclInt, ncclMax, (ncclComm_t)h->rccl, h->stream));
-    else {
-      HIP_TRY(hipMemcpyAsync(h->h_flags + 14, h->bstate.p + BST_OVF, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(mmd_stream_sync_transport(h));
-      double v = h->h_flags[14] ? 1.0 : 0.0;
-      MMD_TRY(mmd_transport_allreduce(h, &v, 1));
-      h->h_flags[14] = v > 0.0 ? 1 : 0;
-      HIP_TRY(hipMemcpyAsync(h->bstate.p + BST_OVF, h->h_flags + 14, sizeof(int), hipMemcpyHostToDevice, h->stream));
-    }
+    MMD_TRY(reduce_flag_max(h, h->bstate.p + BST_OVF));
   }
   static_assert(BST_GHOSTS + 6 < 40, "bst read-back window");
   h->bf_est_nb = est_nb;
@@ -1271,6 +1301,7 @@ static int borders_fast_finish(mmd_handle* h)
   h->prev_nb = hf[BST_NB];
   h->prev_nghost = h->nghost;
   h->ghost_chain_ok = all_self;
+  h->borders_fast_runs++;
   return 1;
 }
 
@@ -1418,6 +1449,8 @@ static int borders_general(mmd_handle* h)
   }
   MMD_TRY(mmd_set_dummy(h));
   h->prev_nghost = h->nghost;
+  h->borders_general_done = true;
+  h->borders_general_runs++;
   h->neigh_nlocal = 0;                 // any existing neighbor list is stale now
   h->tiles_ready = false;
   return 0;

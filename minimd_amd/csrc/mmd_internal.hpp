@@ -220,6 +220,10 @@ struct mmd_handle {
   DevArr<int> est, ex_list;            // handshake-free Comm::exchange (comm.hip): device-resident counts / leaver list
   int ex_prev_send[3] = {0, 0, 0}, ex_prev_recv[3][2] = {{0, 0}, {0, 0}, {0, 0}};     // migration counts of the last exchange (size the fixed messages)
   bool ex_prev_valid = false;
+  int opt_exchange_cap = 0;            // > 0: record capacity of the fixed-size exchange messages (tests force the overflow protocol); 0: 4 x previous + 4096
+  long long ex_fast = 0, borders_fast_runs = 0, borders_general_runs = 0;      // how often each path ran (mmd_get_counter)
+  int ex_overflows = 0;                // exchanges whose fixed-size messages overflowed and were finished by the handshake path (diagnostic, tests)
+  bool borders_general_done = false;   // a swap-by-swap Comm::borders has run (several ranks: the collective condition for the fixed-size-message path)
   bool big_bins = false;       // some bin holds more than NB_BIGBIN atoms: binning runs the grid-wide rank sort too
   bool in_reneighbor = false;  // inside Integrate::run's re-neighboring: Comm::borders follows Atom::sort, ghosts need not ride along
   // one-rank LJ full-list steps: the tile kernel stages ghosts from their owners, no per-step Comm::communicate. 1 = where it

@@ -104,21 +104,31 @@ def ref_runs(big):
         ("lj_1x3x2_half_n60", "dp", ["-i", "in.lj.miniMD", "-nx", "1", "-ny", "3", "-nz", "2", "-n", "60", "--half_neigh", "1"]),
         ("lj_1x3x2_full_n60", "dp", ["-i", "in.lj.miniMD", "-nx", "1", "-ny", "3", "-nz", "2", "-n", "60", "--half_neigh", "0"]),
         ("eam_2x1x3_full_n60", "dp", ["-i", "in.eam.miniMD", "-nx", "2", "-ny", "1", "-nz", "3", "-n", "60", "--half_neigh", "0"]),
+        # the reference's CoMD-parameter decks (data/in.*.miniMD_comd carry the values of ref/in.*.miniMD_comd): the only LJ deck
+        # with epsilon, sigma != 1 (0.167 / 2.315, cutoff 4.59, dt 5e-5) and an EAM deck at another density with skin 0.5, thermo 10
+        ("lj_comd_s10_full_n1000", "dp", ["-i", "in.lj.miniMD_comd", "-s", "10", "-n", "1000", "--half_neigh", "0"]),
+        ("lj_comd_s10_half_n1000", "dp", ["-i", "in.lj.miniMD_comd", "-s", "10", "-n", "1000", "--half_neigh", "1"]),
+        ("lj_comd_s10_full_n300_sp", "sp", ["-i", "in.lj.miniMD_comd", "-s", "10", "-n", "300", "--half_neigh", "0"]),
+        ("eam_comd_s10_full_n300", "dp", ["-i", "in.eam.miniMD_comd", "-s", "10", "-n", "300", "--half_neigh", "0"]),
+        ("eam_comd_s10_half_n300", "dp", ["-i", "in.eam.miniMD_comd", "-s", "10", "-n", "300", "--half_neigh", "1"]),
     ]
     only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
-    if only:
-        cases = [c for c in cases if c[0] in only[0]]
     if big:
         cases += [
             ("lj_s80_full_n100", "dp", ["-i", "in.lj.miniMD", "-s", "80", "-n", "100", "--half_neigh", "0", "-t", "8"]),
             ("lj_s80_half_n100", "dp", ["-i", "in.lj.miniMD", "-s", "80", "-n", "100", "--half_neigh", "1", "-t", "8"]),
             ("eam_s64_full_n100", "dp", ["-i", "in.eam.miniMD", "-s", "64", "-n", "100", "--half_neigh", "0", "-t", "8"]),
+            # BASELINE configs[4] at its real size in DOUBLE precision (16.4 M atoms, half lists; ~5 min on 8 threads): the row the
+            # device's DP run of config E is compared with digit for digit (the reference's SP sums are useless at this size)
+            ("lj_s160_half_n100", "dp", ["-i", "in.lj.miniMD", "-s", "160", "-n", "100", "--half_neigh", "1", "-t", "8"]),
         ]
         # (ref_runs.json also holds "lj_s144_full_n100", 11.9 M atoms: its rows were taken from a separate 9-minute run of
         #  oracle/_ref/miniMD_ref_dp -i in.lj.miniMD -s 144 -n 100 --half_neigh 0 -t 8 and are kept when this script rewrites the file)
+    if only:
+        cases = [c for c in cases if c[0] in only[0]]
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for f in ("in.lj.miniMD", "in.eam.miniMD", "Cu_u6.eam"):
+        for f in ("in.lj.miniMD", "in.eam.miniMD", "in.lj.miniMD_comd", "in.eam.miniMD_comd", "Cu_u6.eam"):
             os.symlink(os.path.join(DATA, f), os.path.join(tmp, f))
         for name, prec, args in cases:
             print("ref run", name, flush=True)

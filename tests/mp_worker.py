@@ -90,7 +90,10 @@ def sim(out, args, precision, rccl=False):
     counts = [None] * world
     dist.all_gather_object(counts, (nl, ng, s.handle.neighbor_info()["total"]))
     stats = [None] * world
-    dist.all_gather_object(stats, s.handle.run_stats())          # of Integrate::run (the last mmd_integrate_run of Sim.run)
+    st = s.handle.run_stats()                                    # of Integrate::run (the last mmd_integrate_run of Sim.run)
+    for c in ("exchange_fast", "exchange_overflows", "borders_fast", "borders_general"):
+        st[c] = s.handle.counter(c)
+    dist.all_gather_object(stats, st)
     if rank == 0:
         json.dump({"rows": s.rows(), "counts": counts, "natoms": s.natoms(), "stats": stats}, open(out, "w"))
     s.close()

@@ -882,6 +882,9 @@ def test_bench_launches_itself_for_two_ranks(tmp_path):
     assert "32x16x16" in d["config"]["workload"] and d["cpu_baseline"] is None      # (CPU baseline only at N=1)
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert d["config"]["transport"] == ("rccl" if torch.cuda.device_count() >= 2 else "host") and d["config"]["transport_ranks"] == 2
+    # a line whose halos did not travel over RCCL says so unmistakably (it is a debug-transport figure, not a scaling one)
+    assert d["valid"] == (d["config"]["transport"] == "rccl") and (d["valid"] or "debug transport" in d["reason"])
+    assert len(d["value_windows"]) == 3 and d["value_windows"][0] == d["value"]
 
 
 @pytest.mark.gpu
@@ -929,6 +932,9 @@ def test_bench_contract_single_gpu():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["unit"] == "GB/s"
     cb = d["cpu_baseline"]
     assert cb and cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert "host:" in cb["sample"] and "hardware threads" in cb["sample"]            # which CPU the baseline ran on
+    assert d["valid"] is True and d["reason"] is None
+    assert len(d["value_windows"]) == 3 and d["value_windows"][0] == d["value"] and min(d["value_windows"]) > 0
 
 
 @pytest.mark.gpu
@@ -1093,6 +1099,60 @@ def test_undersized_ghost_arrays_on_several_ranks_fall_back_together(port, tmp_p
     o.close()
     # (every re-neighboring took the fall-back: the swap-by-swap path waits for its counts)
     assert all(st["host_syncs"] > 3 * 6 for st in res["stats"]), res["stats"]
+
+
+def _two_rank_run(args, port, tmp_path, options="", nprocs=2):
+    out = str(tmp_path / "mp.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MMD_TEST_OPTIONS=options)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nprocs), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "sim", out, "dp"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nprocs,cap", [(2, 8), (4, 64)])
+def test_overflowing_exchange_messages_fall_back_together(nprocs, cap, port, tmp_path):
+    """the handshake-free Comm::exchange with messages far too small (exchange_cap records): the sender notices before any atom has
+    been moved, the flag is max-reduced over the ranks, every rank skips the mutating kernels of that dimension and the later ones, and
+    the count-handshake path finishes them (ref/comm.cpp:364-597). Nobody is lost, rows and per-rank counts are those of the oracle's
+    virtual ranks, and the run does not abort (round 3: 'more atoms migrated than the fixed-size messages hold')."""
+    args = ["-s", "8", "-n", "100", "--half_neigh", "0"]
+    base = sim_rows(args)
+    res = _two_rank_run(args, port, tmp_path, "exchange_cap=%d" % cap, nprocs)
+    rows = [tuple(x) for x in res["rows"]]
+    assert [r_[0] for r_ in rows] == [b[0] for b in base]
+    for a, b in zip(rows, base):
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+    o = Oracle(args, nprocs=nprocs)
+    o.initial(); o.run()
+    assert [o.nlocal(r) for r in range(nprocs)] == [c[0] for c in res["counts"]]
+    assert [o.nghost(r) for r in range(nprocs)] == [c[1] for c in res["counts"]]
+    o.close()
+    assert sum(c[0] for c in res["counts"]) == res["natoms"]
+    # every rank saw the same number of overflows (the decision is collective) and at least one
+    ov = [st["exchange_overflows"] for st in res["stats"]]
+    assert len(set(ov)) == 1 and ov[0] >= 1, res["stats"]
+
+
+@pytest.mark.gpu
+def test_first_exchange_of_a_run_at_s80_on_two_ranks_does_not_overflow(port, tmp_path):
+    """two ranks of -s 80 (1 M atoms each): FCC atoms are created exactly on the sub-domain faces, so at the first re-neighboring about
+    half a lattice plane (~6400 atoms) leaves through each face — more than the 4096 records a fixed-size message sized from the set-up
+    exchange (nobody moves) would hold. The first exchange of a run therefore takes the count-handshake path and sizes the messages
+    of the second; no overflow, nobody lost, rows of the one-rank run."""
+    args = ["-s", "80", "-n", "40", "--half_neigh", "0"]
+    base = sim_rows(args)
+    res = _two_rank_run(args, port, tmp_path)
+    assert sum(c[0] for c in res["counts"]) == res["natoms"] == 2048000
+    for a, b in zip(res["rows"], base):
+        assert a[0] == b[0]
+        for k in (1, 2, 3):
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
+    for st in res["stats"]:
+        assert st["exchange_overflows"] == 0 and st["exchange_fast"] == 1 and st["borders_fast"] >= 1, res["stats"]
 
 
 @pytest.mark.gpu
