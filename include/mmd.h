@@ -60,6 +60,10 @@ int mmd_atom_upload(mmd_handle* h, const mmd_float* x, const mmd_float* v, const
                     int nlocal, int nghost);
 /* Download in reference layout; any pointer may be NULL. x: (nlocal+nghost)*3, v: nlocal*3,
  * f: nf*3 with nf = nlocal (full lists) or nlocal+nghost (half lists), type: nlocal+nghost, tag: nlocal. */
+/* positions only (x[3*(nlocal+nghost)], same atoms in the same order as the last mmd_atom_upload): what a reference Atom looks like after
+ * initialIntegrate + Comm::communicate of a step without re-neighboring (ref/integrate.cpp:94-105). Types, velocities and the neighbor
+ * list (built or uploaded) stay valid — a plugin uploads the list only when the reference's Neighbor::build has run. */
+int mmd_atom_upload_x(mmd_handle* h, const mmd_float* x, int nall);
 int mmd_atom_download(mmd_handle* h, mmd_float* x, mmd_float* v, mmd_float* f, int* type, int* tag);
 int mmd_atom_upload_f(mmd_handle* h, const mmd_float* f, int n);       /* set atom.f (n atoms) */
 int mmd_atom_counts(mmd_handle* h, int* nlocal, int* nghost, int* nmax);
@@ -85,7 +89,10 @@ int mmd_neighbor_info(mmd_handle* h, int* maxneighs, int* mbins, long long* tota
 int mmd_neighbor_tile_stats(mmd_handle* h, long long out[6]);
 /* diagnostics: histograms (nb bins of `width`, the last one open-ended) of the tiles' candidate-union sizes and padded row counts */
 int mmd_neighbor_tile_histogram(mmd_handle* h, int nb, int width, long long* hist_ncand, long long* hist_rows);
-/* rows in REFERENCE layout neighbors[i*maxneighs + k] (ref/neighbor.cpp:128); maxneighs = caller's stride */
+/* rows in REFERENCE layout neighbors[i*maxneighs + k] (ref/neighbor.cpp:128); maxneighs = caller's stride.
+ * Download: valid directly after mmd_neighbor_build (half lists with ghost newton are re-derived with the reference's partition rule from the
+ * current positions). Upload: the rows are also turned into the library's tile form where they fit it (every entry within the cutoff the bins
+ * were set up for), so the tile force kernels serve an uploaded list like one built here; otherwise the general row kernels do. */
 int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneighs, int* numneigh);
 int mmd_neighbor_upload(mmd_handle* h, const int* neighbors, int maxneighs, const int* numneigh, int nlocal);
 
@@ -106,6 +113,13 @@ int mmd_force_eam_setup(mmd_handle* h, int ntypes, int nr, int nrho, int nr_tot,
  * conventions (full lists: 4*sum over both directions / 0.5*virial — ref/force_lj.cpp:441-442). */
 int mmd_force_compute(mmd_handle* h, int evflag, double* eng_vdwl, double* virial);
 int mmd_force_eam_download_fp(mmd_handle* h, mmd_float* fp);           /* fp[nlocal+nghost] after EAM compute */
+/* ForceEAM::communicate (ref/force_eam.cpp:851-887: the halo of fp = F'(rho) between the two sweeps of ForceEAM::compute) as a
+ * customisation point for callers whose ghost atoms were NOT made by this library's Comm::borders (mmd_atom_upload of a reference
+ * Atom incl. its ghosts): between the sweeps the library hands `fp` to the callback as a host array of nlocal + nghost values with the
+ * owned part filled in; the callback fills the ghost part (the reference plugin calls ITS ForceEAM::communicate on its Comm's send lists,
+ * tests/integration/force_eam_hip.h) and returns 0. fn = NULL removes it (then the handle's own Comm serves the halo). */
+typedef int (*mmd_fp_halo_fn)(void* ctx, mmd_float* fp, int nlocal, int nghost);
+int mmd_force_eam_set_fp_halo(mmd_handle* h, mmd_fp_halo_fn fn, void* ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * Comm  (ref/comm.h:39-102, ref/comm.cpp)
@@ -165,7 +179,8 @@ int mmd_timers(mmd_handle* h, double out5[5], double* force_kernel_ms, int* forc
 int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* bytes_sent, long long* transport_syncs);
 /* read-only diagnostic counters of a handle (since mmd_create): "exchange_fast" / "exchange_overflows" = Comm::exchange calls served by the
  * handshake-free path / finished by the count-handshake path after a fixed-size message overflowed; "borders_fast" / "borders_general" =
- * Comm::borders calls served by the device-resident path / the swap-by-swap path. No reference counterpart (the reference has one path). */
+ * Comm::borders calls served by the device-resident path / the swap-by-swap path; "device_bins_coarser" = 1 when the device bins coarser than the
+ * reference's `-b` grid (mmd_neighbor_setup); "tiles_ready" / "rows_uploaded" = state of the current neighbor list. No reference counterpart. */
 int mmd_get_counter(mmd_handle* h, const char* name, long long* value);
 /* time `nrep` launches of one hot kernel with hipEvents on the handle's compute stream.
  * which: 0 = force (current style, evflag=0), 1 = neighbor build, 2 = initial integrate, 3 = final integrate */

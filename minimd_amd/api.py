@@ -76,7 +76,7 @@ def load_library(precision="dp"):
         "mmd_integrate_setup": [P, creal, creal, I, I], "mmd_integrate_initial": [P], "mmd_integrate_final": [P],
         "mmd_thermo_temperature": [P, dp], "mmd_integrate_mark_positions": [P], "mmd_integrate_max_move": [P, dp], "mmd_integrate_run": [P, I, I, I, P, P],
         "mmd_timers": [P, dp, dp, ip], "mmd_run_stats": [P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "mmd_profile_kernel": [P, I, I, dp], "mmd_set_option": [P, C.c_char_p, I],
-        "mmd_get_counter": [P, C.c_char_p, C.POINTER(C.c_longlong)],
+        "mmd_get_counter": [P, C.c_char_p, C.POINTER(C.c_longlong)], "mmd_force_eam_set_fp_halo": [P, P, P], "mmd_atom_upload_x": [P, rp, I],
         "mmd_sync": [P],
         "mmd_input_read": [P, C.c_char_p], "mmd_create_box": [I, I, I, D, rp],
         "mmd_create_atoms": [I, I, I, D, rp, rp, I, rp, rp, ip, ip, ip],
@@ -169,6 +169,10 @@ class Handle:
         type_ = np.ascontiguousarray(type_, np.int32)
         tag = None if tag is None else np.ascontiguousarray(tag, np.int32)
         self._chk(self.L.mmd_atom_upload(self.h, self._rp(x), self._rp(v), self._ip(type_), self._ip(tag), nlocal, nall - nlocal))
+
+    def upload_x(self, x):
+        x = self._r(x).reshape(-1, 3)
+        self._chk(self.L.mmd_atom_upload_x(self.h, self._rp(x), x.shape[0]))
 
     def counts(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()

@@ -53,7 +53,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   if(h->host_only) { delete h; return 0; }
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
-  h->x.release(); h->x_alt.release(); h->v.release(); h->v_alt.release(); h->f.release();
+  h->x.release(); h->x_alt.release(); h->v.release(); h->v_alt.release(); h->f.release(); h->x_stage.release();
   h->type.release(); h->type_alt.release(); h->tag.release(); h->tag_alt.release();
   h->bin_count.release(); h->bin_start.release(); h->binned.release(); h->scan_tmp.release(); h->atom_bin.release(); h->atom_rank.release();
   h->neigh.release(); h->numneigh.release(); h->wave_max.release(); h->ghost_image.release(); h->ghost_root.release();
@@ -99,6 +99,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "time_force_events")) h->time_force_events = value != 0;
   else if(!strcmp(name, "tiles")) h->opt_tiles = value;
   else if(!strcmp(name, "build")) h->opt_build = value;
+  else if(!strcmp(name, "upload_tiles")) h->opt_upload_tiles = value;
   else if(!strcmp(name, "eam_mlo")) h->opt_eam_mlo = value;
   else if(!strcmp(name, "ghost_resolve")) h->opt_ghost_resolve = value;
   else if(!strcmp(name, "time_force_sample")) h->opt_time_sample = value;
@@ -439,6 +440,9 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "exchange_fast")) *value = h->ex_fast;
   else if(!strcmp(name, "borders_fast")) *value = h->borders_fast_runs;
   else if(!strcmp(name, "borders_general")) *value = h->borders_general_runs;
+  else if(!strcmp(name, "device_bins_coarser")) *value = h->neigh_ready && (h->bg.nbin[0] != h->bg_ref.nbin[0] || h->bg.nbin[1] != h->bg_ref.nbin[1] || h->bg.nbin[2] != h->bg_ref.nbin[2]) ? 1 : 0;
+  else if(!strcmp(name, "tiles_ready")) *value = h->tiles_ready ? 1 : 0;
+  else if(!strcmp(name, "rows_uploaded")) *value = h->rows_uploaded ? 1 : 0;
   else { mmd_set_error("mmd_get_counter: unknown counter '%s'", name); return -1; }
   return 0;
 }

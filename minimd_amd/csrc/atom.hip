@@ -65,10 +65,28 @@ extern "C" int mmd_atom_upload(mmd_handle* h, const mmd_float* x, const mmd_floa
   HIP_TRY(hipGetLastError());
   h->nlocal = nlocal;
   h->nghost = nghost;
+  h->ghosts_uploaded = nghost > 0;         // (whatever Comm::borders recorded about the previous ghosts — send lists, owners — is stale now)
+  h->ghost_chain_ok = false;
   MMD_TRY(mmd_set_dummy(h));
   HIP_TRY(mmd_stream_sync(h));
   tmp.release();
   h->neigh_nlocal = 0;
+  return 0;
+}
+
+// positions only, atom for atom (the state a reference Atom is in after initialIntegrate + Comm::communicate of a step without
+// re-neighboring, ref/integrate.cpp:94-105): types, velocities, tags, ghost bookkeeping and the neighbor list stay valid
+extern "C" int mmd_atom_upload_x(mmd_handle* h, const mmd_float* x, int nall)
+{
+  if(!h || !x || nall != h->nlocal + h->nghost) { mmd_set_error("mmd_atom_upload_x: bad arguments (%d atoms here, %d given)", h ? h->nlocal + h->nghost : 0, nall); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  if(nall == 0) return 0;
+  MMD_TRY(h->x_stage.ensure((size_t)3 * nall + 1, false, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->x_stage.p, x, (size_t)3 * nall * sizeof(real), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_pack_x4, dim3(div_up(nall, 256)), dim3(256), 0, h->stream, h->x_stage.p, h->type.p, h->x.p, nall);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(mmd_stream_sync(h));                    // (the caller's array is borrowed for the duration of the call only)
+  h->ghosts_stale = false;
   return 0;
 }
 

@@ -1312,6 +1312,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   if(!h) { mmd_set_error("null handle"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
   h->nghost = 0;
+  h->ghosts_uploaded = false;
   h->nghost_dev = nullptr;
   {
     const bool defer = h->in_reneighbor && h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && h->neigh_ready;

@@ -850,6 +850,21 @@ __global__ __launch_bounds__(256) void k_fp_ghosts(real* __restrict__ fp, const 
 // ForceEAM::communicate (ref/force_eam.cpp:851-887): one scalar per send-list atom, swap by swap
 static int eam_fp_halo(mmd_handle* h)
 {
+  if(h->fp_halo_fn) {
+    // the caller's ForceEAM::communicate (ghosts that this handle's Comm did not make): owned fp to the host, ghost fp back
+    const size_t nall = (size_t)h->nlocal + h->nghost;
+    if(h->fp_stage.size() < nall + 8) h->fp_stage.resize(nall + 8);
+    if(h->nlocal) HIP_TRY(hipMemcpyAsync(h->fp_stage.data(), h->fp.p, (size_t)h->nlocal * sizeof(real), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(mmd_stream_sync(h));
+    if(h->fp_halo_fn(h->fp_halo_ctx, h->fp_stage.data(), h->nlocal, h->nghost) != 0) { mmd_set_error("ForceEAM::communicate callback failed"); return -1; }
+    if(h->nghost) HIP_TRY(hipMemcpyAsync(h->fp.p + h->nlocal, h->fp_stage.data() + h->nlocal, (size_t)h->nghost * sizeof(real), hipMemcpyHostToDevice, h->stream));
+    return 0;
+  }
+  if(h->ghosts_uploaded) {
+    mmd_set_error("ForceEAM::communicate: the ghost atoms were uploaded (mmd_atom_upload), this handle has no send lists for them; "
+                  "rebuild them with mmd_comm_borders or install the caller's halo with mmd_force_eam_set_fp_halo");
+    return -1;
+  }
   if(h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport) {
     if(h->nghost) hipLaunchKernelGGL(k_fp_ghosts, dim3(div_up(h->nghost, 256)), dim3(256), 0, h->stream, h->fp.p, h->ghost_root.p, h->nlocal, h->nghost);
     HIP_TRY(hipGetLastError());
@@ -866,6 +881,13 @@ static int eam_fp_halo(mmd_handle* h)
     }
   }
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mmd_force_eam_set_fp_halo(mmd_handle* h, mmd_fp_halo_fn fn, void* ctx)
+{
+  if(!h) { mmd_set_error("null handle"); return -1; }
+  h->fp_halo_fn = fn; h->fp_halo_ctx = ctx;
   return 0;
 }
 

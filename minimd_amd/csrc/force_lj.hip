@@ -695,7 +695,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
                        h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
                        count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,              \
                        h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce, G); }
-  const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = h->opt_tile_read;
+  const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = ex ? (h->opt_tile_read == 1 ? 1 : 0) : h->opt_tile_read;   // (exact division: one divide per pair)
   TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
   TK(0, 0, 2, 8, 0, 1);                                                                          // production, integrator fused
   TK(0, 0, 2, 8, 0, 0); TK(1, 0, 2, 8, 0, 0); TK(0, 1, 2, 8, 0, 0); TK(1, 1, 2, 8, 0, 0);        // production shape (+ exact-division check)

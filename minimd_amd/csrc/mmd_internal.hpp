@@ -128,6 +128,7 @@ struct mmd_handle {
   DevArr<real4> xold;          // positions marked at the last re-neighboring (--check_exchange, ref/integrate.cpp:168-169)
   int xold_n = -1;
   DevArr<real> v, v_alt, f;
+  DevArr<real> x_stage;        // AoS-3 staging of mmd_atom_upload_x
   DevArr<int> type, type_alt, tag, tag_alt;
   // ---- Neighbor
   bool neigh_ready = false;
@@ -149,6 +150,7 @@ struct mmd_handle {
   // entries of binned[] inside one block; nl16[(tile*maxneighs + k)*64 + lane] = slot of the neighbor in
   // the block's candidate sequence (the order in which k_build walks the surrounding blocks)
   bool tiles_ready = false;
+  bool rows_uploaded = false;            // the current list came through mmd_neighbor_upload (its rows are what a download returns, whatever the mode)
   bool rows_ready = false;               // the wave-interleaved 32-bit rows (`neigh`, wave_max) are materialised
   int ntiles = 0, tile_tmax = 0;          // tile_tmax: largest candidate count of any block (LDS sizing)
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
@@ -182,6 +184,7 @@ struct mmd_handle {
   int tile_cstride = 0, tile_cmax = 0;
   DevArr<unsigned short> nl16;
   int opt_tiles = 1;
+  int opt_upload_tiles = 1;  // mmd_neighbor_upload also derives the tile form of the rows (0: uploaded lists stay on the row kernels)
   int opt_build = 1;         // tile build kernel: 1 = one owned atom per lane (k_build_rows), 0 = one candidate per lane (k_build_tiles)
   int opt_force_transport = 0;   // testing: route self-swaps through the transport too (RCCL loop-back on one GPU)
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
@@ -235,6 +238,10 @@ struct mmd_handle {
   int opt_eam_fold_fp = 1;             // one rank, EAM full lists: ghosts' fp read through their owners in the force sweep, no fp halo launch
                                        // (1: small systems, where the saved launch shows — no difference at -s 64; 2: always; 0: never)
   bool fp_ghosts_stale = false;
+  bool ghosts_uploaded = false;          // the ghost atoms came through mmd_atom_upload, not from this handle's Comm::borders (no send lists, no ghost_root)
+  mmd_fp_halo_fn fp_halo_fn = nullptr;   // caller-supplied ForceEAM::communicate (mmd_force_eam_set_fp_halo)
+  void* fp_halo_ctx = nullptr;
+  std::vector<real> fp_stage;
   int opt_eam_half_rows = 0;           // 1: EAM half lists on the global-atomic row kernels even where the tile kernels apply
   bool eam_half_attr_set = false;
   const int* nghost_dev = nullptr;     // != nullptr: one-rank borders enqueued, ghost count still on the device (nghost holds a bound)

@@ -266,7 +266,7 @@ int mmd_bin_atoms(mmd_handle* h, int count)
     HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
   h->bin_count_clean = -1;
   // (dense bins, e.g. `-b 1`: the long-bin rank sort is on from the first binning, not only once a build has seen such a bin)
-  if(!h->big_bins && (long long)n > 32LL * g.nbin[0] * g.nbin[1] * g.nbin[2]) h->big_bins = true;
+  if(!h->big_bins && (long long)n > 32LL * g.mbin[0] * g.mbin[1] * g.mbin[2]) h->big_bins = true;     // (this rank's bins, not the global grid)
   if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr,
                            h->pbc_pending ? 1 : 0, h->prd[0], h->prd[1], h->prd[2]);
   h->pbc_pending = false;
@@ -1344,6 +1344,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
   h->tiles_ready = false;
   h->rows_ready = false;
+  h->rows_uploaded = false;
   h->neigh_nlocal = 0;
   // ---- tile form: block-local 16-bit rows + per-tile candidate union, see k_build_tiles
   bool want_tiles = h->opt_tiles && nlocal > 0;
@@ -1533,10 +1534,12 @@ extern "C" int mmd_neighbor_geometry(mmd_handle* h, int mbin[3], int mbinlo[3], 
 {
   if(!h || !h->neigh_ready) { mmd_set_error("mmd_neighbor_geometry: call mmd_neighbor_setup first"); return -1; }
   for(int d = 0; d < 3; d++) {
-    if(mbin) mbin[d] = h->bg_ref.mbin[d];          // the reference's bins; blocks and reach are the device's
+    // one self-consistent grid: the REFERENCE's bins and the blocks / reach that belong to them. (When `-b` asks for bins finer than the
+    // build kernels' reach the device bins coarser, mmd_neighbor_setup; mmd_get_counter "device_bins_coarser" says so — lists do not depend on it.)
+    if(mbin) mbin[d] = h->bg_ref.mbin[d];
     if(mbinlo) mbinlo[d] = h->bg_ref.mbinlo[d];
-    if(nblk) nblk[d] = h->bg.nblk[d];
-    if(reach) reach[d] = h->bg.reach[d];
+    if(nblk) nblk[d] = h->bg_ref.nblk[d];
+    if(reach) reach[d] = h->bg_ref.reach[d];
   }
   return 0;
 }
@@ -1632,7 +1635,10 @@ extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneigh
 {
   if(!h || h->neigh_nlocal != h->nlocal) { mmd_set_error("mmd_neighbor_download: no neighbor list for the current atoms"); return -1; }
   const int n = h->nlocal;
-  if(h->halfneigh && h->ghost_newton && n && h->tiles_ready) {
+  if(h->halfneigh && h->ghost_newton && n && h->tiles_ready && !h->rows_uploaded) {
+    // (valid directly after mmd_neighbor_build: the rows are re-derived from the CURRENT positions and the bins of the last build; ghosts that
+    //  a run left one step behind their owners are brought up to date first)
+    if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }
     // half lists with ghost newton: the device list partitions the pairs by the (z,y,x) order of the two positions, the reference by
     // its half stencil of bins + the same-bin rules (ref/neighbor.cpp:143-182, :424-441). What crosses the boundary is the REFERENCE's
     // list: rebuilt here from the same binned atoms with the reference's rule (k_build<3>), rows equal the oracle's as sets.
@@ -1700,6 +1706,214 @@ extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneigh
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Uploaded rows -> tile form (the inverse of k_tiles_to_rows): a list built elsewhere — the reference's own Neighbor::build handed
+// over by mmd_neighbor_upload — is served by the tile force kernels like a list built here. The atoms are binned and cut into pencil
+// tiles exactly as for a build; one wavefront per tile then
+//   1. lays out the tile's candidate runs (the x-stretches of the surrounding pencils, as k_build_rows does) and marks, in an LDS
+//      bitmap over those positions, every atom some row of the tile refers to (binned_inv: atom index -> position in binned[]);
+//   2. numbers the marked positions in order (= the tile's union, written to tile_cand as atom indices);
+//   3. rewrites every row entry as the 16-bit LDS offset of its union slot, k-major, padded with the dummy slot.
+// An entry that lies outside the runs (a list older than the positions, a partner beyond the cutoff the bins were set up for), a
+// union beyond the 16-bit offsets or runs longer than the bitmap raise flags[3]: the rows then stay on the general row kernels.
+// ---------------------------------------------------------------------------------------------------
+#define R2T_MAXC 16384          // candidate positions a tile's runs may span (bitmap: 2 KB of LDS)
+__global__ void k_invert_binned(const int* __restrict__ binned, int n, int* __restrict__ inv)
+{
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if(a < n) inv[binned[a]] = a;
+}
+
+template <int HALF>
+__global__ __launch_bounds__(64) void k_rows_to_tiles(const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ bin_start,
+                                                      const int* __restrict__ binned_inv, BinGeom g, int ntiles, int nlocal, int nall, real cutneigh,
+                                                      int maxneighs, int cstride, const int* __restrict__ tile_block, const int* __restrict__ tile_first,
+                                                      const int* __restrict__ tile_cnt, const int* __restrict__ numneigh, const int* __restrict__ rows,
+                                                      unsigned short* __restrict__ nl16, int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
+                                                      int* __restrict__ tile_max, int* __restrict__ tile_ghost, unsigned short* __restrict__ tile_self,
+                                                      int* __restrict__ tile_rowmax, int* __restrict__ tile_rowsum, int* __restrict__ flags)
+{
+  __shared__ int rng_start[NB_MAX_ROWS], rng_len[NB_MAX_ROWS], rng_off[NB_MAX_ROWS + 1];
+  __shared__ unsigned s_bits[R2T_MAXC / 32];
+  __shared__ int s_pre[R2T_MAXC / 32];
+  __shared__ unsigned short s_self[64];
+  const int lane = threadIdx.x;
+  const int tile = xcd_work_item(ntiles);
+  if(tile < 0) return;
+  const int b = tile_block[tile];
+  const int ta = tile_first[tile], tcn = tile_cnt[tile];
+  const int by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
+  const int ii = lane < tcn ? binned[ta + lane] : -1;
+  const bool owned = ii >= 0 && ii < nlocal;
+  const real4 pme = x[ii >= 0 ? ii : 0];
+  const unsigned long long own_mask = __builtin_amdgcn_ballot_w64(owned);
+  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
+  const int nr = min(ny * nz, NB_MAX_ROWS);
+  const unsigned kx = float_key((float)pme.x);
+  const float bx0 = key_float(wave_min_u(owned ? kx : 0xffffffffu)), bx1 = key_float(wave_max_u(owned ? kx : 0u));
+  {
+    const real xlo = (real)bx0, xhi = (real)bx1;
+    const real reach_x = cutneigh * (real)1.0005 + (real)1.0e-4 * g.binsize[0] + (real)1.0e-5 * (fabs((real)bx0) + fabs((real)bx1));
+    const int fmaxx = 2 * NB_XF * g.nblk[0] - 1;
+    const int f0 = min(max(fine_x_of(g, xlo - reach_x), 0), fmaxx), f1 = min(max(fine_x_of(g, xhi + reach_x), 0), fmaxx);
+    if(lane < nr) {                                    // (NB_MAX_ROWS = 64: one lane per run)
+      int len = 0, start = 0;
+      const int z = bz + lane / ny - g.reach[2], y = by + lane % ny - g.reach[1];
+      if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1] && own_mask != 0ull) {
+        const int row = (z * g.nblk[1] + y) * g.nblk[0] * NB_SUB;
+        start = bin_start[row + 4 * f0];
+        len = bin_start[row + 4 * f1 + 4] - start;
+      }
+      rng_start[lane] = start; rng_len[lane] = len;
+    }
+    const int lmine = lane < nr ? rng_len[lane] : 0;
+    const int incl = wave_incl_scan(lmine);
+    if(lane < nr) rng_off[lane] = incl - lmine;
+    if(lane == 63) rng_off[NB_MAX_ROWS] = incl;
+  }
+  for(int w = lane; w < R2T_MAXC / 32; w += 64) s_bits[w] = 0u;
+  s_self[lane] = (unsigned short)0xffff;
+  __syncthreads();
+  const int ctot = rng_off[NB_MAX_ROWS];
+  unsigned short* __restrict__ rowp = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
+  const size_t cbase = (size_t)tile * cstride;
+  if(own_mask == 0ull) {
+    if(lane == 0) { tile_max[tile] = 0; tile_ncand[tile] = 0; tile_cand[cbase] = nall; tile_ghost[tile] = 0; tile_rowmax[tile] = 0; tile_rowsum[tile] = 0; }
+    if(HALF) tile_self[(size_t)tile * 64 + lane] = (unsigned short)0xffff;
+    return;
+  }
+  bool bad = ctot > R2T_MAXC;
+  const int n = owned ? numneigh[ii] : 0;
+  const int nmax_w = (int)wave_max_u((unsigned)n);
+  const size_t rbase = owned ? ((size_t)(ii >> 6) * maxneighs) * 64 + (ii & 63) : 0;
+  // ---- 1. mark; the candidate position of every entry is parked in its own nl16 cell for step 3
+  if(!bad) {
+    for(int k = 0; k < nmax_w && k < maxneighs; k++) {
+      if(k < n) {
+        const int j = rows[rbase + (size_t)k * 64];
+        const int a = binned_inv[j];
+        int c = -1;
+        for(int r = 0; r < nr; r++) { const int d = a - rng_start[r]; if((unsigned)d < (unsigned)rng_len[r]) c = rng_off[r] + d; }
+        if(c < 0) bad = true;
+        else { atomicOr(&s_bits[c >> 5], 1u << (c & 31)); rowp[(unsigned)k * 64u] = (unsigned short)c; }
+      }
+    }
+  }
+  bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+  __syncthreads();
+  // ---- 2. number the marked positions: lane l owns words [8 l, 8 l + 8)
+  constexpr int WPL = R2T_MAXC / 32 / 64;
+  int mine = 0;
+#pragma unroll
+  for(int q = 0; q < WPL; q++) mine += __popc(s_bits[lane * WPL + q]);
+  const int incl = wave_incl_scan(mine);
+  int run = incl - mine;
+  const int S = __shfl(incl, 63, 64);
+  bool any_ghost = false;
+  if(!bad) {
+#pragma unroll
+    for(int q = 0; q < WPL; q++) {
+      const int w = lane * WPL + q;
+      unsigned word = s_bits[w];
+      s_pre[w] = run;
+      while(word) {
+        const int bq = __builtin_ctz(word);
+        word &= word - 1;
+        const int c = w * 32 + bq;
+        int a = 0;
+        for(int r = 0; r < nr; r++) { const int d = c - rng_off[r]; if((unsigned)d < (unsigned)rng_len[r]) a = rng_start[r] + d; }
+        const int atom = binned[a];
+        if(run < cstride - 1) tile_cand[cbase + run] = atom;
+        any_ghost = any_ghost || atom >= nlocal;
+        if(HALF && (unsigned)(a - ta) < 64u) s_self[a - ta] = (unsigned short)run;
+        run++;
+      }
+    }
+  }
+  any_ghost = __builtin_amdgcn_ballot_w64(any_ghost) != 0ull;
+  __syncthreads();
+  // ---- 3. rows as LDS offsets of the union slots, padded with the dummy slot (= S) to the tile's longest row (multiple of NB_ROW_PAD)
+  const int kc = min((nmax_w + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD, maxneighs);
+  const unsigned short dummy = (unsigned short)(S * NB_SLOT_BYTES);
+  if(!bad) {
+    for(int k = 0; k < kc; k++) {
+      unsigned short v = dummy;
+      if(k < n) {
+        const int c = rowp[(unsigned)k * 64u];
+        const int slot = s_pre[c >> 5] + __popc(s_bits[c >> 5] & ((1u << (c & 31)) - 1u));
+        v = (unsigned short)(slot * NB_SLOT_BYTES);
+      }
+      rowp[(unsigned)k * 64u] = v;
+    }
+  }
+  if(HALF) tile_self[(size_t)tile * 64 + lane] = owned ? s_self[lane] : (unsigned short)0xffff;
+  const int tsum = wave_sum(n);
+  if(lane == 0) {
+    tile_max[tile] = bad ? 0 : kc;
+    tile_ncand[tile] = bad ? 0 : S;
+    tile_cand[cbase + (bad ? 0 : min(S, cstride - 1))] = nall;
+    tile_ghost[tile] = any_ghost ? 1 : 0;
+    tile_rowmax[tile] = nmax_w;
+    tile_rowsum[tile] = tsum;
+    if(bad || S > cstride - 2 || (S + 1) * NB_SLOT_BYTES > 65535 || nmax_w > maxneighs) atomicMax(&flags[3], 1);
+  }
+}
+
+// tile form of the uploaded rows (h->neigh / numneigh, wave-interleaved): 1 = tiles ready, 0 = not applicable / a tile did not fit
+// (the row kernels serve the list), < 0 error
+static int tiles_from_rows(mmd_handle* h)
+{
+  h->tiles_ready = false;
+  const int nlocal = h->nlocal, nall = h->nlocal + h->nghost;
+  if(!h->opt_tiles || !h->opt_upload_tiles || !h->neigh_ready || nlocal == 0 || h->opt_build != 1) return 0;
+  const BinGeom& g = h->bg;
+  if((2 * g.reach[1] + 1) * (2 * g.reach[2] + 1) > NB_MAX_ROWS) return 0;
+  MMD_TRY(mmd_bin_atoms(h, -1));
+  int* inv = h->atom_rank.p;                              // (free again after the fill pass of the binning)
+  hipLaunchKernelGGL(k_invert_binned, dim3(div_up(nall, 256)), dim3(256), 0, h->stream, h->binned.p, nall, inv);
+  const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2], nunits = g.nblk[1] * g.nblk[2];
+  MMD_TRY(h->tile_of_block.ensure((size_t)nblocks + 2, false, h->stream));
+  MMD_TRY(h->pencil_range.ensure((size_t)2 * nunits + 2, false, h->stream));
+  hipLaunchKernelGGL(k_pencil_count, dim3(nunits), dim3(64), 0, h->stream, h->binned.p, h->bin_start.p, nunits, g.nblk[0], nlocal, h->tile_of_block.p, h->pencil_range.p);
+  int nt = 0;
+  MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nunits, &nt));
+  h->ntiles = nt;
+  MMD_TRY(h->tile_block.ensure((size_t)nt + 2, false, h->stream));
+  MMD_TRY(h->tile_first.ensure((size_t)nt + 2, false, h->stream));
+  MMD_TRY(h->tile_max.ensure((size_t)nt + 2, false, h->stream));
+  MMD_TRY(h->tile_ncand.ensure((size_t)nt + 2, false, h->stream));
+  MMD_TRY(h->tile_cnt.ensure((size_t)nt + 2, false, h->stream));
+  MMD_TRY(h->tile_ghost.ensure((size_t)nt + 2, false, h->stream));
+  MMD_TRY(h->tile_rowmax.ensure((size_t)nt + 2, false, h->stream));
+  MMD_TRY(h->tile_rowsum.ensure((size_t)nt + 2, false, h->stream));
+  if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
+  h->tile_cstride = NB_CHUNKS * 64 + 64;
+  MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
+  MMD_TRY(h->nl16.ensure((size_t)nt * h->maxneighs * 64 + 16 * 64, false, h->stream));
+  h->core.rows_built = false;
+  hipLaunchKernelGGL(k_pencil_fill, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
+                     h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, (const int*)nullptr);
+  if(nt) {
+#define R2T(HF) hipLaunchKernelGGL((k_rows_to_tiles<HF>), dim3(xcd_grid(nt)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p, (const int*)inv, g, nt, nlocal, \
+                                   nall, h->cutneigh, h->maxneighs, h->tile_cstride, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->neigh.p,  \
+                                   h->nl16.p, h->tile_cand.p, h->tile_ncand.p, h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p,                  \
+                                   h->tile_rowsum.p, h->d_flags)
+    if(h->halfneigh) R2T(1); else R2T(0);
+#undef R2T
+    hipLaunchKernelGGL(k_tile_reduce, dim3(std::min(32, std::max(1, div_up(nt, 1024)))), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, nt,
+                       h->d_flags, (unsigned long long*)(h->d_flags + 4), (const int*)nullptr, (const int*)nullptr);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(mmd_stream_sync(h));
+  if(h->h_flags[12] && !h->big_bins) { h->big_bins = true; return tiles_from_rows(h); }       // (a bin longer than NB_BIGBIN: bin again with the rank sort on)
+  if(h->h_flags[3] || nt == 0) return 0;
+  h->tile_cmax = h->h_flags[2];
+  h->ntiles_interior = -1;
+  h->tiles_ready = true;
+  return 1;
+}
+
 extern "C" int mmd_neighbor_upload(mmd_handle* h, const int* neighbors, int maxneighs, const int* numneigh, int nlocal)
 {
   if(!h || !neighbors || !numneigh || nlocal != h->nlocal) { mmd_set_error("mmd_neighbor_upload: bad arguments (nlocal mismatch?)"); return -1; }
@@ -1726,9 +1940,13 @@ extern "C" int mmd_neighbor_upload(mmd_handle* h, const int* neighbors, int maxn
   HIP_TRY(hipGetLastError());
   HIP_TRY(mmd_stream_sync(h));
   tmp.release();
-  h->neigh_nlocal = nlocal;
   h->max_row = maxn;
-  h->tiles_ready = false;         // an uploaded list has no block-local form
   h->rows_ready = true;
+  h->rows_uploaded = true;
+  h->neigh_nlocal = 0;
+  // the tile form of these rows, where they fit it: the list is then served by the tile force kernels like one built here
+  const int rt = tiles_from_rows(h);
+  if(rt < 0) return rt;
+  h->neigh_nlocal = nlocal;
   return 0;
 }

@@ -63,16 +63,26 @@ def test_lj_force_full_matches_oracle(size, ntypes):
     h.force_lj_setup(*o.lj_tables())
     nb = o.neighbors()
     h.neighbor_upload(nb, o.numneigh())
-    for exact in (0, 1):
-        h.set_option("exact_div", exact)
-        eng, vir = h.force_compute(1)
-        f = h.download()["f"]
-        fo = o.f()
-        scale = np.abs(fo).max()
-        # tolerance: 1e-12 of the largest force component (FMA + Newton reciprocal vs strict IEEE order)
-        assert np.abs(f - fo).max() <= 1e-12 * scale
-        assert abs(eng - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl())
-        assert abs(vir - o.virial()) <= 1e-11 * max(1.0, abs(o.virial()))
+    # an uploaded list is turned into the tile form (k_rows_to_tiles) and served by k_lj_full_tile; with tiles off the same rows run
+    # on the general row kernel k_lj_full
+    assert h.counter("tiles_ready") == 1 and h.counter("rows_uploaded") == 1 and h.neighbor_tile_stats()["tiles"] > 0
+    for tiles in (1, 0):
+        h.set_option("tiles", tiles)
+        for exact in (0, 1):
+            h.set_option("exact_div", exact)
+            eng, vir = h.force_compute(1)
+            f = h.download()["f"]
+            fo = o.f()
+            scale = np.abs(fo).max()
+            # tolerance: 1e-12 of the largest force component (FMA + Newton reciprocal vs strict IEEE order)
+            assert np.abs(f - fo).max() <= 1e-12 * scale
+            assert abs(eng - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl())
+            assert abs(vir - o.virial()) <= 1e-11 * max(1.0, abs(o.virial()))
+    # what went in comes back out (rows as the reference has them, in its order)
+    nb2, nn2 = h.neighbor_download()
+    np.testing.assert_array_equal(nn2, o.numneigh())
+    for i in range(o.nlocal()):
+        assert list(nb2[i, :nn2[i]]) == list(nb[i, :nn2[i]])
     h.close(); o.close()
 
 
@@ -131,13 +141,16 @@ def test_lj_force_half_matches_oracle(gn):
     h = handle_from_oracle(o)
     h.force_lj_setup(*o.lj_tables())
     h.neighbor_upload(o.neighbors(), o.numneigh())
-    eng, vir = h.force_compute(1)
-    f = h.download(halfneigh=True)["f"]
-    fo = o.f(with_ghosts=True)
-    # atomics reorder the per-atom sums: 1e-11 of the largest component
-    assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
-    assert abs(eng - o.eng_vdwl()) <= 1e-11 * abs(o.eng_vdwl())
-    assert abs(vir - o.virial()) <= 1e-10 * max(1.0, abs(o.virial()))
+    assert h.counter("tiles_ready") == 1 and h.neighbor_tile_stats()["tiles"] > 0
+    for tiles in (1, 0):              # the reference's half list in tile form (k_lj_half_tile), then on the row kernel (k_lj_half)
+        h.set_option("tiles", tiles)
+        eng, vir = h.force_compute(1)
+        f = h.download(halfneigh=True)["f"]
+        fo = o.f(with_ghosts=True)
+        # atomics reorder the per-atom sums: 1e-11 of the largest component
+        assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+        assert abs(eng - o.eng_vdwl()) <= 1e-11 * abs(o.eng_vdwl())
+        assert abs(vir - o.virial()) <= 1e-10 * max(1.0, abs(o.virial()))
     h.close(); o.close()
 
 
