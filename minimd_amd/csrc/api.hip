@@ -261,7 +261,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   const bool reverse = h->halfneigh && h->ghost_newton;
   bool initial_done = false;        // initialIntegrate of this step already ran fused with the previous finalIntegrate
   // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
-  const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport);
+  const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport || h->opt_overlap >= 2);     // (2: also on one rank — the ghost update under the interior tiles)
   bool halo_pending = false, collect_pending = false;
   int core_next = 0;                 // CoreRows: what the next force call may assume about the displacement since the build
   // the per-step halos are timed (into TIME_COMM) only where they are more than one tiny kernel: an event pair costs the stream

@@ -422,6 +422,32 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_half(const real4* __restrict__
 // (ref/force_lj.cpp:271-357): without ghost newton the partner gets no force when it is a ghost and the pair counts half
 // in energy and virial. f was zeroed over owned+ghost atoms beforehand. Dynamic LDS:
 //   [positions: pos_bytes][accumulators: pos_bytes][wave-slice forces: 3*64 reals][16 doubles][EV && !GN: ghost flag per slot]
+// Single precision (round 4): the LDS atomic path, not the arithmetic, is what the half-list kernel waits for (ds_add_f64 / ds_add_u64 /
+// ds_add_u32 all retire ~5 lanes per clock and CU, ds_add_f32 an eighth of that), so a pair's x and y shares travel in ONE 64-bit integer
+// atomic: fixed point with 20 fractional bits, x in the high and y in the low 32 bits of V = qx * 2^32 + qy (as a two's-complement sum the
+// fields add independently as long as neither leaves int32: |sum| < 2048). z keeps its double accumulator: 2 instead of 3 LDS atomics per
+// pair. A candidate collects from at most the 64 atoms of the tile, so shares below 2^5 can never overflow a field; a share beyond that
+// (a pair closer than ~0.76 sigma: 100 epsilon up the repulsive wall) goes to global memory directly. Resolution 2^-20 of force / c_out per
+// share, rounded to nearest (unbiased): ~1e-6 after a row of adds, against ~1e-7 for float sums — far inside the SP parity rule.
+#ifndef LJH_PACK
+#define LJH_PACK (MMD_PRECISION == 1)
+#endif
+#define LJH_FIX_SCALE 1048576.0f          // 2^20
+#define LJH_FIX_SHARE 32.0f               // largest |share| that takes the packed path
+#define LJH_FIX_SUM 1024.0f               // largest |own force / c_out| folded into a packed accumulator
+__device__ __forceinline__ unsigned long long ljh_pack_xy(float px, float py)
+{
+  const long long qx = (long long)__float2int_rn(px * LJH_FIX_SCALE), qy = (long long)__float2int_rn(py * LJH_FIX_SCALE);
+  return (unsigned long long)((qx << 32) + qy);
+}
+__device__ __forceinline__ void ljh_unpack_xy(unsigned long long v, double& x, double& y)
+{
+  const long long V = (long long)v;
+  const long long lo = (long long)(int)(unsigned)v;                 // sign-extended low field
+  x = (double)((V - lo) >> 32) * (1.0 / (double)LJH_FIX_SCALE);
+  y = (double)lo * (1.0 / (double)LJH_FIX_SCALE);
+}
+
 template <int EV, int GN>
 __global__ __launch_bounds__(128) void k_lj_half_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
@@ -544,6 +570,19 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
             if(ablate & 16) { unsafeAtomicAdd((float*)a + 0, (float)px); unsafeAtomicAdd((float*)a + 2, (float)py); unsafeAtomicAdd((float*)a + 4, (float)pz); }
             else { atomicAdd((unsigned*)a + 0, (unsigned)__float_as_int((float)px)); atomicAdd((unsigned*)a + 2, (unsigned)__float_as_int((float)py)); atomicAdd((unsigned*)a + 4, (unsigned)__float_as_int((float)pz)); }
           } else
+          if(LJH_PACK && !(ablate & 1)) {
+            if(fmaxf(fabsf((float)px), fabsf((float)py)) < LJH_FIX_SHARE) {
+              atomicAdd((unsigned long long*)a, ljh_pack_xy((float)px, (float)py));
+              if(!(ablate & 32)) unsafeAtomicAdd(a + 1, (double)pz);          // (ablate: profiling only)
+            } else {                        // (a pair far up the repulsive wall: its partner's share leaves the chip directly)
+              int j = s_idx[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))];
+              if(GN && ghost_root != nullptr && j >= nlocal) j = ghost_root[j - nlocal];
+              if(GN || j < nlocal) {
+                unsafeAtomicAdd(f + 3 * (size_t)j + 0, (real)(-(px * c_out))); unsafeAtomicAdd(f + 3 * (size_t)j + 1, (real)(-(py * c_out)));
+                unsafeAtomicAdd(f + 3 * (size_t)j + 2, (real)(-(pz * c_out)));
+              }
+            }
+          } else
           if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, (double)px); unsafeAtomicAdd(a + 1, (double)py); unsafeAtomicAdd(a + 2, (double)pz); }   // (ablate: profiling only)
           if(EV) {
             real scale = (real)1.0;
@@ -565,7 +604,11 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   if(wv == 0 && i >= 0) {
     fx += s_f[lane]; fy += s_f[64 + lane]; fz += s_f[128 + lane];
     const unsigned own = tile_self[(size_t)tile * 64 + lane];
-    if(own != 0xffffu) {          // the atom is one of the tile's candidates: its own force joins that accumulator (sign: see flush)
+    if(LJH_PACK && own != 0xffffu && fmaxf(fabsf((float)fx), fabsf((float)fy)) < LJH_FIX_SUM) {
+      ((unsigned long long*)s_acc)[3 * own] += ljh_pack_xy(-(float)fx, -(float)fy);
+      s_acc[3 * own + 1] -= (double)fz;
+    } else
+    if(!LJH_PACK && own != 0xffffu) {          // the atom is one of the tile's candidates: its own force joins that accumulator (sign: see flush)
       s_acc[3 * own] -= (double)fx; s_acc[3 * own + 1] -= (double)fy; s_acc[3 * own + 2] -= (double)fz;
     } else {
       real* fi = f + 3 * (size_t)i;
@@ -578,7 +621,13 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   for(int e = tid; e < 3 * ncand && !(ablate & 2); e += NT) {
     const int t = (int)(((unsigned)e * 43691u) >> 17);      // e / 3 (exact below 98304)
     int j = s_idx[t];
-    const double a = s_acc[e];
+    double a = s_acc[e];
+    if(LJH_PACK) {                       // record = {x and y packed, z as a double, unused}
+      const int c = e - 3 * t;
+      double ax, ay;
+      ljh_unpack_xy(((const unsigned long long*)s_acc)[3 * t], ax, ay);
+      a = c == 0 ? ax : (c == 1 ? ay : s_acc[3 * t + 1]);
+    }
     // one rank: a ghost is an image of an owned atom, its share goes straight to the owner (Comm::reverse_communicate folded in)
     if(GN && ghost_root != nullptr && j >= nlocal) j = ghost_root[j - nlocal];
     if((GN || j < nlocal) && a != 0) unsafeAtomicAdd(f + 3 * (size_t)j + (e - 3 * t), (real)(-(a * (double)c_out)));

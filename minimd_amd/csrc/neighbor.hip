@@ -802,12 +802,29 @@ __global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__
 // balanced rows, and candidates below every tile atom are dropped in the cull, so the union is the upper half shell only.
 // mmd_neighbor_download re-homes the owned pairs to the reference's `j > i` partition (k_rows_to_ref_half).
 // ---------------------------------------------------------------------------------------------------
+#ifndef NB2_BATCH
 #define NB2_BATCH 4            // chunks of 64 candidates in flight per batch of loads
+#endif
+#ifndef NB2_BUF
 #define NB2_BUF 448            // LDS candidate buffer (slots); flushed between batches when fewer than 64*NB2_BATCH are free
+#endif
 #define NB2_NE (4 * NB2_BUF / 64)   // list entries (non-empty hit words) per lane that fit the recycled candidate buffer
 #define NB2_NG 40              // groups of 32 tested candidates a tile may produce (more: the global-row build takes over)
 static_assert(NB2_NG <= 64, "a lane keeps its parked groups in a 64-bit mask");
 #define NB2_PF (MMD_PRECISION == 2)
+// Double precision, round 4: the float pre-test is evaluated as |a|^2 + |b|^2 - 2 a.b on coordinates relative to the tile's CENTRE: the buffer
+// holds -2b and |b|^2 of every candidate, a lane keeps its atom a and thr = cutneighsq - |a|^2, so d = rsq - cutneighsq costs three packed
+// fma + one packed subtract per TWO candidates (the difference form: three subtracts + three fma), the hit bit is the SIGN of d shifted into
+// the lane's word by one v_alignbit_b32 (no v_cmp / v_addc pair), and a running min3 of |d| says at the end of a group of 32 whether any pair
+// of the lane came closer to the threshold than the error bound of this arithmetic — only then (about one lane-group in five tiles at LJ
+// density) are the candidates of the group looked at one by one and the pairs inside the band re-tested exactly in double. 5 instead of
+// 8.3 VALU instructions per candidate; rows are still those of an all-double build. -DNB2_DOT=0: the difference form with two thresholds.
+#ifndef NB2_DOT
+#define NB2_DOT 1
+#endif
+#define NB2_DOTF (NB2_PF && NB2_DOT)
+#define NB2_NARR (NB2_DOTF ? 5 : 4)            // arrays of the candidate buffer: DOT -2x | -2y | -2z | |b|^2 | index, otherwise x | y | z | index
+#define NB2_IDX ((NB2_NARR - 1) * NB2_BUF)     // the atom index (bit pattern) of a buffered candidate
 
 // bits = (bits << 1) | (my bit of m): one VALU instruction (carry-in = the compare mask)
 __device__ __forceinline__ unsigned nb2_shift_in(unsigned bits, unsigned long long m)
@@ -818,6 +835,14 @@ __device__ __forceinline__ unsigned nb2_shift_in(unsigned bits, unsigned long lo
 }
 
 typedef float nb2_f2 __attribute__((ext_vector_type(2)));
+// bits = (bits << 1) | sign(d): one v_alignbit_b32
+__device__ __forceinline__ unsigned nb2_shift_sign(unsigned bits, float d) { return __builtin_amdgcn_alignbit(bits, __float_as_uint(d), 31); }
+// min(acc, |a|, |b|): one v_min3_f32 with source modifiers
+__device__ __forceinline__ float nb2_min3_abs(float acc, float a, float b)
+{
+  asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(acc) : "v"(a), "v"(b));
+  return acc;
+}
 
 template <int MODE, int CORE>
 __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, const int* __restrict__ binned,
@@ -837,7 +862,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   __shared__ int rng_start[NB_MAX_ROWS], rng_len[NB_MAX_ROWS];
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
-  __shared__ __align__(16) float s_buf[4 * NB2_BUF];
+  __shared__ __align__(16) float s_buf[NB2_NARR * NB2_BUF];
   // (the group number of a lane's list entries is not stored: bit g of the lane's gmask says "I parked a word for group g", entries are in group order)
   __shared__ unsigned char s_own[MODE != 0 ? NB2_BUF : 8];      // half lists: which tile atom the candidate is (0xff: none)
   __shared__ unsigned short s_selfpos[64];            // buffer position of each tile atom's own candidate record (0xffff: not in this buffer)
@@ -899,8 +924,18 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float cull = (float)cutneighsq * 1.001f + 1.0e-4f;
   // PF: local origin = the box's lower corner (exact in `real`); |local coordinate| of my atom and of every candidate that
   // survives the cull is <= Lmax, which bounds the float error of the pre-test's rsq
-  const real ox = NB2_PF ? (real)bx0 : (real)0, oy = NB2_PF ? (real)by0 : (real)0, oz = NB2_PF ? (real)bz0 : (real)0;
+  // (DOT: the box's centre — halves the magnitudes that enter the products)
+  const real ox = NB2_DOTF ? (real)(0.5f * (bx0 + bx1)) : (NB2_PF ? (real)bx0 : (real)0), oy = NB2_DOTF ? (real)(0.5f * (by0 + by1)) : (NB2_PF ? (real)by0 : (real)0),
+             oz = NB2_DOTF ? (real)(0.5f * (bz0 + bz1)) : (NB2_PF ? (real)bz0 : (real)0);
   const float Lmax = fmaxf(fmaxf(bx1 - bx0, by1 - by0), bz1 - bz0) + 1.01f * (float)cutneigh + 0.01f;
+  // DOT error model: |a_c| <= La, |b_c| <= Lb per coordinate (a = tile atom, b = a candidate that survived the cull). Worst-case absolute error
+  // of d against the exact rsq - cutneighsq of the double positions, in units of 2^-24: rounding of the local coordinates to float
+  // 6 cut (La + Lb), |b|^2 by three operations of magnitude <= 3 Lb^2 (9 Lb^2), the three fma of the chain with partial sums
+  // <= 3 Lb^2 + 6 La Lb, thr = float(cutneighsq - |a|^2) (|thr| <= cutneighsq + 3 La^2). The band is twice that.
+  const float La = 0.5f * fmaxf(fmaxf(bx1 - bx0, by1 - by0), bz1 - bz0) + 1.0e-3f, Lb = La + 1.01f * (float)cutneigh + 0.01f;
+  const float eps_dot = 2.0f * 5.96046448e-08f /* 2^-24 */ *
+                        (6.0f * (float)cutneigh * (La + Lb) + 18.0f * Lb * Lb + 18.0f * La * Lb + (float)cutneighsq + 3.0f * La * La);
+  const float ztol2 = 4.0f * 5.96046448e-08f * 2.0f * (La + Lb);      // band of zz = 2 (z_a - z_b) in float (half lists), 4x its worst-case error
   const float eps = 4.76837158e-07f /* 2^-21 */ * (3.0f * (float)cutneigh * Lmax + (float)cutneighsq);
   const float cut_lo = (float)cutneighsq - eps, cut_hi = (float)cutneighsq + eps;
   // half lists: a pair is kept by the atom BELOW it — partner above in (z,y,x) order on the exact positions, the rule of
@@ -912,8 +947,14 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float ztol = 4.76837158e-07f * Lmax;
   const float zcull = bz0 - fabsf(bz0) * 2.4e-7f - 1.0e-30f;      // a candidate below every tile atom is nobody's upper partner
   // lanes without an owned atom sit far away on the other side of the padding candidates: never a hit
-  const float fxi = owned ? (float)(pme.x - ox) : -1.0e15f, fyi = owned ? (float)(pme.y - oy) : -1.0e15f, fzi = owned ? (float)(pme.z - oz) : -1.0e15f;
+  // (DOT: such lanes sit at the centre with a threshold of -1e30: d = |b|^2 + 1e30 > 0 for every candidate)
+  const float far_i = NB2_DOTF ? 0.0f : -1.0e15f;
+  const float fxi = owned ? (float)(pme.x - ox) : far_i, fyi = owned ? (float)(pme.y - oy) : far_i, fzi = owned ? (float)(pme.z - oz) : far_i;
   const float zlo = fzi + ztol, zhi = fzi - ztol;
+  const double aa_d = (double)fxi * (double)fxi + (double)fyi * (double)fyi + (double)fzi * (double)fzi;
+  const float thr_i = owned ? (float)((double)cutneighsq - aa_d) : -1.0e30f;              // d = (|b|^2 - 2 a.b) - thr_i = rsq - cutneighsq
+  const float thrc_i = owned ? (float)((double)core_thr - aa_d) : -1.0e30f;               // CORE: the same against the core radius
+  const float twofz = 2.0f * fzi;
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
@@ -933,8 +974,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   auto flush = [&]() {
     const int fill8 = (fill + 7) & ~7;
     if(lane < fill8 - fill) {
-      s_buf[fill + lane] = 1.0e15f; s_buf[NB2_BUF + fill + lane] = 1.0e15f; s_buf[2 * NB2_BUF + fill + lane] = 1.0e15f;
-      s_buf[3 * NB2_BUF + fill + lane] = __int_as_float((int)0x80000000);      // (an owned index as far as MODE 1 is concerned)
+      if(NB2_DOTF) {                      // -2 b and |b|^2 of a candidate at (1e15, 1e15, 1e15)
+        s_buf[fill + lane] = -2.0e15f; s_buf[NB2_BUF + fill + lane] = -2.0e15f; s_buf[2 * NB2_BUF + fill + lane] = -2.0e15f;
+        s_buf[3 * NB2_BUF + fill + lane] = 3.0e30f;
+      } else { s_buf[fill + lane] = 1.0e15f; s_buf[NB2_BUF + fill + lane] = 1.0e15f; s_buf[2 * NB2_BUF + fill + lane] = 1.0e15f; }
+      s_buf[NB2_IDX + fill + lane] = __int_as_float((int)0x80000000);      // (an owned index as far as MODE 1 is concerned)
       if(MODE != 0) s_own[fill + lane] = (unsigned char)0xff;
     }
     __syncthreads();
@@ -942,6 +986,67 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0, bits_c = 0;
+      if constexpr(NB2_DOTF) {
+        unsigned bits_z = 0;
+        float acc = 3.0e38f, accz = 3.0e38f;       // smallest |d| (and |zz|) of this lane in the group
+        const nb2_f2 AX2 = {fxi, fxi}, AY2 = {fyi, fyi}, AZ2 = {fzi, fzi}, THR2 = {thr_i, thr_i}, THRC2 = {thrc_i, thrc_i}, TFZ2 = {twofz, twofz};
+        for(int q = 0; q < G; q += 8) {
+          const float4* vx = (const float4*)&s_buf[gq + q];
+          const float4* vy = (const float4*)&s_buf[NB2_BUF + gq + q];
+          const float4* vz = (const float4*)&s_buf[2 * NB2_BUF + gq + q];
+          const float4* vb = (const float4*)&s_buf[3 * NB2_BUF + gq + q];
+          nb2_f2 mx2[4], my2[4], mz2[4], bb2[4];
+#pragma unroll
+          for(int u = 0; u < 2; u++) {
+            const float4 tx = vx[u], ty = vy[u], tz = vz[u], tb = vb[u];
+            mx2[2 * u] = nb2_f2{tx.x, tx.y}; mx2[2 * u + 1] = nb2_f2{tx.z, tx.w};
+            my2[2 * u] = nb2_f2{ty.x, ty.y}; my2[2 * u + 1] = nb2_f2{ty.z, ty.w};
+            mz2[2 * u] = nb2_f2{tz.x, tz.y}; mz2[2 * u + 1] = nb2_f2{tz.z, tz.w};
+            bb2[2 * u] = nb2_f2{tb.x, tb.y}; bb2[2 * u + 1] = nb2_f2{tb.z, tb.w};
+          }
+#pragma unroll
+          for(int u2 = 0; u2 < 4; u2++) {
+            const nb2_f2 t2 = __builtin_elementwise_fma(AZ2, mz2[u2], __builtin_elementwise_fma(AY2, my2[u2], __builtin_elementwise_fma(AX2, mx2[u2], bb2[u2])));
+            const nb2_f2 d2 = t2 - THR2;
+            bits = nb2_shift_sign(bits, d2.x); bits = nb2_shift_sign(bits, d2.y);
+            acc = nb2_min3_abs(acc, d2.x, d2.y);
+            if(CORE) { const nb2_f2 c2 = t2 - THRC2; bits_c = nb2_shift_sign(bits_c, c2.x); bits_c = nb2_shift_sign(bits_c, c2.y); }
+            if(MODE != 0) {                          // partner above me in z: zz = 2 (z_a - z_b) < 0
+              const nb2_f2 z2 = mz2[u2] + TFZ2;
+              bits_z = nb2_shift_sign(bits_z, z2.x); bits_z = nb2_shift_sign(bits_z, z2.y);
+              accz = nb2_min3_abs(accz, z2.x, z2.y);
+            }
+          }
+        }
+        // candidate q of the group sits at bit G-1-q
+        if(MODE == 1) {                              // without ghost newton a ghost partner is kept by whoever sees it
+          const unsigned long long gm = __builtin_amdgcn_ballot_w64(lane < G && __float_as_int(s_buf[NB2_IDX + gq + lane]) >= nlocal);
+          bits_z |= __brev((unsigned)gm) >> (32 - G);
+        }
+        if(MODE != 0) bits &= bits_z;
+        const bool amb = acc < eps_dot || (MODE != 0 && accz < ztol2);
+        if(__builtin_amdgcn_ballot_w64(amb) != 0ull) {
+          // some lane has a pair inside the error band: walk the group once, re-evaluate d per candidate (the same operations: the same
+          // value) and decide the pairs inside the band exactly, in double, from the global positions (ref/neighbor.cpp:165,179)
+          for(int qq = 0; qq < G; qq++) {
+            const float mx = s_buf[gq + qq], my = s_buf[NB2_BUF + gq + qq], mz = s_buf[2 * NB2_BUF + gq + qq], bb = s_buf[3 * NB2_BUF + gq + qq];
+            const float d = __builtin_fmaf(fzi, mz, __builtin_fmaf(fyi, my, __builtin_fmaf(fxi, mx, bb))) - thr_i;
+            bool need = amb && fabsf(d) < eps_dot;
+            if(MODE != 0) need = need || (amb && fabsf(mz + twofz) < ztol2 && d < eps_dot);
+            if(need) {
+              const int jx = __float_as_int(s_buf[NB2_IDX + gq + qq]);
+              const real4 pj = x[jx];
+              const real dx = pme.x - pj.x, dy = pme.y - pj.y, dz = pme.z - pj.z;
+              const real rsq = dx * dx + dy * dy + dz * dz;
+              bool ok = rsq <= cutneighsq;
+              if(MODE != 0 && !(MODE == 1 && jx >= nlocal))
+                ok = ok && (pj.z > pme.z || (pj.z == pme.z && (pj.y > pme.y || (pj.y == pme.y && pj.x > pme.x))));
+              const unsigned bm = 1u << (G - 1 - qq);
+              bits = ok ? (bits | bm) : (bits & ~bm);
+            }
+          }
+        }
+      } else {
       for(int q = 0; q < G; q += 8) {
         // 8 buffered candidates per trip: 6 ds_read_b128 (uniform addresses). On this part a VALU instruction costs a
         // wavefront the same issue slot whether it is 32 or 64 bits wide, but v_pk_*_f32 handles TWO floats per lane: the
@@ -991,7 +1096,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                 rule_hi = rule;
               }
               if(MODE == 1) {                                        // without ghost newton a ghost partner is kept by whoever sees it
-                const int cju = __builtin_amdgcn_readfirstlane(__float_as_int(s_buf[3 * NB2_BUF + gq + q + u]));
+                const int cju = __builtin_amdgcn_readfirstlane(__float_as_int(s_buf[NB2_IDX + gq + q + u]));
                 if(cju >= nlocal) { rule = ~0ull; rule_hi = ~0ull; }
               }
               m &= rule; mh &= rule_hi;
@@ -1009,7 +1114,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           while(amb) {
             const int bq = __builtin_ctz(amb);
             amb &= amb - 1;
-            const int jx = __float_as_int(s_buf[3 * NB2_BUF + gq + (G - 1 - bq)]);
+            const int jx = __float_as_int(s_buf[NB2_IDX + gq + (G - 1 - bq)]);
             const real4 pj = x[jx];
             const real dx = pme.x - pj.x, dy = pme.y - pj.y, dz = pme.z - pj.z;
             const real rsq = dx * dx + dy * dy + dz * dz;
@@ -1020,6 +1125,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           }
         }
       }
+      }       // (difference form)
       // full lists: the atom itself (rsq = 0) is a hit of its own lane: dropped here
       if(MODE == 0) { const unsigned sp = (unsigned)(selfpos - gq); if(sp < (unsigned)G) bits &= ~(1u << (G - 1 - sp)); }
       // ---- the candidates some lane keeps form the tile's union: they get the next slots, in candidate order
@@ -1028,11 +1134,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         const int bq = G - 1 - lane;
         if((used >> bq) & 1u) {
           const int slot = S + __popc(used >> 1 >> bq);           // used candidates before mine
-          if(slot < cstride - 1) tile_cand[cbase + slot] = __float_as_int(s_buf[3 * NB2_BUF + gq + lane]);
+          if(slot < cstride - 1) tile_cand[cbase + slot] = __float_as_int(s_buf[NB2_IDX + gq + lane]);
           if(MODE != 0) { const unsigned own = s_own[gq + lane]; if(own != 0xffu) s_self[own] = (unsigned short)slot; }
         }
       }
-      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && __float_as_int(s_buf[3 * NB2_BUF + gq + lane]) >= nlocal) != 0ull;
+      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && __float_as_int(s_buf[NB2_IDX + gq + lane]) >= nlocal) != 0ull;
       // ---- a lane's NON-EMPTY hit words wait, with their group numbers, in a scratch list (lane-interleaved, read back by
       // the same lane) for the lock-step expansion at the end of the tile
       if(gcount < NB2_NG) {
@@ -1096,8 +1202,12 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       if(m) {
         const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if(keep) {
-          s_buf[pos] = (float)(pp[u].x - ox); s_buf[NB2_BUF + pos] = (float)(pp[u].y - oy); s_buf[2 * NB2_BUF + pos] = (float)(pp[u].z - oz);
-          s_buf[3 * NB2_BUF + pos] = __int_as_float(cjv);
+          const float lx = (float)(pp[u].x - ox), ly = (float)(pp[u].y - oy), lz = (float)(pp[u].z - oz);
+          if(NB2_DOTF) {
+            s_buf[pos] = -2.0f * lx; s_buf[NB2_BUF + pos] = -2.0f * ly; s_buf[2 * NB2_BUF + pos] = -2.0f * lz;
+            s_buf[3 * NB2_BUF + pos] = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+          } else { s_buf[pos] = lx; s_buf[NB2_BUF + pos] = ly; s_buf[2 * NB2_BUF + pos] = lz; }
+          s_buf[NB2_IDX + pos] = __int_as_float(cjv);
           const unsigned own = (unsigned)(aa[u] - ta);                   // the tile's own atoms are binned[ta .. ta+63]
           if(MODE != 0) s_own[pos] = own < 64u ? (unsigned char)own : (unsigned char)0xff;
           if(MODE == 0 && own < 64u) s_selfpos[own] = (unsigned short)pos;
@@ -1435,7 +1545,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
         if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         hipLaunchKernelGGL(k_tile_reduce, dim3(std::min(32, std::max(1, div_up(h->ntiles, 1024)))), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
                            h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr);
-        order_here = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport) && h->ntiles > 0;
+        order_here = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport || h->opt_overlap >= 2) && h->ntiles > 0;
         if(order_here) {                  // several ranks: the interior-first order of the halo overlap, no extra host synchronisation
           const int nb_o = div_up(h->ntiles, 1024);
           MMD_TRY(h->tile_order.ensure((size_t)h->ntiles + 8, false, h->stream));

@@ -559,13 +559,17 @@ def test_baseline_eam_s64():
     s.close()
 
 
-def test_config_e_full_size_sp_half_lists_against_this_codes_own_dp_run():
-    """BASELINE configs[4] at its real size: -s 160 (16 384 000 atoms), single precision, half neighbor lists with the
-    third-law scatter, 100 steps. No SP row of the reference is pinned at this size (its float sums have lost their digits,
-    DESIGN.md §6), so the run is judged by size-independent properties and against the DP half-list run of the same box:
-    atoms conserved with unique tags, total force ~ 0, the initial lists hold exactly the pairs the DP build finds,
-    rows within the reference's SP pass rule of the DP rows, and U at step 100 = -5.65 (liquid at this state point)."""
+def test_config_e_full_size_dp_equals_the_reference_row_and_sp_follows_dp():
+    """BASELINE configs[4] at its real size: -s 160 (16 384 000 atoms), half neighbor lists with the third-law scatter, 100 steps.
+    DOUBLE precision: the rows equal the row the UNMODIFIED reference printed for this configuration (tests/golden/ref_runs.json
+    `lj_s160_half_n100`, a 10-minute run of oracle/_ref/miniMD_ref_dp -s 160 --half_neigh 1 -t 8) to the printed digits, ghost count and
+    neighbor total equal its YAML report. SINGLE precision (the configuration BASELINE names): no SP row of the reference is pinned at
+    this size (its float sums have lost their digits), so the SP run is judged by size-independent properties — atoms
+    conserved with unique tags, total force ~ 0, the initial lists hold exactly the pairs the DP build finds — and against the DP rows
+    within float-trajectory bounds."""
     natoms = 4 * 160 ** 3
+    ent = REFRUNS["lj_s160_half_n100"]
+    assert ent["natoms"] == natoms
     out = {}
     for prec in ("dp", "sp"):
         s = mm().Sim(["-s", 160, "-n", 100, "--half_neigh", 1], precision=prec)
@@ -586,6 +590,13 @@ def test_config_e_full_size_sp_half_lists_against_this_codes_own_dp_run():
             del d, f, x
         out[prec] = (s.rows(), tot0, tot, ng)
         s.close()
+    # ---- DP against the reference's own row
+    rows_close(out["dp"][0], ent["rows"], 2e-6)
+    for a, b in zip(out["dp"][0], ent["rows"]):
+        assert [fmt7(v) for v in a[1:4]] == [fmt7(v) for v in b[1:4]], (a, b)               # digit for digit
+    assert abs(out["dp"][3] - ent["nghost"]) <= 5e-6 * ent["nghost"]                     # (6 printed digits)
+    assert abs(out["dp"][2] - ent["neigh_total"]) <= 5e-6 * ent["neigh_total"]            # (the YAML report prints 6 digits)
+    # ---- SP against DP
     assert out["sp"][1] == out["dp"][1]                       # the lattice has no pair within float rounding of the cutoff
     assert abs(out["sp"][2] - out["dp"][2]) <= 2e-4 * out["dp"][2] and abs(out["sp"][3] - out["dp"][3]) <= 2e-4 * out["dp"][3]    # (float trajectories drift: other pairs sit inside the skin after 100 steps)
     assert [r[0] for r in out["sp"][0]] == [0, 100]
@@ -597,9 +608,45 @@ def test_config_e_full_size_sp_half_lists_against_this_codes_own_dp_run():
         assert abs(a[1] - b[1]) <= 1e-2 * abs(b[1]) and abs(a[2] - b[2]) <= 2e-3 * abs(b[2]) and abs(a[3] - b[3]) <= 5e-2, (a, b)
     t, u, p = out["sp"][0][-1][1:]
     assert abs(u - (-5.652)) < 5e-3 and abs(t - 0.695) < 5e-3
-    # DP rows at this size against the exact lattice values of step 0 (1.44 / -6.773368 / -5.01967)
-    t0, u0, p0 = out["dp"][0][0][1:]
-    assert fmt7(t0) == fmt7(1.44) and fmt7(u0) == fmt7(-6.773368) and abs(p0 - (-5.01967)) < 2e-5
+
+
+# ---- the reference's CoMD-parameter decks (ref/in.lj.miniMD_comd, ref/in.eam.miniMD_comd; values in data/in.*.miniMD_comd) ------------------
+@pytest.mark.parametrize("name", ["lj_comd_s10_full_n1000", "lj_comd_s10_half_n1000", "lj_comd_s10_full_n300_sp", "eam_comd_s10_full_n300",
+                                  "eam_comd_s10_half_n300"])
+def test_comd_decks_match_the_reference_rows(name):
+    """in.lj.miniMD_comd is the only deck with epsilon, sigma != 1 (0.167 / 2.315, cutoff 4.59, dt 5e-5): it exercises the folded constant
+    c_out = 48 eps sigma^6 of the LJ tile kernels away from 48 and a 704 000-entry list on 4000 atoms (176 neighbors per atom); in.eam.miniMD_comd
+    runs EAM at another density with skin 0.5 and a thermo row every 10 steps. Rows of the unmodified reference (tests/golden/ref_runs.json):
+    <= 2e-6 relative to step 300, <= 1.5e-5 to step 1000, plus the reference's own pass rule; neighbor totals and ghost counts of its YAML report."""
+    ent = REFRUNS[name]
+    prec = ent["precision"]
+    s = mm().Sim([a for a in ent["args"]], precision=prec, cwd=os.path.join(REPO, "data"))
+    s.initial(); s.run()
+    rows = s.rows()
+    eam = name.startswith("eam")
+    if prec == "dp":
+        rows_close(rows, ent["rows"], 1.5e-5)
+        for a, b in zip(rows, ent["rows"]):
+            if a[0] <= 300:
+                for k in (1, 2, 3):
+                    assert abs(a[k] - b[k]) <= 2e-6 * max(1.0, abs(b[k])), (a, b)
+    else:
+        # single precision: the reference sums 704 000 pair energies of ~+0.9 each in FLOAT — its own step-0 row reads U = 166.5229, P = 221.5665
+        # where the exact lattice values (its DP build, and this code in either precision: sums in double, rounded once) are 166.3043 / 221.2786.
+        # The SP run is therefore judged against the reference's DOUBLE rows with the reference's SP pass rule, and against the reference's SP
+        # rows only as far as their own summation error allows (2.5e-3).
+        dp_rows = [r for r in REFRUNS["lj_comd_s10_full_n1000"]["rows"] if r[0] <= 300]
+        rows_close(rows, dp_rows, 2e-4)
+        for k in (1, 2, 3):
+            assert abs(rows[0][k] - dp_rows[0][k]) <= 2e-5 * max(1.0, abs(dp_rows[0][k])), (rows[0], dp_rows[0])
+        rows_close(rows, ent["rows"], 2.5e-3)
+        assert ref_pass_rule(dp_rows, rows, ent["natoms"], 4, eam=eam)[0]
+    if prec == "dp":
+        assert ref_pass_rule(ent["rows"], rows, ent["natoms"], 8, eam=eam)[0]
+    nl, ng, _ = s.handle.counts()
+    assert nl == ent["natoms"] and ng == int(ent["nghost"])
+    assert abs(s.handle.neighbor_info()["total"] - ent["neigh_total"]) <= 5e-6 * ent["neigh_total"] + (2 if prec == "sp" else 0)
+    s.close()
 
 
 @pytest.mark.parametrize("name", ["lj_s1_full_n60", "lj_1x3x2_half_n60", "lj_1x3x2_full_n60", "eam_2x1x3_full_n60"])
