@@ -292,7 +292,7 @@ def main():
     k_ms = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
     achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
     traffic, traffic_source = None, None
-    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if world == 1 and args.size == 80 and os.path.exists(tpath):
             # HBM bytes per launch of the same kernel on the same workload from the committed rocprofv3 --pmc passes

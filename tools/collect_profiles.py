@@ -80,7 +80,9 @@ row("B' LJ half -s 80 DP", "k_lj_half_tile<0, 1>", "kernel_stats_Bh.md", N80, 26
 row("C EAM -s 64 DP: density sweep", "k_eam_density_tile<0, 0>", "kernel_stats_C.md", N64, 4 * 60.25 + 4 + 28 + 8 + 0.167 * 28, "pmc_eam.txt", "k_eam_density_tile<0, 0>", "")
 row("C EAM -s 64 DP: force sweep (fused integrator)", "k_eam_force_tile<0, 1, 0>", "kernel_stats_C.md", N64, 4 * 60.25 + 4 + 28 + 8 + 24 + 0.167 * 8, "pmc_eam.txt", "k_eam_force_tile<0, 1, 0>", "both sweeps + fp halo: 592 B/atom; rows in two parts, core part on 18 of 20 steps")
 row("E LJ half -s 160 SP", "k_lj_half_tile<0, 1>", "kernel_stats_E.md", N160, 211, note="")
-row("Neighbor build -s 80 DP (per rebuild)", "k_build_rows<0, 0>", "kernel_stats_bench.md", N80, 347, "pmc_build.txt", "k_build_rows<0, 0>", "instruction-issue bound (3.6e8 VALU instructions per launch)")
+row("Neighbor build -s 80 DP (per rebuild)", "k_build_rows<0, 0>", "kernel_stats_bench.md", N80, 347, "pmc_build.txt", "k_build_rows<0, 0>", "instruction-issue bound (%s VALU + %s SALU + %s LDS wave-instructions per launch)" % tuple(
+        ("%.2e" % v) if v else "?" for v in (pmc("pmc_build.txt", "k_build_rows<0, 0>", "SQ_INSTS_VALU"), pmc("pmc_build.txt", "k_build_rows<0, 0>", "SQ_INSTS_SALU"),
+                                             pmc("pmc_build.txt", "k_build_rows<0, 0>", "SQ_INSTS_LDS"))))
 row("Neighbor build -s 160 SP half (per rebuild)", "k_build_rows<2, 0>", "kernel_stats_E.md", N160, 190, note="")
 hdr = ["# %s — per-kernel roofline table (8 TB/s HBM3E peak)" % tag, "",
        "Average durations: `rocprofv3 --kernel-trace --stats` of the un-modified commands (`profiles/%s_kernel_stats_*.md`); algorithmic bytes: SURVEY.md §8(d);" % tag,
