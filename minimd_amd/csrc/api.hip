@@ -39,6 +39,7 @@ extern "C" int mmd_create(int device, mmd_handle** out)
   HIP_TRY(hipHostMalloc((void**)&h->h_result, 32 * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&h->d_result, 32 * sizeof(double)));
   HIP_TRY(hipHostMalloc((void**)&h->h_flags, 64 * sizeof(int), hipHostMallocDefault));
+  { int khz = 0; if(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) == hipSuccess && khz > 0) h->clk_rate_hz = 1.0e3 * khz; (void)hipGetLastError(); }
   HIP_TRY(hipHostMalloc((void**)&h->h_flags_big, 64 * sizeof(int), hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&h->d_flags, 64 * sizeof(int)));
   HIP_TRY(hipMemset(h->d_result, 0, 32 * sizeof(double)));
@@ -111,6 +112,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "core_pct")) h->opt_core_pct = value;
   else if(!strcmp(name, "borders_fast")) h->opt_borders_fast = value;
   else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
+  else if(!strcmp(name, "spin_readback")) h->opt_spin_readback = value;
   else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) {
@@ -246,8 +248,10 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     ~TransientGuard() {
       h->fuse_now = 0; h->resolve_now = false; h->fold_reverse_now = false; h->core.mode_now = 0; h->zero_f_in_integrate = false;
       h->halo_pending = false; h->in_reneighbor = false; h->pbc_defer = false; h->launch_ev_a = h->launch_ev_b = nullptr;
+      h->in_run = false;
     }
   } transient_guard{h};
+  h->in_run = true;
   // (a previous run that failed mid-step may have left the ghosts one step behind their owners)
   if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -331,8 +335,15 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       // phase clocks are event pairs on the stream (no host synchronisation just to read a clock); the pairs that have
       // completed are folded into the timers after the build, whose own count read-back has drained the stream anyway
       h->in_reneighbor = true;
-      int rc = ev_begin(h, 2);
       const bool sort_now = first_step + n + 1 >= h->next_sort;
+      // phase clocks: one rank with Atom::sort in the window and the production build — the first kernel of each phase (k_bin_count of the sort,
+      // k_bin_count of the build) and k_tile_reduce stamp the device's wall clock into the build's result words; otherwise event pairs on the stream
+      // (each record costs the stream a marker packet, ~5 us of idle GPU)
+      const bool dev_clock = h->clk_rate_hz > 0 && h->opt_spin_readback && h->nprocs == 1 && !h->opt_force_transport && sort_now && h->opt_async_counts &&
+                             h->nlocal > 0 && h->neigh_ready && h->opt_tiles && h->opt_build == 1 && h->tiles_ready && !h->opt_check_exchange;
+      h->clk_written = 0;
+      h->clk_slot = dev_clock ? 0 : -1;
+      int rc = dev_clock ? 0 : ev_begin(h, 2);
       // one rank: Comm::exchange is Atom::pbc alone; when Atom::sort follows, its binning pass wraps the atoms on the way
       h->pbc_defer = sort_now && h->nprocs == 1 && h->opt_async_counts && h->nlocal > 0 && h->neigh_ready;
       if(rc >= 0) rc = mmd_comm_exchange(h);
@@ -343,10 +354,21 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       h->in_reneighbor = false;
       MMD_TRY(rc);
       if(h->opt_check_exchange) MMD_TRY(mmd_integrate_mark_positions(h));
-      MMD_TRY(ev_end(h));
-      MMD_TRY(ev_begin(h, 3));
+      if(!dev_clock) { MMD_TRY(ev_end(h)); MMD_TRY(ev_begin(h, 3)); }
+      else h->clk_slot = 1;
       MMD_TRY(mmd_neighbor_build(h));
-      MMD_TRY(ev_end(h));
+      h->clk_slot = -1;
+      if(!dev_clock) MMD_TRY(ev_end(h));
+      else if(h->clk_written == 7) {
+        // (a build that went through a fall-back or ran twice leaves stamps that do not line up: that re-neighboring is not clocked)
+        long long c[3];
+        memcpy(c, h->h_flags + 56, sizeof(c));
+        if(c[0] > h->clk_last && c[1] >= c[0] && c[2] >= c[1]) {
+          const double t_comm = (double)(c[1] - c[0]) / h->clk_rate_hz, t_neigh = (double)(c[2] - c[1]) / h->clk_rate_hz;
+          h->timer[1] += t_comm; h->timer[4] += t_comm; h->timer[3] += t_neigh;       // ref/integrate.cpp:155-166
+          h->clk_last = c[2];
+        }
+      }
       core_next = 1;                               // the atoms are where the build saw them
       collect_pending = true;                  // (folded into the timers once this step's force kernel is in flight)
     }

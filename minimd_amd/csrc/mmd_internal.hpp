@@ -269,6 +269,14 @@ struct mmd_handle {
   double* h_result = nullptr;  // pinned host: [0..7]
   double* d_result = nullptr;
   int* h_flags = nullptr;      // pinned host ints
+  int* h_flags_dev = nullptr;  // device view of h_flags (k_publish_flags)
+  int flag_seq = 0;
+  int clk_slot = -1;           // >= 0: the next k_bin_count stamps the device wall clock into result word pair 56 + 2 * clk_slot (phase clocks of a re-neighboring)
+  int clk_written = 0;         // bit s: slot s was stamped in this re-neighboring; bit 2: the build published its words (incl. its own stamp)
+  long long clk_last = 0;      // last stamp seen (stamps of one re-neighboring must lie behind it and ascend)
+  double clk_rate_hz = 0;      // hipDeviceAttributeWallClockRate
+  int opt_spin_readback = 1;   // Integrate::run: the host polls pinned memory for the build's results instead of blocking on the stream
+  bool in_run = false;         // inside mmd_integrate_run
   int* h_flags_big = nullptr;  // pinned host ints (64): read-back of the device-resident borders state
   std::vector<int> h_bstate;
   int* d_flags = nullptr;

@@ -162,8 +162,11 @@ __device__ __forceinline__ int bin_of(const BinGeom& g, real x, real y, real z)
 // wrap and bin the owned atoms in one pass.
 __global__ __launch_bounds__(256) void k_bin_count(real4* __restrict__ x, int n, BinGeom g, int* __restrict__ atom_bin, int* __restrict__ atom_rank,
                                                    int* __restrict__ bin_count, int nlocal, const int* __restrict__ nghost_dev, int pbc,
-                                                   real xprd, real yprd, real zprd)
+                                                   real xprd, real yprd, real zprd, long long* __restrict__ clk)
 {
+  // (phase clocks of a re-neighboring: the first kernel of a phase stamps the device's constant-rate wall clock into a result word that returns
+  //  with the build's flags — no event packets on the stream)
+  if(clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *clk = wall_clock64();
   n = deferred_count(n, nlocal, nghost_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -268,7 +271,8 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   // (dense bins, e.g. `-b 1`: the long-bin rank sort is on from the first binning, not only once a build has seen such a bin)
   if(!h->big_bins && (long long)n > 32LL * g.mbin[0] * g.mbin[1] * g.mbin[2]) h->big_bins = true;     // (this rank's bins, not the global grid)
   if(n) hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->x.p, n, g, h->atom_bin.p, h->atom_rank.p, h->bin_count.p, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr,
-                           h->pbc_pending ? 1 : 0, h->prd[0], h->prd[1], h->prd[2]);
+                           h->pbc_pending ? 1 : 0, h->prd[0], h->prd[1], h->prd[2], h->clk_slot >= 0 ? (long long*)(h->d_flags + 56 + 2 * h->clk_slot) : (long long*)nullptr);
+  if(n && h->clk_slot >= 0) { h->clk_written |= 1 << h->clk_slot; h->clk_slot = -1; }
   h->pbc_pending = false;
   MMD_TRY(mmd_exclusive_scan_from(h, h->bin_count.p, h->bin_start.p, g.mbins, nullptr));
   hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n > 0 ? n : 1, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p, h->d_flags + 12, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr);
@@ -1301,6 +1305,7 @@ __global__ __launch_bounds__(1024) void k_tile_reduce(const int* __restrict__ ti
   // a few workgroups, one slice of the tiles each, three atomics per workgroup into words k_tile_fill / k_pencil_fill zeroed
   // (one workgroup walking all 32 k tiles took 20 us)
   __shared__ int s_a[16], s_b[16];
+  if(blockIdx.x == 0 && threadIdx.x == 0) *(long long*)(flags + 60) = wall_clock64();                   // end of the build phase (see k_bin_count)
   if(blockIdx.x == 0 && bst && threadIdx.x < 40) flags[16 + threadIdx.x] = bst[threadIdx.x];          // deferred one-rank borders: its counts travel with the flags
   if(ntiles_dev) { if(blockIdx.x == 0 && threadIdx.x == 0) flags[6] = *ntiles_dev; ntiles = min(ntiles, *ntiles_dev); }     // flags[6]: the count for the host
   __shared__ long long s_c[16];
@@ -1438,6 +1443,39 @@ int mmd_ensure_rows(mmd_handle* h)
   return finish_rows(h, false);
 }
 
+// The build's result words travel to the host as stores of a kernel into pinned memory, closed by a sequence number with system scope;
+// the host spins on that word (no runtime call in the loop). After two seconds without it the blocking wait takes over (and reports
+// whatever went wrong on the stream).
+__global__ __launch_bounds__(64) void k_publish_flags(const int* __restrict__ src, int* __restrict__ dst, int n, int seq)
+{
+  const int t = threadIdx.x;
+  if(t < n) dst[t] = src[t];
+  __threadfence_system();
+  __syncthreads();
+  if(t == 0) __hip_atomic_store(dst + 62, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int flags_publish_and_wait(mmd_handle* h, int n)
+{
+  if(!h->h_flags_dev) HIP_TRY(hipHostGetDevicePointer((void**)&h->h_flags_dev, h->h_flags, 0));
+  const int seq = ++h->flag_seq;
+  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, h->stream, (const int*)h->d_flags, h->h_flags_dev, n, seq);
+  HIP_TRY(hipGetLastError());
+  h->host_syncs++;
+  const double t0 = mmd_wall();
+  unsigned long spins = 0;
+  while(__atomic_load_n(&h->h_flags[62], __ATOMIC_ACQUIRE) != seq) {
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+    __builtin_ia32_pause();
+#endif
+    if((++spins & 0x3fff) == 0 && mmd_wall() - t0 > 2.0) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if(__atomic_load_n(&h->h_flags[62], __ATOMIC_ACQUIRE) != seq) { mmd_set_error("neighbor build: the result words did not reach the host"); return -1; }
+      break;
+    }
+  }
+  return 0;
+}
+
 extern "C" int mmd_neighbor_build(mmd_handle* h)
 {
   if(!h || !h->neigh_ready) { mmd_set_error("mmd_neighbor_build: call mmd_neighbor_setup first"); return -1; }
@@ -1564,9 +1602,16 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
       // [0..3] results, [4..5] total, [6] tile count, [12] long-bin flag, [16..55] bst of a deferred one-rank borders
+      if(h->opt_build == 1 && h->opt_spin_readback && h->in_run) {
+        // inside Integrate::run the build's results are PUBLISHED into pinned host memory by a one-wavefront kernel and the host polls that
+        // memory: a blocking stream wait costs the wake-up of a sleeping thread (~40 us between the copy and the next force kernel)
+        MMD_TRY(flags_publish_and_wait(h, 62));
+        h->clk_written |= 4;
+      } else {
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, (h->nghost_dev ? 56 : 16) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       if(h->opt_build != 1) HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(mmd_stream_sync(h));
+      }
       if(h->opt_build == 1) memcpy(h->h_result, h->h_flags + 4, sizeof(double));
       if(h->nghost_dev) {                   // the ghost counts of the deferred one-rank borders arrived with the flags
         memcpy(h->h_flags_big, h->h_flags + 16, 40 * sizeof(int));
