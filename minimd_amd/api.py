@@ -272,6 +272,24 @@ class Handle:
         self._chk(self.L.mmd_force_compute(self.h, evflag, C.byref(e), C.byref(v)))
         return e.value, v.value
 
+    def set_fp_halo(self, fn):
+        """install (fn(fp: np.ndarray[nlocal+nghost], nlocal, nghost) -> None, fills fp[nlocal:]) or remove (None) the caller's ForceEAM::communicate"""
+        if fn is None:
+            self._fp_cb = None
+            self._chk(self.L.mmd_force_eam_set_fp_halo(self.h, None, None))
+            return
+        creal = self.L._creal
+
+        def _cb(ctx, buf, nlocal, nghost):
+            try:
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(creal)), shape=(nlocal + nghost,))
+                fn(arr, nlocal, nghost)
+                return 0
+            except Exception:  # noqa: BLE001
+                return -1
+        self._fp_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)(_cb)      # keep the trampoline alive
+        self._chk(self.L.mmd_force_eam_set_fp_halo(self.h, C.cast(self._fp_cb, C.c_void_p), None))
+
     def eam_fp(self):
         nl, ng, _ = self.counts()
         fp = np.zeros(nl + ng, self.real)

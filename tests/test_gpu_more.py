@@ -1064,6 +1064,75 @@ def test_reference_program_runs_on_the_plugin(prec, lists):
     assert "ForceHIP:" not in r.stderr                   # (the plugin reports C-ABI errors there)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [0, 1])
+def test_uploaded_list_older_than_the_positions(half):
+    """a list handed over by mmd_neighbor_upload need not be fresh: the oracle's list of step 20 with its positions of step 27 (atoms have
+    drifted: a partner may lie outside the candidate runs of its tile, then k_rows_to_tiles leaves the list to the row kernels). Whichever
+    kernels serve it, forces, energy and virial are those of the oracle on the same list and positions; then only the positions move
+    (mmd_atom_upload_x) and the same list keeps serving them."""
+    o = Oracle(["-s", 8, "-n", 27, "--half_neigh", half, "-gn", 0])
+    o.initial(); o.run()
+    o.lib.orc_force_compute(o.w, 1)
+    h = handle_from_oracle(o)
+    h.force_lj_setup(*o.lj_tables())
+    h.neighbor_upload(o.neighbors(), o.numneigh())
+    for tiles in (1, 0):
+        h.set_option("tiles", tiles)
+        eng, vir = h.force_compute(1)
+        f = h.download(halfneigh=bool(half))["f"]
+        fo = o.f(with_ghosts=bool(half))
+        assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+        assert abs(eng - o.eng_vdwl()) <= 1e-11 * abs(o.eng_vdwl()) and abs(vir - o.virial()) <= 1e-10 * max(1.0, abs(o.virial()))
+    h.set_option("tiles", 1)
+    if not half:
+        # positions only: every owned atom nudged, ghosts follow their owners' shift is NOT required by the API (the caller's Comm does that):
+        # here the whole array is shifted rigidly, which leaves every pair distance — and so every force — unchanged
+        x = o.x() + np.array([0.01, -0.02, 0.005])
+        h.upload_x(x)
+        np.testing.assert_array_equal(h.download()["x"], x)
+        eng2, vir2 = h.force_compute(1)
+        f2 = h.download()["f"]
+        assert np.abs(f2 - o.f()).max() <= 1e-10 * np.abs(o.f()).max() and abs(eng2 - eng) <= 1e-11 * abs(eng)
+        with pytest.raises(Exception):
+            h.upload_x(x[:-1])                               # another atom count is an error, not a silent truncation
+    h.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_eam_with_uploaded_ghosts_needs_the_callers_fp_halo():
+    """ghost atoms that came through mmd_atom_upload (a reference Atom incl. its ghosts) have no send lists in this handle: ForceEAM::compute
+    fails loudly unless the caller's ForceEAM::communicate is installed (mmd_force_eam_set_fp_halo, what ForceEAMHIP does with the reference's
+    Comm); with it — here the oracle's fp of the ghosts — forces, fp and energy are the oracle's."""
+    ntypes = 1
+    o = Oracle(["-i", "in.eam.miniMD", "-s", 5, "-n", 20, "--half_neigh", 0, "--ntypes", ntypes])
+    o.initial(); o.run()
+    h = handle_from_oracle(o)                         # atoms AND ghosts uploaded; no comm_setup / borders on this handle
+    from minimd_amd import api
+    h.force_eam_setup(ntypes, api.eam_tables_from_file(os.path.join(REPO, "data", "Cu_u6.eam"), ntypes))
+    h.neighbor_upload(o.neighbors(), o.numneigh())
+    with pytest.raises(Exception, match="fp_halo|borders"):
+        h.force_compute(1)
+    fpo = o.eam_fp()
+    seen = {}
+
+    def halo(fp, nlocal, nghost):
+        seen["owned_err"] = float(np.abs(fp[:nlocal] - fpo[:nlocal]).max())
+        fp[nlocal:] = fpo[nlocal:nlocal + nghost]
+    h.set_fp_halo(halo)
+    for tiles in (1, 0):
+        h.set_option("tiles", tiles)
+        eng, vir = h.force_compute(1)
+        assert seen["owned_err"] <= 1e-12 * np.abs(fpo).max()
+        f, fo = h.download()["f"], o.f()
+        assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+        assert abs(eng - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl())
+    h.set_fp_halo(None)
+    with pytest.raises(Exception):
+        h.force_compute(1)
+    h.close(); o.close()
+
+
 def _run_ref_program(exe_name, deck, lists, nsteps=200, size=10):
     exe = os.path.join(REPO, "oracle", "_ref", exe_name)
     if not os.path.exists(exe):
