@@ -194,7 +194,8 @@ def test_documented_force_plugin_compiles_against_the_reference_headers():
     r = subprocess.run(["make", "-s", "-C", os.path.join(REPO, "tests", "integration"), "check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     text = open(os.path.join(REPO, "INTEGRATION.md")).read()
-    assert "tests/integration/force_hip.h" in text
+    for fn in ("tests/integration/force_hip.h", "tests/integration/force_eam_hip.h", "tests/integration/neighbor_hip.cpp"):
+        assert fn in text and os.path.exists(os.path.join(REPO, fn))
 
 
 # ---- the user-facing validation harness (ref/run_one_test, ref/run_tests restated as tools/run_one_test.py) -------------------
