@@ -826,9 +826,14 @@ static_assert(NB2_NG <= 64, "a lane keeps its parked groups in a 64-bit mask");
 #ifndef NB2_DOT
 #define NB2_DOT 1
 #endif
-#define NB2_DOTF (NB2_PF && NB2_DOT)
-#define NB2_NARR (NB2_DOTF ? 5 : 4)            // arrays of the candidate buffer: DOT -2x | -2y | -2z | |b|^2 | index, otherwise x | y | z | index
-#define NB2_IDX ((NB2_NARR - 1) * NB2_BUF)     // the atom index (bit pattern) of a buffered candidate
+#ifndef NB2_DOT_SP
+#define NB2_DOT_SP 1                           // single precision: the same pre-test; the exact re-test then is the reference's own float expression
+#endif
+// FULL lists only. Half lists keep the difference form: every tile atom is a candidate of its own tile, and the atom itself has zz = 2 (z_a - z_b) = 0
+// exactly — a running min of |zz| (the z-order rule's ambiguity measure) is zero in every group that holds the lane's own atom, which sends two or
+// three groups per tile through the one-by-one walk (measured: k_build_rows<2,0> 527 -> 820 us at -s 80; EAM half 314 -> 438 us). Excluding the
+// atom itself costs two more instructions per candidate, which is what the form saves.
+#define NB2_DOTF(MODE) (NB2_DOT && (MODE) == 0 && (NB2_PF || NB2_DOT_SP))
 
 // bits = (bits << 1) | (my bit of m): one VALU instruction (carry-in = the compare mask)
 __device__ __forceinline__ unsigned nb2_shift_in(unsigned bits, unsigned long long m)
@@ -866,6 +871,9 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   __shared__ int rng_start[NB_MAX_ROWS], rng_len[NB_MAX_ROWS];
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
+  constexpr bool DOTK = NB2_DOTF(MODE);
+  constexpr int NB2_NARR = DOTK ? 5 : 4;             // arrays of the candidate buffer: DOT -2x | -2y | -2z | |b|^2 | index, otherwise x | y | z | index
+  constexpr int NB2_IDX = (NB2_NARR - 1) * NB2_BUF;  // the atom index (bit pattern) of a buffered candidate
   __shared__ __align__(16) float s_buf[NB2_NARR * NB2_BUF];
   // (the group number of a lane's list entries is not stored: bit g of the lane's gmask says "I parked a word for group g", entries are in group order)
   __shared__ unsigned char s_own[MODE != 0 ? NB2_BUF : 8];      // half lists: which tile atom the candidate is (0xff: none)
@@ -929,8 +937,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // PF: local origin = the box's lower corner (exact in `real`); |local coordinate| of my atom and of every candidate that
   // survives the cull is <= Lmax, which bounds the float error of the pre-test's rsq
   // (DOT: the box's centre — halves the magnitudes that enter the products)
-  const real ox = NB2_DOTF ? (real)(0.5f * (bx0 + bx1)) : (NB2_PF ? (real)bx0 : (real)0), oy = NB2_DOTF ? (real)(0.5f * (by0 + by1)) : (NB2_PF ? (real)by0 : (real)0),
-             oz = NB2_DOTF ? (real)(0.5f * (bz0 + bz1)) : (NB2_PF ? (real)bz0 : (real)0);
+  const real ox = DOTK ? (real)(0.5f * (bx0 + bx1)) : (NB2_PF ? (real)bx0 : (real)0), oy = DOTK ? (real)(0.5f * (by0 + by1)) : (NB2_PF ? (real)by0 : (real)0),
+             oz = DOTK ? (real)(0.5f * (bz0 + bz1)) : (NB2_PF ? (real)bz0 : (real)0);
   const float Lmax = fmaxf(fmaxf(bx1 - bx0, by1 - by0), bz1 - bz0) + 1.01f * (float)cutneigh + 0.01f;
   // DOT error model: |a_c| <= La, |b_c| <= Lb per coordinate (a = tile atom, b = a candidate that survived the cull). Worst-case absolute error
   // of d against the exact rsq - cutneighsq of the double positions, in units of 2^-24: rounding of the local coordinates to float
@@ -938,8 +946,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // <= 3 Lb^2 + 6 La Lb, thr = float(cutneighsq - |a|^2) (|thr| <= cutneighsq + 3 La^2). The band is twice that.
   const float La = 0.5f * fmaxf(fmaxf(bx1 - bx0, by1 - by0), bz1 - bz0) + 1.0e-3f, Lb = La + 1.01f * (float)cutneigh + 0.01f;
   const float eps_dot = 2.0f * 5.96046448e-08f /* 2^-24 */ *
-                        (6.0f * (float)cutneigh * (La + Lb) + 18.0f * Lb * Lb + 18.0f * La * Lb + (float)cutneighsq + 3.0f * La * La);
-  const float ztol2 = 4.0f * 5.96046448e-08f * 2.0f * (La + Lb);      // band of zz = 2 (z_a - z_b) in float (half lists), 4x its worst-case error
+                        (6.0f * (float)cutneigh * (La + Lb) + 18.0f * Lb * Lb + 18.0f * La * Lb + (float)cutneighsq + 3.0f * La * La +
+                         // single precision: what has to be reproduced is the reference's FLOAT rsq (three products, two sums: <= 4 roundings of
+                         // magnitude cutneigh^2 away from the exact rsq of the float positions) — the band covers that too
+                         (NB2_PF ? 0.0f : 8.0f * (float)cutneighsq));
   const float eps = 4.76837158e-07f /* 2^-21 */ * (3.0f * (float)cutneigh * Lmax + (float)cutneighsq);
   const float cut_lo = (float)cutneighsq - eps, cut_hi = (float)cutneighsq + eps;
   // half lists: a pair is kept by the atom BELOW it — partner above in (z,y,x) order on the exact positions, the rule of
@@ -952,13 +962,12 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float zcull = bz0 - fabsf(bz0) * 2.4e-7f - 1.0e-30f;      // a candidate below every tile atom is nobody's upper partner
   // lanes without an owned atom sit far away on the other side of the padding candidates: never a hit
   // (DOT: such lanes sit at the centre with a threshold of -1e30: d = |b|^2 + 1e30 > 0 for every candidate)
-  const float far_i = NB2_DOTF ? 0.0f : -1.0e15f;
+  const float far_i = DOTK ? 0.0f : -1.0e15f;
   const float fxi = owned ? (float)(pme.x - ox) : far_i, fyi = owned ? (float)(pme.y - oy) : far_i, fzi = owned ? (float)(pme.z - oz) : far_i;
   const float zlo = fzi + ztol, zhi = fzi - ztol;
   const double aa_d = (double)fxi * (double)fxi + (double)fyi * (double)fyi + (double)fzi * (double)fzi;
   const float thr_i = owned ? (float)((double)cutneighsq - aa_d) : -1.0e30f;              // d = (|b|^2 - 2 a.b) - thr_i = rsq - cutneighsq
   const float thrc_i = owned ? (float)((double)core_thr - aa_d) : -1.0e30f;               // CORE: the same against the core radius
-  const float twofz = 2.0f * fzi;
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
@@ -978,7 +987,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   auto flush = [&]() {
     const int fill8 = (fill + 7) & ~7;
     if(lane < fill8 - fill) {
-      if(NB2_DOTF) {                      // -2 b and |b|^2 of a candidate at (1e15, 1e15, 1e15)
+      if(DOTK) {                      // -2 b and |b|^2 of a candidate at (1e15, 1e15, 1e15)
         s_buf[fill + lane] = -2.0e15f; s_buf[NB2_BUF + fill + lane] = -2.0e15f; s_buf[2 * NB2_BUF + fill + lane] = -2.0e15f;
         s_buf[3 * NB2_BUF + fill + lane] = 3.0e30f;
       } else { s_buf[fill + lane] = 1.0e15f; s_buf[NB2_BUF + fill + lane] = 1.0e15f; s_buf[2 * NB2_BUF + fill + lane] = 1.0e15f; }
@@ -990,10 +999,9 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0, bits_c = 0;
-      if constexpr(NB2_DOTF) {
-        unsigned bits_z = 0;
-        float acc = 3.0e38f, accz = 3.0e38f;       // smallest |d| (and |zz|) of this lane in the group
-        const nb2_f2 AX2 = {fxi, fxi}, AY2 = {fyi, fyi}, AZ2 = {fzi, fzi}, THR2 = {thr_i, thr_i}, THRC2 = {thrc_i, thrc_i}, TFZ2 = {twofz, twofz};
+      if constexpr(DOTK) {
+        float acc = 3.0e38f;                         // smallest |d| of this lane in the group
+        const nb2_f2 AX2 = {fxi, fxi}, AY2 = {fyi, fyi}, AZ2 = {fzi, fzi}, THR2 = {thr_i, thr_i}, THRC2 = {thrc_i, thrc_i};
         for(int q = 0; q < G; q += 8) {
           const float4* vx = (const float4*)&s_buf[gq + q];
           const float4* vy = (const float4*)&s_buf[NB2_BUF + gq + q];
@@ -1015,36 +1023,22 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             bits = nb2_shift_sign(bits, d2.x); bits = nb2_shift_sign(bits, d2.y);
             acc = nb2_min3_abs(acc, d2.x, d2.y);
             if(CORE) { const nb2_f2 c2 = t2 - THRC2; bits_c = nb2_shift_sign(bits_c, c2.x); bits_c = nb2_shift_sign(bits_c, c2.y); }
-            if(MODE != 0) {                          // partner above me in z: zz = 2 (z_a - z_b) < 0
-              const nb2_f2 z2 = mz2[u2] + TFZ2;
-              bits_z = nb2_shift_sign(bits_z, z2.x); bits_z = nb2_shift_sign(bits_z, z2.y);
-              accz = nb2_min3_abs(accz, z2.x, z2.y);
-            }
           }
         }
         // candidate q of the group sits at bit G-1-q
-        if(MODE == 1) {                              // without ghost newton a ghost partner is kept by whoever sees it
-          const unsigned long long gm = __builtin_amdgcn_ballot_w64(lane < G && __float_as_int(s_buf[NB2_IDX + gq + lane]) >= nlocal);
-          bits_z |= __brev((unsigned)gm) >> (32 - G);
-        }
-        if(MODE != 0) bits &= bits_z;
-        const bool amb = acc < eps_dot || (MODE != 0 && accz < ztol2);
+        const bool amb = acc < eps_dot;
         if(__builtin_amdgcn_ballot_w64(amb) != 0ull) {
           // some lane has a pair inside the error band: walk the group once, re-evaluate d per candidate (the same operations: the same
           // value) and decide the pairs inside the band exactly, in double, from the global positions (ref/neighbor.cpp:165,179)
           for(int qq = 0; qq < G; qq++) {
             const float mx = s_buf[gq + qq], my = s_buf[NB2_BUF + gq + qq], mz = s_buf[2 * NB2_BUF + gq + qq], bb = s_buf[3 * NB2_BUF + gq + qq];
             const float d = __builtin_fmaf(fzi, mz, __builtin_fmaf(fyi, my, __builtin_fmaf(fxi, mx, bb))) - thr_i;
-            bool need = amb && fabsf(d) < eps_dot;
-            if(MODE != 0) need = need || (amb && fabsf(mz + twofz) < ztol2 && d < eps_dot);
-            if(need) {
+            if(amb && fabsf(d) < eps_dot) {
               const int jx = __float_as_int(s_buf[NB2_IDX + gq + qq]);
               const real4 pj = x[jx];
               const real dx = pme.x - pj.x, dy = pme.y - pj.y, dz = pme.z - pj.z;
               const real rsq = dx * dx + dy * dy + dz * dz;
-              bool ok = rsq <= cutneighsq;
-              if(MODE != 0 && !(MODE == 1 && jx >= nlocal))
-                ok = ok && (pj.z > pme.z || (pj.z == pme.z && (pj.y > pme.y || (pj.y == pme.y && pj.x > pme.x))));
+              const bool ok = rsq <= cutneighsq;
               const unsigned bm = 1u << (G - 1 - qq);
               bits = ok ? (bits | bm) : (bits & ~bm);
             }
@@ -1207,7 +1201,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if(keep) {
           const float lx = (float)(pp[u].x - ox), ly = (float)(pp[u].y - oy), lz = (float)(pp[u].z - oz);
-          if(NB2_DOTF) {
+          if(DOTK) {
             s_buf[pos] = -2.0f * lx; s_buf[NB2_BUF + pos] = -2.0f * ly; s_buf[2 * NB2_BUF + pos] = -2.0f * lz;
             s_buf[3 * NB2_BUF + pos] = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
           } else { s_buf[pos] = lx; s_buf[NB2_BUF + pos] = ly; s_buf[2 * NB2_BUF + pos] = lz; }
