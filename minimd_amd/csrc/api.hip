@@ -464,6 +464,11 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "borders_general")) *value = h->borders_general_runs;
   else if(!strcmp(name, "device_bins_coarser")) *value = h->neigh_ready && (h->bg.nbin[0] != h->bg_ref.nbin[0] || h->bg.nbin[1] != h->bg_ref.nbin[1] || h->bg.nbin[2] != h->bg_ref.nbin[2]) ? 1 : 0;
   else if(!strcmp(name, "tiles_ready")) *value = h->tiles_ready ? 1 : 0;
+  else if(!strcmp(name, "eam_lds_density")) *value = h->eam_diag[0];
+  else if(!strcmp(name, "eam_lds_force")) *value = h->eam_diag[1];
+  else if(!strcmp(name, "eam_wg_density")) *value = h->eam_diag[2];
+  else if(!strcmp(name, "eam_wg_force")) *value = h->eam_diag[3];
+  else if(!strcmp(name, "tile_cmax")) *value = h->tile_cmax;
   else if(!strcmp(name, "rows_uploaded")) *value = h->rows_uploaded ? 1 : 0;
   else { mmd_set_error("mmd_get_counter: unknown counter '%s'", name); return -1; }
   return 0;

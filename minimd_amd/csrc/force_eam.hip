@@ -401,7 +401,12 @@ __device__ __forceinline__ float rsqrt_fast(float a)
 #endif
 #define EAM_TU 4              // row padding granularity of the tile lists (NB_ROW_PAD) = pairs per trip of the density sweep
 #define EAM_DSTRIDE 6         // reals per knot record of the density sweep's LDS table
-#define EAM_FSTRIDE 10        // reals per knot record of the force sweep's LDS table
+#ifndef EAM_FSTRIDE
+#define EAM_FSTRIDE 10        // reals per knot record of the force sweep's LDS table (7 are used; 7 = packed records, read as ds_read_b64: tuning variant)
+#endif
+#ifndef EAM_LDS_BUDGET
+#define EAM_LDS_BUDGET (150 * 1024)     // LDS of a CU the persistent grids are sized for
+#endif
 #ifndef EAM_FU
 #define EAM_FU 4              // pairs per trip of the force sweep (+ one trip of EAM_TU where 4 rows remain)
 #endif
@@ -621,9 +626,10 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   double* s_red = (double*)(((size_t)(s_f + 3 * 64 * (EAM_FW - 1)) + 7) & ~(size_t)7);
   int* s_idx = (int*)(s_red + 16);                                     // HALF: the candidates' atom indices, for the flush
   unsigned char* s_gh = (unsigned char*)(s_idx + ((cmax + 2 + 3) & ~3)); // HALF && EV: candidate is a ghost
-  for(int t = tid; t < (nr + 1 - mlo) * 8; t += NT) {
-    const int m = (t >> 3) + mlo, c = t & 7;
-    s_tab[(t >> 3) * EAM_FSTRIDE + c] = c < 3 ? rhor_spline[m * 7 + c] : (c < 7 ? z2r_spline[m * 7 + c] : (real)0);
+  for(int t = tid; t < (nr + 1 - mlo) * 7; t += NT) {
+    const int q = (int)(((unsigned)t * 9363u) >> 16);       // t / 7 (exact below 13108)
+    const int m = q + mlo, c = t - 7 * q;
+    s_tab[q * EAM_FSTRIDE + c] = c < 3 ? rhor_spline[m * 7 + c] : z2r_spline[m * 7 + c];
   }
   const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;     // persistent workgroups, see k_eam_density_tile
   const bool use_core = eam_use_core(C, lane);
@@ -986,8 +992,8 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     MMD_TRY(mmd_zero_forces(h, nall));
     const size_t tl1 = eam_tile_lds_density_half(h), tl2 = eam_tile_lds_force_half(h);
     const int cus = h->prop.multiProcessorCount;
-    const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl1 + 512)))) / 8 * 8);
-    const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 512)))) / 8 * 8);
+    const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, EAM_LDS_BUDGET / (tl1 + 512)))) / 8 * 8);
+    const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, EAM_LDS_BUDGET / (tl2 + 512)))) / 8 * 8);
     if(!h->eam_half_attr_set) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -1071,8 +1077,9 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     MMD_TRY(h->partials.ensure((size_t)3 * nt + 8, false, h->stream));
     // persistent grids: as many workgroups as fit the LDS budget of every CU (multiple of 8 for the XCD split)
     const int cus = h->prop.multiProcessorCount;
-    const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl1 + 512)))) / 8 * 8);
-    const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (tl2 + 512)))) / 8 * 8);
+    const int pgrid1 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, EAM_LDS_BUDGET / (tl1 + 512)))) / 8 * 8);
+    const int pgrid2 = std::max(8, (int)(cus * std::max<size_t>(1, std::min<size_t>(8, EAM_LDS_BUDGET / (tl2 + 512)))) / 8 * 8);
+    h->eam_diag[0] = (int)tl1; h->eam_diag[1] = (int)tl2; h->eam_diag[2] = pgrid1 / cus; h->eam_diag[3] = pgrid2 / cus;
     if(!h->eam_attr_set) {     // > 64 KiB of dynamic LDS needs the opt-in (per device: the flag lives in the handle)
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));

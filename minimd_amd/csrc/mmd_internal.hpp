@@ -207,6 +207,7 @@ struct mmd_handle {
   real rdr = 0, rdrho = 0;
   bool eam_uniform = true;
   int opt_eam_mlo = -1;      // first spline knot kept in LDS by the EAM tile kernels (-1: 0.3 x cutoff)
+  int eam_diag[4] = {0, 0, 0, 0};   // last full-list tile launch: LDS bytes of the two sweeps, workgroups per CU of their persistent grids
   bool eam_attr_set = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this handle's device
   DevArr<real> rhor_spline, frho_spline, z2r_spline, fp, rho;
   // ---- Comm

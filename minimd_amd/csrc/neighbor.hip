@@ -829,11 +829,18 @@ static_assert(NB2_NG <= 64, "a lane keeps its parked groups in a 64-bit mask");
 #ifndef NB2_DOT_SP
 #define NB2_DOT_SP 1                           // single precision: the same pre-test; the exact re-test then is the reference's own float expression
 #endif
-// FULL lists only. Half lists keep the difference form: every tile atom is a candidate of its own tile, and the atom itself has zz = 2 (z_a - z_b) = 0
-// exactly — a running min of |zz| (the z-order rule's ambiguity measure) is zero in every group that holds the lane's own atom, which sends two or
-// three groups per tile through the one-by-one walk (measured: k_build_rows<2,0> 527 -> 820 us at -s 80; EAM half 314 -> 438 us). Excluding the
-// atom itself costs two more instructions per candidate, which is what the form saves.
-#define NB2_DOTF(MODE) (NB2_DOT && (MODE) == 0 && (NB2_PF || NB2_DOT_SP))
+// Half lists: the z-order rule ("partner above me") travels the same way — zz = 2 (z_a - z_b) from the buffered -2 z_b, two sign words for
+// zz < -ztol ("surely above") and zz < +ztol ("possibly above"); a pair that is a distance hit and lies between the two is decided exactly.
+// (A running min of |zz| as the ambiguity measure does NOT work: every tile atom is a candidate of its own tile and has zz = 0 exactly against
+// itself, which sent two or three groups per tile through the one-by-one walk: k_build_rows<2,0> 527 -> 820 us at -s 80. The two words name the
+// candidates, so the atom itself is masked out with its buffer position like in the full-list kernel.)
+// Built, parity-green, and NOT faster than the difference form for half lists (same-box A/B at -s 80 / EAM -s 64 / -s 160 SP: 5293 vs 5290,
+// 2326 vs 2304, 7677 vs 7697 Matom-steps/s): half-list tiles test only the upper half shell (~310 candidates), their build is dominated by the cull
+// and the expansion. Off by default (tools/build_variant.sh <name> neighbor -DNB2_DOT_HALF=1).
+#ifndef NB2_DOT_HALF
+#define NB2_DOT_HALF 0
+#endif
+#define NB2_DOTF(MODE) (NB2_DOT && ((MODE) == 0 || NB2_DOT_HALF) && (NB2_PF || NB2_DOT_SP))
 
 // bits = (bits << 1) | (my bit of m): one VALU instruction (carry-in = the compare mask)
 __device__ __forceinline__ unsigned nb2_shift_in(unsigned bits, unsigned long long m)
@@ -961,6 +968,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float ztol = 4.76837158e-07f * Lmax;
   const float zcull = bz0 - fabsf(bz0) * 2.4e-7f - 1.0e-30f;      // a candidate below every tile atom is nobody's upper partner
   // lanes without an owned atom sit far away on the other side of the padding candidates: never a hit
+  const float ztol2 = 4.0f * 5.96046448e-08f * 2.0f * (La + Lb);      // band of zz = 2 (z_a - z_b) in float (half lists): 4x its worst-case error
   // (DOT: such lanes sit at the centre with a threshold of -1e30: d = |b|^2 + 1e30 > 0 for every candidate)
   const float far_i = DOTK ? 0.0f : -1.0e15f;
   const float fxi = owned ? (float)(pme.x - ox) : far_i, fyi = owned ? (float)(pme.y - oy) : far_i, fzi = owned ? (float)(pme.z - oz) : far_i;
@@ -968,6 +976,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const double aa_d = (double)fxi * (double)fxi + (double)fyi * (double)fyi + (double)fzi * (double)fzi;
   const float thr_i = owned ? (float)((double)cutneighsq - aa_d) : -1.0e30f;              // d = (|b|^2 - 2 a.b) - thr_i = rsq - cutneighsq
   const float thrc_i = owned ? (float)((double)core_thr - aa_d) : -1.0e30f;               // CORE: the same against the core radius
+  const float twofz = 2.0f * fzi;
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
@@ -995,13 +1004,15 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       if(MODE != 0) s_own[fill + lane] = (unsigned char)0xff;
     }
     __syncthreads();
-    const int selfpos = MODE == 0 ? (int)s_selfpos[lane] : -1;
+    const int selfpos = (MODE == 0 || DOTK) ? (int)s_selfpos[lane] : -1;
     for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0, bits_c = 0;
       if constexpr(DOTK) {
         float acc = 3.0e38f;                         // smallest |d| of this lane in the group
+        unsigned bits_zs = 0, bits_zp = 0;           // half lists: partner surely / possibly above me in z
         const nb2_f2 AX2 = {fxi, fxi}, AY2 = {fyi, fyi}, AZ2 = {fzi, fzi}, THR2 = {thr_i, thr_i}, THRC2 = {thrc_i, thrc_i};
+        const nb2_f2 ZS2 = {twofz + ztol2, twofz + ztol2}, ZP2 = {twofz - ztol2, twofz - ztol2};
         for(int q = 0; q < G; q += 8) {
           const float4* vx = (const float4*)&s_buf[gq + q];
           const float4* vy = (const float4*)&s_buf[NB2_BUF + gq + q];
@@ -1023,23 +1034,47 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             bits = nb2_shift_sign(bits, d2.x); bits = nb2_shift_sign(bits, d2.y);
             acc = nb2_min3_abs(acc, d2.x, d2.y);
             if(CORE) { const nb2_f2 c2 = t2 - THRC2; bits_c = nb2_shift_sign(bits_c, c2.x); bits_c = nb2_shift_sign(bits_c, c2.y); }
+            if(MODE != 0) {                          // zz = 2 (z_a - z_b) = twofz + (-2 z_b): above me <=> zz < 0
+              const nb2_f2 zs = mz2[u2] + ZS2, zp = mz2[u2] + ZP2;
+              bits_zs = nb2_shift_sign(bits_zs, zs.x); bits_zs = nb2_shift_sign(bits_zs, zs.y);
+              bits_zp = nb2_shift_sign(bits_zp, zp.x); bits_zp = nb2_shift_sign(bits_zp, zp.y);
+            }
           }
         }
         // candidate q of the group sits at bit G-1-q
-        const bool amb = acc < eps_dot;
+        unsigned zamb = 0;                           // half lists: distance hits whose z order the float test cannot decide
+        if(MODE != 0) {
+          if(MODE == 1) {                            // without ghost newton a ghost partner is kept by whoever sees it
+            const unsigned long long gm = __builtin_amdgcn_ballot_w64(lane < G && __float_as_int(s_buf[NB2_IDX + gq + lane]) >= nlocal);
+            const unsigned gb = __brev((unsigned)gm) >> (32 - G);
+            bits_zs |= gb; bits_zp |= gb;
+          }
+          zamb = bits & bits_zp & ~bits_zs;
+          const unsigned sp = (unsigned)(selfpos - gq);      // the atom itself: a distance hit with zz = 0 — never a partner
+          if(sp < (unsigned)G) zamb &= ~(1u << (G - 1 - sp));
+          bits &= bits_zs;
+        }
+        const bool amb = acc < eps_dot || zamb != 0u;
         if(__builtin_amdgcn_ballot_w64(amb) != 0ull) {
           // some lane has a pair inside the error band: walk the group once, re-evaluate d per candidate (the same operations: the same
           // value) and decide the pairs inside the band exactly, in double, from the global positions (ref/neighbor.cpp:165,179)
           for(int qq = 0; qq < G; qq++) {
             const float mx = s_buf[gq + qq], my = s_buf[NB2_BUF + gq + qq], mz = s_buf[2 * NB2_BUF + gq + qq], bb = s_buf[3 * NB2_BUF + gq + qq];
             const float d = __builtin_fmaf(fzi, mz, __builtin_fmaf(fyi, my, __builtin_fmaf(fxi, mx, bb))) - thr_i;
-            if(amb && fabsf(d) < eps_dot) {
+            const unsigned bm = 1u << (G - 1 - qq);
+            bool need = amb && fabsf(d) < eps_dot;
+            if(MODE != 0) {
+              // (a pair inside the distance band matters only where the z rule may keep it; the atom itself is never tested)
+              need = (need && ((bits_zp & bm) != 0u) && (unsigned)(selfpos - gq) != (unsigned)qq) || ((zamb & bm) != 0u);
+            }
+            if(need) {
               const int jx = __float_as_int(s_buf[NB2_IDX + gq + qq]);
               const real4 pj = x[jx];
               const real dx = pme.x - pj.x, dy = pme.y - pj.y, dz = pme.z - pj.z;
               const real rsq = dx * dx + dy * dy + dz * dz;
-              const bool ok = rsq <= cutneighsq;
-              const unsigned bm = 1u << (G - 1 - qq);
+              bool ok = rsq <= cutneighsq;
+              if(MODE != 0 && !(MODE == 1 && jx >= nlocal))
+                ok = ok && (pj.z > pme.z || (pj.z == pme.z && (pj.y > pme.y || (pj.y == pme.y && pj.x > pme.x))));
               bits = ok ? (bits | bm) : (bits & ~bm);
             }
           }
@@ -1155,7 +1190,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       n += __popc(bits);
       S += __popc(used);
     }
-    if(MODE == 0) s_selfpos[lane] = (unsigned short)0xffff;
+    if(MODE == 0 || DOTK) s_selfpos[lane] = (unsigned short)0xffff;
     __syncthreads();
     fill = 0;
   };
@@ -1208,7 +1243,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           s_buf[NB2_IDX + pos] = __int_as_float(cjv);
           const unsigned own = (unsigned)(aa[u] - ta);                   // the tile's own atoms are binned[ta .. ta+63]
           if(MODE != 0) s_own[pos] = own < 64u ? (unsigned char)own : (unsigned char)0xff;
-          if(MODE == 0 && own < 64u) s_selfpos[own] = (unsigned short)pos;
+          if((MODE == 0 || DOTK) && own < 64u) s_selfpos[own] = (unsigned short)pos;
         }
         fill += __popcll(m);
       }
