@@ -522,6 +522,33 @@ __global__ void k_pencil_fill(const int* __restrict__ pencil_range, int npencils
   }
 }
 
+// the same with the scan of the per-pencil tile counts folded in (re-neighborings inside a run, where nobody needs the count on the host before the
+// build has run): every workgroup sums the counts in front of it itself, the last one stores the total behind the counts (ntiles_dev of the build)
+__global__ __launch_bounds__(256) void k_pencil_fill_scan(const int* __restrict__ pencil_range, int npencils, int nblk0, int* __restrict__ ntile_of_pencil,
+                                                          int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags,
+                                                          int cap, real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev)
+{
+  __shared__ int lds[17];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if(p == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[7] = 0; }
+  if(p == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};    // the dummy atom, see k_tile_fill
+  const int before = block_prefix_total(ntile_of_pencil, blockIdx.x * 256, lds);
+  const int mine = p < npencils ? ntile_of_pencil[p] : 0;
+  int tot;
+  const int inc = block_incl_scan(mine, lds, &tot);
+  const int t0 = before + inc - mine, t1 = t0 + mine;
+  if(p < npencils) {
+    const int a0 = pencil_range[2 * p], a1 = pencil_range[2 * p + 1];
+    for(int t = t0; t < t1 && t < cap; t++) {
+      tile_block[t] = p * nblk0;
+      tile_first[t] = a0 + (t - t0) * 64;
+      tile_cnt[t] = min(64, a1 - tile_first[t]);
+    }
+  }
+  // (every workgroup has read the counts in front of it before the last one finishes? No: the total goes to slot [npencils], which nobody sums)
+  if(blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ntile_of_pencil[npencils] = before + tot;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fused tile build (full lists): same register-transposed test as k_build, but
 //   * hits go to an LDS row buffer rows[k][lane-of-atom] as raw candidate slots (ds_write_b16, no global
@@ -1483,6 +1510,8 @@ __global__ __launch_bounds__(64) void k_publish_flags(const int* __restrict__ sr
   __syncthreads();
   if(t == 0) __hip_atomic_store(dst + 62, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// (Publishing from the last workgroup of k_tile_reduce instead — one launch less — was built and measured: the 1024-thread workgroup's system-scope
+//  fence makes that kernel 14 instead of 6 us and bench.py --size 32 loses 2.7 %: 4480 against 4600 Matom-steps/s. A one-wavefront kernel it stays.)
 static int flags_publish_and_wait(mmd_handle* h, int n)
 {
   if(!h->h_flags_dev) HIP_TRY(hipHostGetDevicePointer((void**)&h->h_flags_dev, h->h_flags, 0));
@@ -1539,7 +1568,8 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     // comes back with the build's result flags: one host synchronisation less per re-neighboring
     int nt = 0;
     const bool nt_async = h->opt_build == 1 && h->opt_async_counts && h->ntiles_hint > 0;
-    MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nunits, nt_async ? nullptr : &nt));
+    const bool fill_scans = nt_async && pencil;           // (the fill kernel sums the counts itself: no scan launch)
+    if(!fill_scans) MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nunits, nt_async ? nullptr : &nt));
     if(nt_async) nt = h->ntiles_hint + h->ntiles_hint / 32 + 64;
     const int* nt_dev = nt_async ? h->tile_of_block.p + nunits : nullptr;
     h->ntiles = nt;
@@ -1578,7 +1608,10 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
-    if(pencil)
+    if(fill_scans)
+      hipLaunchKernelGGL(k_pencil_fill_scan, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
+                         h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev);
+    else if(pencil)
       hipLaunchKernelGGL(k_pencil_fill, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
                          h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev);
     else

@@ -72,6 +72,28 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int* src, int* d, int 
   }
 }
 
+// second launch of the two-launch scan: every workgroup sums the tile totals in front of it itself (a few hundred ints: no launch for a
+// scan of the totals), then scans its tile; the last workgroup also stores the grand total
+__global__ __launch_bounds__(256) void k_scan_apply_self(const int* src, int* d, int n, const int* __restrict__ sums, int* total)   // (src may be d)
+{
+  __shared__ int lds[17];
+  const int before = block_prefix_total(sums, blockIdx.x, lds);
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  int v[4];
+  int s = 0;
+#pragma unroll
+  for(int k = 0; k < 4; k++) { v[k] = base + k < n ? src[base + k] : 0; s += v[k]; }
+  int tot;
+  const int inc = block_incl_scan(s, lds, &tot);
+  int run = before + inc - s;
+#pragma unroll
+  for(int k = 0; k < 4; k++) {
+    if(base + k < n) d[base + k] = run;
+    run += v[k];
+  }
+  if(blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = before + tot;
+}
+
 // exclusive scan of src[n] into data[n] (src == data: in place). data[n] must be writable: the grand total is also stored there
 // (bin_start[mbins] convention)
 int mmd_exclusive_scan_from(mmd_handle* h, const int* src, int* data, int n, int* total_host)
@@ -82,8 +104,12 @@ int mmd_exclusive_scan_from(mmd_handle* h, const int* src, int* data, int n, int
     const int ntiles = div_up(n, SCAN_TILE);
     MMD_TRY(h->scan_tmp.ensure((size_t)ntiles + 8, false, h->stream));
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, h->stream, src, n, h->scan_tmp.p);
+    if(ntiles <= 8192) {      // two launches: each workgroup of the second sums the totals in front of it (<= 32 per thread)
+      hipLaunchKernelGGL(k_scan_apply_self, dim3(ntiles), dim3(256), 0, h->stream, src, data, n, (const int*)h->scan_tmp.p, data + n);
+    } else {
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, (const int*)h->scan_tmp.p, h->scan_tmp.p, ntiles, data + n);
     hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, h->stream, src, data, n, h->scan_tmp.p);
+    }
   }
   HIP_TRY(hipGetLastError());
   if(total_host) {
