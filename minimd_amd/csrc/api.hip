@@ -44,6 +44,9 @@ extern "C" int mmd_create(int device, mmd_handle** out)
   HIP_TRY(hipMalloc((void**)&h->d_flags, 64 * sizeof(int)));
   HIP_TRY(hipMemset(h->d_result, 0, 32 * sizeof(double)));
   HIP_TRY(hipMemset(h->d_flags, 0, 64 * sizeof(int)));
+  // (pinned memory comes back from the runtime's pool as the previous owner left it: the sequence word the host polls — h_flags[62],
+  //  flags_publish_and_wait — must not start with somebody else's number)
+  memset(h->h_flags, 0, 64 * sizeof(int)); memset(h->h_flags_big, 0, 64 * sizeof(int)); memset(h->h_result, 0, 32 * sizeof(double));
   *out = h;
   return 0;
 }
