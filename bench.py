@@ -355,6 +355,9 @@ def main():
         "phases_s_max": {k: max(r["phases_s"][k] for r in per_rank) for k in ("total", "comm", "force", "neigh", "extra")},
         "host_syncs_per_step": max(r["host_syncs"] for r in per_rank) / max(args.steps, 1),
         "host_syncs_per_rebuild": max(r["host_syncs"] for r in per_rank) / max(args.steps // 20, 1),
+        # Force::compute launches of re-neighboring steps that were enqueued behind the build, before its result words reached the host
+        # (whole life of the handle; "noop" = the build's verdict on the device cancelled them and the step loop launched again)
+        "force_launched_behind_build": {"launches": sim.handle.counter("spec_runs"), "noop": sim.handle.counter("spec_fails")},
         # waits of the host-staged test transport (ranks sharing a GPU): staging of messages through host memory, absent with RCCL
         "host_transport_syncs_per_step": max(r["transport_syncs"] for r in per_rank) / max(args.steps, 1),
         "halo_bytes_per_step": {"sum_over_ranks": sum(r["bytes_sent"] for r in per_rank) / max(args.steps, 1),

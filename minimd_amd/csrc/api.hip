@@ -65,7 +65,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->tile_cand.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
   for(auto& s : h->swaps) s.sendlist.release();
-  h->buf_send.release(); h->buf_recv.release(); h->est.release(); h->ex_list.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->partials.release();
+  h->buf_send.release(); h->buf_recv.release(); h->est.release(); h->ex_list.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->brd_bits.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if(h->ev_x_ready) { (void)hipEventDestroy(h->ev_x_ready); (void)hipEventDestroy(h->ev_halo_done); }
   h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release(); h->tile_words.release(); h->tile_kcore.release(); h->xbuild.release(); h->core_words.release();
@@ -116,6 +116,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "borders_fast")) h->opt_borders_fast = value;
   else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
   else if(!strcmp(name, "spin_readback")) h->opt_spin_readback = value;
+  else if(!strcmp(name, "spec")) h->opt_spec = value;
   else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) {
@@ -252,6 +253,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       h->fuse_now = 0; h->resolve_now = false; h->fold_reverse_now = false; h->core.mode_now = 0; h->zero_f_in_integrate = false;
       h->halo_pending = false; h->in_reneighbor = false; h->pbc_defer = false; h->launch_ev_a = h->launch_ev_b = nullptr;
       h->in_run = false;
+      h->spec_fn = nullptr; h->spec = SpecLaunch{nullptr, nullptr, nullptr}; h->spec_done = false;
     }
   } transient_guard{h};
   h->in_run = true;
@@ -287,6 +289,28 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     HIP_TRY(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
   }
   if(h->opt_check_exchange && h->xold_n != h->nlocal) MMD_TRY(mmd_integrate_mark_positions(h));
+  bool folded = false;
+  // Force::compute of step n (not overlapped with a halo): which kernel form, which transient switches — one place, because on a
+  // re-neighboring step the neighbor build may issue this launch itself, behind its own kernels (opt_spec, mmd_internal.hpp)
+  auto launch_force = [&](int n, int evflag) -> int {
+    fused_force = fuse_force && !evflag && n + 1 < ntimes && (h->style == 0 ? mmd_lj_can_fuse_integrate(h) : mmd_eam_can_fuse_integrate(h));
+    if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
+    h->fuse_now = fused_force;
+    h->resolve_now = h->ghosts_stale;
+    h->fold_reverse_now = folded = fold && h->ghost_chain_ok && mmd_lj_half_tiles_available(h);
+    h->core.mode_now = core_next;                // rows in two parts (CoreRows): which part this call may walk
+    h->core.tracked_last = false;
+    const int rc = force_compute_async(h, evflag, nullptr, nullptr, true);
+    h->fuse_now = 0;
+    h->resolve_now = false;
+    h->fold_reverse_now = false;
+    h->core.mode_now = 0;
+    core_next = h->core.tracked_last ? 2 : 0;
+    return rc;
+  };
+  // the launch behind the build: LJ over full lists in tile form on one rank, no halo overlap, lists of the previous build to size it from
+  const bool spec_static = h->opt_spec > 0 && h->style == 0 && !h->halfneigh && h->nprocs == 1 && !overlap && !h->opt_force_transport && h->opt_spin_readback &&
+                           h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && !h->opt_check_exchange && h->lj_uniform;
   for(int n = 0; n < ntimes; n++) {
     if(!initial_done) MMD_TRY(mmd_integrate_initial(h));
     initial_done = false;
@@ -326,6 +350,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       }
     } else {
       h->ghosts_stale = false;                   // (borders rebuilds every ghost)
+      const bool had_tiles = h->tiles_ready && h->neigh_nlocal == h->nlocal && h->nlocal > 0;
       if(h->opt_check_exchange && h->xold_n == h->nlocal) {    // ref/integrate.cpp:112-151 (warning text as there)
         double d_max = 0;
         MMD_TRY(mmd_integrate_max_move(h, &d_max));
@@ -359,7 +384,15 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       if(h->opt_check_exchange) MMD_TRY(mmd_integrate_mark_positions(h));
       if(!dev_clock) { MMD_TRY(ev_end(h)); MMD_TRY(ev_begin(h, 3)); }
       else h->clk_slot = 1;
-      MMD_TRY(mmd_neighbor_build(h));
+      core_next = 1;                               // the atoms are where the build saw them
+      h->spec_done = false;
+      {
+        const int ev_rb = thermo_nstat > 0 && ((first_step + n + 1) % thermo_nstat == 0);
+        if(spec_static && had_tiles && !ev_rb) h->spec_fn = [&launch_force, n]() { return launch_force(n, 0); };
+        const int rcb = mmd_neighbor_build(h);
+        h->spec_fn = nullptr;
+        MMD_TRY(rcb);
+      }
       h->clk_slot = -1;
       if(!dev_clock) MMD_TRY(ev_end(h));
       else if(h->clk_written == 7) {
@@ -372,12 +405,11 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
           h->clk_last = c[2];
         }
       }
-      core_next = 1;                               // the atoms are where the build saw them
       collect_pending = true;                  // (folded into the timers once this step's force kernel is in flight)
     }
     const int step = first_step + n + 1;
     const int evflag = thermo_nstat > 0 && (step % thermo_nstat == 0);
-    bool folded = false;
+    folded = false;
     if(halo_pending) {
       // overlapped step: interior tiles ran under the halo; now wait for the ghosts and finish the boundary tiles
       HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
@@ -387,22 +419,10 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       MMD_TRY(rc1);
       if(h->time_force_events) MMD_TRY(ev_end(h));
       halo_pending = false;
-    } else {
-      fused_force = fuse_force && !evflag && n + 1 < ntimes && (h->style == 0 ? mmd_lj_can_fuse_integrate(h) : mmd_eam_can_fuse_integrate(h));
-      if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
-      h->fuse_now = fused_force;
-      h->resolve_now = h->ghosts_stale;
-      h->fold_reverse_now = folded = fold && h->ghost_chain_ok && mmd_lj_half_tiles_available(h);
-      h->core.mode_now = core_next;                // rows in two parts (CoreRows): which part this call may walk
-      h->core.tracked_last = false;
-      const int rc = force_compute_async(h, evflag, nullptr, nullptr, true);
-      h->fuse_now = 0;
-      h->resolve_now = false;
-      h->fold_reverse_now = false;
-      h->core.mode_now = 0;
-      core_next = h->core.tracked_last ? 2 : 0;
-      MMD_TRY(rc);
-    }
+    } else if(h->spec_done) {
+      h->spec_done = false;                        // (the neighbor build issued this step's launch behind its own kernels, and its verdict let it run)
+    } else
+      MMD_TRY(launch_force(n, evflag));
     if(reverse && !folded) {
       if(time_halo) MMD_TRY(ev_begin(h, 1));
       MMD_TRY(mmd_comm_reverse_communicate(h));
@@ -473,6 +493,8 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "eam_wg_force")) *value = h->eam_diag[3];
   else if(!strcmp(name, "tile_cmax")) *value = h->tile_cmax;
   else if(!strcmp(name, "rows_uploaded")) *value = h->rows_uploaded ? 1 : 0;
+  else if(!strcmp(name, "spec_runs")) *value = h->spec_runs;          // Force::compute launches issued behind a neighbor build ...
+  else if(!strcmp(name, "spec_fails")) *value = h->spec_fails;        // ... and how many of them the build's verdict turned into no-ops
   else { mmd_set_error("mmd_get_counter: unknown counter '%s'", name); return -1; }
   return 0;
 }

@@ -1172,6 +1172,212 @@ __global__ __launch_bounds__(256) void k_border_unpack(real4* __restrict__ x, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One rank, every swap a periodic self swap (round 4): the six swaps in THREE launches instead of eight.
+// A ghost is a periodic image of an owned atom ("root"), and whether swap q selects an atom or one of its earlier images depends on the
+// root's own coordinate alone: the images made by the x swaps carry the root's y and z, those made by the y swaps its z (pack_border adds a
+// shift of zero in the other dimensions). So the ghosts fall into 26 lists, one per non-empty combination (x swap | none, y swap | none,
+// z swap | none), each holding the roots inside ALL its slabs in ascending index order, and the swap-by-swap sequence of ref/comm.cpp:364-597
+// (a swap scans the owned atoms, then the ghosts of the earlier dimensions in index order) is these lists laid end to end in the order of
+// BrdList::M below. k_brd_count: per workgroup of 1024 atoms the number of members of every list (+ row 26: atoms inside any slab) and a
+// byte of slab bits per atom; k_brd_scan: exclusive scan of each row over the workgroups; k_brd_scatter: every member writes its ghost
+// (position + the shifts of its swaps, image code, root, type) and the entry of the send list of the swap that made it — the index of the atom or
+// earlier image it was copied from. Same ghosts, same send lists, same counts as the swap-by-swap path.
+// ---------------------------------------------------------------------------------------------------
+#define BRD_NL 26
+#define BRD_ROWS 27
+struct SelfSwaps { real lo[6], hi[6], sx[6], sy[6], sz[6]; int pbc_any[6], px[6], py[6], pz[6]; int cap_list[6]; int* sendlist[6]; };
+// slab bits a list asks for (bit q = swap q), in ghost order: swap 0, swap 1, swap 2 over {owned, images of 0, of 1}, swap 3 likewise,
+// swap 4 over {owned, images of 0, 1, 2 (three lists), 3 (three lists)}, swap 5 likewise
+constexpr int brd_mask_of(int l)
+{
+  constexpr int M[BRD_NL] = {0x01, 0x02, 0x04, 0x05, 0x06, 0x08, 0x09, 0x0a, 0x10, 0x11, 0x12, 0x14, 0x15, 0x16, 0x18, 0x19, 0x1a,
+                             0x20, 0x21, 0x22, 0x24, 0x25, 0x26, 0x28, 0x29, 0x2a};
+  return M[l];
+}
+constexpr int brd_find(int m) { for(int l = 0; l < BRD_NL; l++) if(brd_mask_of(l) == m) return l; return -1; }
+template <int L> struct BrdList {
+  static constexpr int index = L;
+  static constexpr int mask = brd_mask_of(L);
+  static constexpr int swap = L < 1 ? 0 : L < 2 ? 1 : L < 5 ? 2 : L < 8 ? 3 : L < 17 ? 4 : 5;              // the swap that makes the list's ghosts
+  // the list its ghosts are copied from (-1: from the owned atoms): the one whose mask is this mask without the bit of the making swap
+  static constexpr int source = (mask & ~(1 << swap)) == 0 ? -1 : brd_find(mask & ~(1 << swap));
+  static_assert(source < L, "a list is copied from an earlier one");
+};
+// f(BrdList<0>{}), ..., f(BrdList<25>{})
+template <int L = 0, class Fn>
+__device__ __forceinline__ void brd_for_lists(Fn&& f)
+{
+  if constexpr(L < BRD_NL) { f(BrdList<L>{}); brd_for_lists<L + 1>(f); }
+}
+
+__device__ __forceinline__ int brd_slab_bits(const real4 p, const SelfSwaps& W)
+{
+  int F = 0;
+#pragma unroll
+  for(int q = 0; q < 6; q++) {
+    const real c = q < 2 ? p.x : (q < 4 ? p.y : p.z);
+    F |= (c >= W.lo[q] && c <= W.hi[q]) ? (1 << q) : 0;          // ref/comm.cpp:411-413
+  }
+  return F;
+}
+
+__global__ __launch_bounds__(256) void k_brd_count(const real4* __restrict__ x, int nlocal, SelfSwaps W, unsigned char* __restrict__ bits,
+                                                   int* __restrict__ cnt, int nblk, int* __restrict__ bst)
+{
+  __shared__ int s_c[4][BRD_ROWS];
+  if(blockIdx.x == 0 && threadIdx.x < 64) bst[threadIdx.x] = 0;          // the state words of this borders pass (filled in by k_brd_scatter)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
+  int c[BRD_ROWS];
+#pragma unroll
+  for(int l = 0; l < BRD_ROWS; l++) c[l] = 0;
+#pragma unroll
+  for(int r = 0; r < 4; r++) {
+    const int i = base + r * 64;
+    const int F = i < nlocal ? brd_slab_bits(x[i], W) : 0;
+    if(i < nlocal) bits[i] = (unsigned char)F;
+    const unsigned long long any = __builtin_amdgcn_ballot_w64(F != 0);
+    if(any == 0ull) continue;                                            // (interior atoms: nothing to count)
+    brd_for_lists([&](auto L) {
+      constexpr int l = decltype(L)::index, m = decltype(L)::mask;
+      c[l] += __popcll(__builtin_amdgcn_ballot_w64((F & m) == m));
+    });
+    c[BRD_NL] += __popcll(any);
+  }
+  if(lane == 0) {
+#pragma unroll
+    for(int l = 0; l < BRD_ROWS; l++) s_c[wave][l] = c[l];
+  }
+  __syncthreads();
+  if(threadIdx.x < BRD_ROWS) cnt[threadIdx.x * nblk + blockIdx.x] = s_c[0][threadIdx.x] + s_c[1][threadIdx.x] + s_c[2][threadIdx.x] + s_c[3][threadIdx.x];
+}
+
+// one workgroup per row: exclusive scan over the nblk workgroups of k_brd_count, the row's total behind it (tot[row])
+__global__ __launch_bounds__(256) void k_brd_scan(int* __restrict__ cnt, int nblk, int* __restrict__ tot)
+{
+  __shared__ int lds[17];
+  int* __restrict__ row = cnt + (size_t)blockIdx.x * nblk;
+  int carry = 0;
+  for(int c0 = 0; c0 < nblk; c0 += 1024) {
+    const int b = c0 + threadIdx.x * 4;
+    int v[4];
+#pragma unroll
+    for(int k = 0; k < 4; k++) v[k] = b + k < nblk ? row[b + k] : 0;
+    int total;
+    const int inc = block_incl_scan(v[0] + v[1] + v[2] + v[3], lds, &total);
+    int e = carry + inc - (v[0] + v[1] + v[2] + v[3]);
+#pragma unroll
+    for(int k = 0; k < 4; k++) { if(b + k < nblk) row[b + k] = e; e += v[k]; }
+    carry += total;
+  }
+  if(threadIdx.x == 0) tot[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_brd_scatter(real4* __restrict__ x, int nlocal, SelfSwaps W, const unsigned char* __restrict__ bits,
+                                                     const int* __restrict__ cnt, int nblk, const int* __restrict__ tot, int* __restrict__ bst,
+                                                     int cap_atoms, int cap_ghost, int* __restrict__ ghost_image, int* __restrict__ ghost_root,
+                                                     int* __restrict__ type)
+{
+  __shared__ int s_c[4][BRD_NL];
+  // ---- where every list starts among the ghosts, where every swap's ghosts start (uniform: the 27 totals through the scalar cache)
+  int lbase[BRD_NL], sw_first[7], sw_num[6];
+  {
+#pragma unroll
+    for(int q = 0; q < 6; q++) sw_num[q] = 0;
+    int g = 0;
+    brd_for_lists([&](auto L) {
+      const int t = tot[decltype(L)::index];
+      lbase[decltype(L)::index] = g;
+      g += t;
+      sw_num[decltype(L)::swap] += t;
+    });
+    sw_first[0] = 0;
+#pragma unroll
+    for(int q = 0; q < 6; q++) sw_first[q + 1] = sw_first[q] + sw_num[q];
+  }
+  const int nghost = sw_first[6];
+  bool ovf = nghost > cap_ghost || nlocal + nghost > cap_atoms;
+#pragma unroll
+  for(int q = 0; q < 6; q++) ovf = ovf || sw_num[q] > W.cap_list[q];
+  if(blockIdx.x == 0 && threadIdx.x == 0) {
+    bst[BST_NB] = tot[BRD_NL];
+    bst[BST_OVF] = ovf ? 1 : 0;
+#pragma unroll
+    for(int q = 0; q < 6; q++) { bst[BST_SEND + q] = sw_num[q]; bst[BST_RECV + q] = sw_num[q]; bst[BST_GHOSTS + q] = sw_first[q]; }
+    bst[BST_GHOSTS + 6] = nghost;
+  }
+  if(ovf) return;                                       // (the arrays were sized too small: the swap-by-swap path redoes the borders with grown ones)
+  {
+    const int a0 = cnt[BRD_NL * nblk + blockIdx.x], a1 = (int)blockIdx.x + 1 < nblk ? cnt[BRD_NL * nblk + blockIdx.x + 1] : tot[BRD_NL];
+    if(a0 == a1) return;                                // no boundary atom in this workgroup
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
+  int F[4];
+  int c[BRD_NL];
+#pragma unroll
+  for(int l = 0; l < BRD_NL; l++) c[l] = 0;
+#pragma unroll
+  for(int r = 0; r < 4; r++) {
+    const int i = base + r * 64;
+    F[r] = i < nlocal ? (int)bits[i] : 0;
+    if(__builtin_amdgcn_ballot_w64(F[r] != 0) == 0ull) continue;
+    const int Fr = F[r];
+    brd_for_lists([&](auto L) {
+      constexpr int l = decltype(L)::index, m = decltype(L)::mask;
+      c[l] += __popcll(__builtin_amdgcn_ballot_w64((Fr & m) == m));
+    });
+  }
+  if(lane == 0) {
+#pragma unroll
+    for(int l = 0; l < BRD_NL; l++) s_c[wave][l] = c[l];
+  }
+  __syncthreads();
+  // members of list l in front of this wavefront's first atom: the workgroup's scanned count + the earlier wavefronts of the workgroup
+  int off[BRD_NL];
+#pragma unroll
+  for(int l = 0; l < BRD_NL; l++) {
+    int o = lbase[l] + cnt[l * nblk + blockIdx.x];
+    for(int w = 0; w < wave; w++) o += s_c[w][l];
+    off[l] = o;
+  }
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for(int r = 0; r < 4; r++) {
+    if(__builtin_amdgcn_ballot_w64(F[r] != 0) == 0ull) continue;
+    const int i = base + r * 64;
+    const int Fr = F[r];
+    const real4 p0 = Fr != 0 ? x[i] : real4{0, 0, 0, 0};
+    int g[BRD_NL];                                     // ghost number of my image in list l (valid where I am a member)
+    brd_for_lists([&](auto L) {
+      using LL = decltype(L);
+      constexpr int l = LL::index, m = LL::mask, q = LL::swap, src = LL::source;
+      const bool in = (Fr & m) == m;
+      const unsigned long long mm = __builtin_amdgcn_ballot_w64(in);
+      g[l] = off[l] + __popcll(mm & below);
+      off[l] += __popcll(mm);
+      if(in) {
+        // the chain of swaps this image went through, in order: position and image code exactly as pack_border accumulates them
+        real4 p = p0;
+        int code = IMAGE_NONE;
+#pragma unroll
+        for(int s = 0; s < 6; s++) {
+          if(m & (1 << s)) {
+            if(W.pbc_any[s]) { p.x += W.sx[s]; p.y += W.sy[s]; p.z += W.sz[s]; }
+            code = image_add(code, W.px[s], W.py[s], W.pz[s]);
+          }
+        }
+        x[nlocal + g[l]] = p;
+        ghost_image[g[l]] = code;
+        ghost_root[g[l]] = i;
+        type[nlocal + g[l]] = (int)p.w;
+        W.sendlist[q][g[l] - sw_first[q]] = src < 0 ? i : nlocal + g[src < 0 ? 0 : src];
+      }
+    });
+  }
+}
+
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
 static int borders_fast_finish(mmd_handle* h);
 
@@ -1213,6 +1419,38 @@ static int borders_device_resident(mmd_handle* h, bool defer)
   const int nt_own = div_up(nlocal, CP_TILE), nt_sw = div_up(est_nb + est_ghost, CP_TILE);
   MMD_TRY(h->flag_tmp.ensure((size_t)std::max(nt_own, 2 * nt_sw) + 8, false, h->stream));
   MMD_TRY(h->bstate.ensure(64, false, h->stream));
+  bool fused = !any_remote && h->opt_borders_fast >= 2;
+  for(int q = 0; q < 6 && fused; q++) fused = h->swaps[q].dim == q / 2;
+  if(fused) {
+    // every swap a periodic self swap: count / scan / scatter over the 26 image lists (above)
+    SelfSwaps W;
+    for(int q = 0; q < 6; q++) {
+      const Swap& sw = h->swaps[q];
+      W.lo[q] = sw.slablo; W.hi[q] = sw.slabhi;
+      W.sx[q] = sw.pbc[0] * h->prd[0]; W.sy[q] = sw.pbc[1] * h->prd[1]; W.sz[q] = sw.pbc[2] * h->prd[2];
+      W.pbc_any[q] = sw.pbc_any; W.px[q] = sw.pbc[0]; W.py[q] = sw.pbc[1]; W.pz[q] = sw.pbc[2];
+      W.cap_list[q] = cap_list[q]; W.sendlist[q] = h->swaps[q].sendlist.p;
+    }
+    const int nblk = nt_own > 0 ? nt_own : 1;
+    MMD_TRY(h->flag_tmp.ensure((size_t)BRD_ROWS * nblk + BRD_ROWS + 8, false, h->stream));
+    MMD_TRY(h->brd_bits.ensure((size_t)nlocal + 64, false, h->stream));
+    int* tot = h->flag_tmp.p + (size_t)BRD_ROWS * nblk;
+    hipLaunchKernelGGL(k_brd_count, dim3(nblk), dim3(256), 0, h->stream, h->x.p, nlocal, W, h->brd_bits.p, h->flag_tmp.p, nblk, h->bstate.p);
+    hipLaunchKernelGGL(k_brd_scan, dim3(BRD_ROWS), dim3(256), 0, h->stream, h->flag_tmp.p, nblk, tot);
+    hipLaunchKernelGGL(k_brd_scatter, dim3(nblk), dim3(256), 0, h->stream, h->x.p, nlocal, W, h->brd_bits.p, h->flag_tmp.p, nblk, tot, h->bstate.p,
+                       cap_atoms, cap_ghost_eff, h->ghost_image.p, h->ghost_root.p, h->type.p);
+    HIP_TRY(hipGetLastError());
+    h->bf_est_nb = 0x7fffffff;                   // (no launch of this form is sized by the number of boundary atoms)
+    if(defer) {
+      h->nghost = cap_ghost_eff;
+      h->nghost_dev = h->bstate.p + BST_GHOSTS + 6;
+      for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x.p) h->xalt_dummy_slot[k] = -1;
+      return 2;
+    }
+    HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(mmd_stream_sync(h));
+    return borders_fast_finish(h);
+  }
   SlabSet S;
   S.n = 6;
   for(int q = 0; q < 6; q++) { S.lo[q] = h->swaps[q].slablo; S.hi[q] = h->swaps[q].slabhi; S.dim[q] = h->swaps[q].dim; }

@@ -163,6 +163,13 @@ __device__ __forceinline__ int xcd_work_item(int n)
   const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   return w < n ? w : -1;
 }
+// the same for a launch whose grid was sized for MORE than n items (n known on the device only): every XCD still takes a contiguous eighth of n
+__device__ __forceinline__ int xcd_work_item_of(int n)
+{
+  const int per = (n + 7) >> 3;
+  const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  return ((int)(blockIdx.x >> 3) < per && w < n) ? w : -1;
+}
 static inline int xcd_grid(int n) { return ((n + 7) / 8) * 8; }
 
 // a count that may still be on its way to the host: `bound` = nlocal + the capacity the arrays were sized for

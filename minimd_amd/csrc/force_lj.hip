@@ -182,9 +182,16 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, int pos_bytes, LJParams P, real* __restrict__ f,
-    double* __restrict__ partials, int ablate_arg, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, GhostResolve G)
+    double* __restrict__ partials, int ablate_arg, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, GhostResolve G, SpecLaunch SP)
 {
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
+  // A launch enqueued BEHIND a neighbor build whose results the host has not seen yet (mmd_internal.hpp: SpecLaunch): the build's own
+  // verdict decides on the device whether this launch does anything at all, and the tile / ghost counts come from device memory
+  if(SP.gate != nullptr) {
+    if(*(const volatile int*)SP.gate == 0) return;
+    ntiles = min(ntiles, *SP.ntiles_dev);
+    nall = deferred_count(nall, nlocal, SP.nghost_dev);
+  }
   extern __shared__ __align__(16) unsigned char s_raw[];
   real* s_f = (real*)(s_raw + pos_bytes);
   double* s_red = (double*)(s_raw + pos_bytes + lj_tile_sf_bytes(LJ_TILE_WAVES));
@@ -192,9 +199,11 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform => the k loop runs on the scalar unit
   // XCD-aware order (device_utils.hpp): neighbouring tiles share most of their candidate atoms
-  const int witem = xcd_work_item(ntiles);
+  const int witem = SP.gate != nullptr ? xcd_work_item_of(ntiles) : xcd_work_item(ntiles);
   if(witem < 0) return;                          // (grid is padded to a multiple of 8)
   const int tile = tile_list ? tile_list[witem] : witem;
+  // (a fused launch behind a build: the dummy atom of the second position buffer sits behind the last ghost, whose number only the device knows)
+  if(FUSE && SP.gate != nullptr && witem == 0 && tid == 0) xnew[nall] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
   // The tile's loads are issued as three round trips — header scalars; candidate indices + own atom index + first slots; positions —
   // not as the six a straight reading of the steps below would make (indices -> positions -> LDS, then atom index -> position, then slots).
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];     // a tile never straddles pencils
@@ -738,12 +747,14 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   h->launch_ev_a = h->launch_ev_b = nullptr;
   GhostResolve G{nullptr, nullptr, nullptr, {h->prd[0], h->prd[1], h->prd[2]}};
   if(h->resolve_now) { G.root = h->ghost_root.p; G.image = h->ghost_image.p; G.tile_ghost = h->tile_ghost.p; }
+  const SpecLaunch SP = list == nullptr ? h->spec : SpecLaunch{nullptr, nullptr, nullptr};
+  if(SP.gate != nullptr) { h->spec_launches++; h->spec_fused = fz != 0; }
 #define TK(EVv, Xv, Wv, Uv, Rv, Fv) if(!launched && ev == EVv && ex == Xv && tw == Wv && tu == Uv && rd == Rv && fz == Fv) { launched = true;  \
     hipExtLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv, Rv, Fv>), dim3(xcd_grid(count)), dim3(64 * Wv),                    \
                        pos_bytes + lj_tile_sf_bytes(Wv) + 16 * sizeof(double), h->stream, kev_a, kev_b, 0, h->x.p,                   \
                        h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
                        count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,              \
-                       h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce, G); }
+                       h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce, G, SP); }
   const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = ex ? (h->opt_tile_read == 1 ? 1 : 0) : h->opt_tile_read;   // (exact division: one divide per pair)
   TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
   TK(0, 0, 2, 8, 0, 1);                                                                          // production, integrator fused
@@ -804,6 +815,7 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   }
   const int ev = evflag ? 1 : 0, uni = h->lj_uniform ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
   int nsum = nblocks;
+  if(h->spec.gate != nullptr && (!mmd_lj_tiles_available(h) || evflag)) { mmd_set_error("Force::compute behind the build: only the gated tile launch may run there"); return -1; }
   if(mmd_lj_tiles_available(h)) {
     nsum = h->ntiles;
     MMD_TRY(h->partials.ensure((size_t)2 * nsum + 8, false, h->stream));

@@ -13,6 +13,7 @@
 //   bins   bin_start[mbins+1], binned[nall]: counting-sorted atom indices, bins numbered block-major
 //                          (2x2x2 bins = one block = ~one wavefront of atoms) for L1/L2 locality
 #pragma once
+#include <functional>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -114,6 +115,11 @@ struct Swap {                // one of the 2*sum(need) swaps of Comm::setup (ref
 };
 
 struct EventPair { hipEvent_t a, b; int kind = 0; };
+
+// A force launch enqueued behind a neighbor build whose result words the host has not read yet (Integrate::run, one rank): the kernel
+// takes the build's verdict (`gate`, written by k_publish_flags: 1 = every list fits what this launch was sized for), the tile count and
+// the ghost count from device memory. gate == nullptr: an ordinary launch.
+struct SpecLaunch { const int* gate; const int* ntiles_dev; const int* nghost_dev; };
 
 struct mmd_handle {
   int device = 0;
@@ -221,6 +227,7 @@ struct mmd_handle {
   void* host_ctx = nullptr;
   std::vector<char> stage_send, stage_recv;
   DevArr<int> flag_tmp, bnd_list, bstate;
+  DevArr<unsigned char> brd_bits;      // one-rank borders in three launches: per owned atom, which of the six send slabs hold it
   DevArr<int> est, ex_list;            // handshake-free Comm::exchange (comm.hip): device-resident counts / leaver list
   int ex_prev_send[3] = {0, 0, 0}, ex_prev_recv[3][2] = {{0, 0}, {0, 0}, {0, 0}};     // migration counts of the last exchange (size the fixed messages)
   bool ex_prev_valid = false;
@@ -259,7 +266,7 @@ struct mmd_handle {
   int force_calls = 0;
   bool resolve_now = false, ghosts_stale = false;
   hipEvent_t launch_ev_a = nullptr, launch_ev_b = nullptr;     // event pair the next tile-kernel launch attaches to its dispatch
-  int opt_borders_fast = 1, opt_borders_est = 150;    // device-resident one-rank borders on/off; its sizing estimate in per cent of the previous counts
+  int opt_borders_fast = 2, opt_borders_est = 150;    // device-resident borders: 0 off, 1 swap by swap (count / scatter pair per dimension), 2 + the three-launch form where every swap is a self swap; its sizing estimate in per cent of the previous counts
   int prev_nb = 0, prev_nghost = 0;   // counts of the last Comm::borders (size the device-resident one-rank path of the next one)
   // ---- Integrate
   real dt = 0, dtforce = 0;
@@ -277,6 +284,16 @@ struct mmd_handle {
   long long clk_last = 0;      // last stamp seen (stamps of one re-neighboring must lie behind it and ascend)
   double clk_rate_hz = 0;      // hipDeviceAttributeWallClockRate
   int opt_spin_readback = 1;   // Integrate::run: the host polls pinned memory for the build's results instead of blocking on the stream
+  // Force::compute of a re-neighboring step launched BEHIND the build, before its result words have reached the host (no idle GPU while the
+  // host reads them and enqueues the kernel): Integrate::run leaves the launch as a closure, mmd_neighbor_build calls it between publishing
+  // the words and polling for them; the kernel does nothing unless the build's verdict on the device says the lists fit (SpecLaunch)
+  int opt_spec = 16;                   // 0: off; > 0: on, the launch provides LDS for the previous build's largest candidate union + this many atoms
+  std::function<int()> spec_fn;        // transient: how to launch this step's Force::compute
+  SpecLaunch spec = {nullptr, nullptr, nullptr};   // transient: set around spec_fn
+  bool spec_fused = false;             // the gated launch carried the integrator (it wrote the second position buffer's dummy atom itself)
+  bool spec_done = false;              // the build launched this step's force kernel and its verdict was "go"
+  int spec_cmax = 0;                   // largest candidate union the speculative launch provides LDS for
+  long long spec_launches = 0, spec_runs = 0, spec_fails = 0;
   bool in_run = false;         // inside mmd_integrate_run
   int* h_flags_big = nullptr;  // pinned host ints (64): read-back of the device-resident borders state
   std::vector<int> h_bstate;

@@ -175,13 +175,14 @@ __global__ __launch_bounds__(256) void k_bin_count(real4* __restrict__ x, int n,
   if(valid) {
     real4 p = x[i];
     if(pbc) {
+      const real4 q = p;
       if(p.x < (real)0.0) p.x += xprd;
       if(p.x >= xprd) p.x -= xprd;
       if(p.y < (real)0.0) p.y += yprd;
       if(p.y >= yprd) p.y -= yprd;
       if(p.z < (real)0.0) p.z += zprd;
       if(p.z >= zprd) p.z -= zprd;
-      x[i] = p;
+      if(p.x != q.x || p.y != q.y || p.z != q.z) x[i] = p;         // (a few atoms in a thousand cross a face between two re-neighborings: the others are not written back)
     }
     b = bin_of(g, p.x, p.y, p.z);
   }
@@ -1502,9 +1503,22 @@ int mmd_ensure_rows(mmd_handle* h)
 // The build's result words travel to the host as stores of a kernel into pinned memory, closed by a sequence number with system scope;
 // the host spins on that word (no runtime call in the loop). After two seconds without it the blocking wait takes over (and reports
 // whatever went wrong on the stream).
-__global__ __launch_bounds__(64) void k_publish_flags(const int* __restrict__ src, int* __restrict__ dst, int n, int seq)
+// The verdict a force launch enqueued behind the build waits on (SpecLaunch, mmd_internal.hpp) is formed here, from the same words and by the
+// same rules the host applies after reading them (mmd_neighbor_build below): 1 = rows, unions, tile count and the deferred borders all fit
+// what that launch was sized for. Word 15 of the flags, published with the others.
+struct BuildVerdict { int on, maxneighs, ntiles_cap, nt_async, cmax, has_bst, est_nb, big_bins, core_rows; };
+#define NB_GATE_WORD 15
+__global__ __launch_bounds__(64) void k_publish_flags(int* __restrict__ src, int* __restrict__ dst, int n, int seq, BuildVerdict V)
 {
   const int t = threadIdx.x;
+  if(V.on && t == 0) {
+    const int maxn = src[0], need = V.core_rows ? max(maxn, src[7]) : maxn;
+    bool ok = !(maxn >= V.maxneighs || need > V.maxneighs) && src[3] == 0 && !(src[12] != 0 && !V.big_bins) && src[2] <= V.cmax;
+    if(V.nt_async) ok = ok && src[6] <= V.ntiles_cap;
+    if(V.has_bst) ok = ok && src[16 + 1] == 0 && src[16 + 0] <= V.est_nb;        // BST_OVF, BST_NB of the deferred one-rank borders (comm.hip)
+    src[NB_GATE_WORD] = ok ? 1 : 0;
+  }
+  __syncthreads();
   if(t < n) dst[t] = src[t];
   __threadfence_system();
   __syncthreads();
@@ -1512,12 +1526,17 @@ __global__ __launch_bounds__(64) void k_publish_flags(const int* __restrict__ sr
 }
 // (Publishing from the last workgroup of k_tile_reduce instead — one launch less — was built and measured: the 1024-thread workgroup's system-scope
 //  fence makes that kernel 14 instead of 6 us and bench.py --size 32 loses 2.7 %: 4480 against 4600 Matom-steps/s. A one-wavefront kernel it stays.)
-static int flags_publish_and_wait(mmd_handle* h, int n)
+static int flags_publish(mmd_handle* h, int n, const BuildVerdict& V)
 {
   if(!h->h_flags_dev) HIP_TRY(hipHostGetDevicePointer((void**)&h->h_flags_dev, h->h_flags, 0));
   const int seq = ++h->flag_seq;
-  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, h->stream, (const int*)h->d_flags, h->h_flags_dev, n, seq);
+  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, h->stream, h->d_flags, h->h_flags_dev, n, seq, V);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+static int flags_wait(mmd_handle* h)
+{
+  const int seq = h->flag_seq;
   h->host_syncs++;
   const double t0 = mmd_wall();
   unsigned long spins = 0;
@@ -1664,40 +1683,80 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
       // [0..3] results, [4..5] total, [6] tile count, [12] long-bin flag, [16..55] bst of a deferred one-rank borders
+      int spec_cmax_used = 0;
+      int verdict = 0;                    // 1: this step's Force::compute was launched behind the build and the build's verdict let it run
+      bool spec_go = false;
       if(h->opt_build == 1 && h->opt_spin_readback && h->in_run) {
         // inside Integrate::run the build's results are PUBLISHED into pinned host memory by a one-wavefront kernel and the host polls that
         // memory: a blocking stream wait costs the wake-up of a sleeping thread (~40 us between the copy and the next force kernel)
-        MMD_TRY(flags_publish_and_wait(h, 62));
+        // Force::compute of this step goes onto the stream BEFORE the host has the words (SpecLaunch, mmd_internal.hpp): sized for the
+        // tile capacity of this build and the previous build's largest union (+ opt_spec slots), gated on the device by the verdict the
+        // publishing kernel forms. One attempt per re-neighboring: after a "no" the lists are rebuilt and the step loop launches as usual.
+        std::function<int()> fn;
+        fn.swap(h->spec_fn);
+        BuildVerdict V{};
+        const int spec_cmax = h->tile_cmax + std::max(h->opt_spec, 0);
+        spec_cmax_used = spec_cmax;
+        bool spec = h->opt_spec > 0 && (bool)fn && attempt == 0 && tmode == 0 && nt_async && !order_here && h->tile_cmax > 0 && h->ntiles > 0;
+        const int save_cmax = h->tile_cmax;
+        if(spec) {
+          h->tile_cmax = spec_cmax; h->tiles_ready = true; h->neigh_nlocal = nlocal;
+          spec = mmd_lj_tiles_available(h) != 0;
+          if(!spec) { h->tile_cmax = save_cmax; h->tiles_ready = false; h->neigh_nlocal = 0; }
+        }
+        if(spec) V = BuildVerdict{1, h->maxneighs, h->ntiles, 1, spec_cmax, h->nghost_dev != nullptr ? 1 : 0, h->bf_est_nb, h->big_bins ? 1 : 0, core_rows ? 1 : 0};
+        MMD_TRY(flags_publish(h, 62, V));
+        if(spec) {
+          h->spec = SpecLaunch{h->d_flags + NB_GATE_WORD, nt_dev, h->nghost_dev};
+          h->spec_fused = false;
+          const long long before = h->spec_launches;
+          const int rc = fn();
+          h->spec = SpecLaunch{nullptr, nullptr, nullptr};
+          h->tile_cmax = save_cmax; h->tiles_ready = false; h->neigh_nlocal = 0;
+          if(rc < 0) return rc;
+          if(h->spec_launches != before + 1) { mmd_set_error("neighbor build: the force launch behind the build did not take the gated tile path"); return -1; }
+          spec_go = true;
+          h->spec_runs++;
+        }
+        MMD_TRY(flags_wait(h));
         h->clk_written |= 4;
+        if(spec_go) { verdict = h->h_flags[NB_GATE_WORD]; if(!verdict) h->spec_fails++; }
       } else {
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, (h->nghost_dev ? 56 : 16) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       if(h->opt_build != 1) HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(mmd_stream_sync(h));
       }
       if(h->opt_build == 1) memcpy(h->h_result, h->h_flags + 4, sizeof(double));
+      // (a verdict of 1 means the gated force kernel is running on these lists: every rule below that sends the build around again is part
+      //  of the verdict, so none of them can fire then — if one does, the two have come apart and the run must not go on)
+#define NB_REDO_GUARD() if(verdict) { mmd_set_error("neighbor build: verdict of the device and rules of the host disagree"); return -1; }
       if(h->nghost_dev) {                   // the ghost counts of the deferred one-rank borders arrived with the flags
         memcpy(h->h_flags_big, h->h_flags + 16, 40 * sizeof(int));
         const int rc = mmd_borders_deferred_finish(h);
         if(rc < 0) return rc;
-        if(rc == 0) return mmd_neighbor_build(h);       // (estimates too small: borders were redone swap by swap; build again)
+        if(rc == 0) { NB_REDO_GUARD(); return mmd_neighbor_build(h); }       // (estimates too small: borders were redone swap by swap; build again)
       }
       if(nt_async) {
-        if(h->h_flags[6] > h->ntiles) { h->ntiles_hint = 0; return mmd_neighbor_build(h); }     // more tiles than provided for: size from the count
+        if(h->h_flags[6] > h->ntiles) { NB_REDO_GUARD(); h->ntiles_hint = 0; return mmd_neighbor_build(h); }     // more tiles than provided for: size from the count
         h->ntiles = h->h_flags[6];
       }
       if(h->h_flags[12] && !h->big_bins) {                       // a bin longer than NB_BIGBIN showed up: bin again with the rank sort on
+        NB_REDO_GUARD();
         h->big_bins = true;
         return mmd_neighbor_build(h);
       }
-      if(h->h_flags[3]) { want_tiles = false; break; }           // a block has too many candidates: global-row build below
+      if(h->h_flags[3]) { NB_REDO_GUARD(); want_tiles = false; break; }           // a block has too many candidates: global-row build below
       const int maxn = h->h_flags[0];
       h->max_row = maxn;
       const int need = core_rows ? std::max(maxn, h->h_flags[7]) : maxn;      // (two padded parts per row need a little more room)
       if(maxn >= h->maxneighs || need > h->maxneighs) {            // ref/neighbor.cpp:186-208
+        NB_REDO_GUARD();
         int m = (int)(std::max(maxn, need) * 1.2);
         h->maxneighs = (m + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
         continue;
       }
+      if(verdict && h->h_flags[2] > spec_cmax_used) { mmd_set_error("neighbor build: verdict of the device and rules of the host disagree (union)"); return -1; }
+#undef NB_REDO_GUARD
       h->core.rows_built = core_rows;
       unsigned long long tot;
       memcpy(&tot, h->h_result, sizeof(tot));
@@ -1707,6 +1766,9 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       h->ntiles_hint = h->ntiles;
       h->neigh_nlocal = nlocal;
       h->ntiles_interior = order_here ? h->h_flags[13] : -1;    // (-1: the interior/boundary order is derived on demand, mmd_order_tiles)
+      h->spec_done = verdict != 0;
+      if(verdict && h->spec_fused)           // the gated kernel wrote the dummy atom of the second position buffer behind the last ghost
+        for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x_alt.p) h->xalt_dummy_slot[k] = nlocal + h->nghost;
       return 0;
     }
     if(want_tiles) { mmd_set_error("mmd_neighbor_build: neighbor rows keep overflowing (maxneighs=%d)", h->maxneighs); return -1; }

@@ -157,6 +157,8 @@ int mmd_prepare_x_alt(mmd_handle* h)
   int q = -1;
   for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x_alt.p) q = k;
   if(q < 0) { q = h->xalt_dummy_next; h->xalt_dummy_next ^= 1; h->xalt_dummy_ptr[q] = h->x_alt.p; h->xalt_dummy_slot[q] = -1; }
+  // (a launch behind the neighbor build: the ghost count is still on the device, the gated kernel writes the dummy atom itself)
+  if(h->spec.gate != nullptr) { h->xalt_dummy_slot[q] = -1; return 0; }
   if(h->xalt_dummy_slot[q] != slot) {
     hipLaunchKernelGGL(k_set_dummy, dim3(1), dim3(1), 0, h->stream, h->x_alt.p, slot);
     HIP_TRY(hipGetLastError());

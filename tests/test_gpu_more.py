@@ -921,6 +921,39 @@ def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_force_launch_behind_the_build_changes_nothing(prec):
+    """option spec (default on): on a re-neighboring step of a one-rank LJ full-list run Force::compute goes onto the stream behind the
+    neighbor build, before the build's result words have reached the host, gated on the device by the build's own verdict. Same bits as
+    the ordinary launch order (spec 0) after 130 steps with 6 re-neighborings; with ghost estimates that are too small (borders_est 60)
+    or no LDS margin for a larger union (spec 1 on a melting lattice) the verdict is "no", the gated launch does nothing and the step
+    loop launches again — still the same bits."""
+    res = []
+    for mode in ("off", "on", "on_borders_overflow", "on_tight_union"):
+        s = mm().Sim(["-s", "14", "-n", "130", "--half_neigh", "0"], precision=prec)
+        s.handle.set_option("spec", {"off": 0, "on_tight_union": 1}.get(mode, 16))
+        if mode == "on_borders_overflow":
+            s.handle.set_option("borders_est", 60)
+        s.initial(); s.run()
+        d = s.handle.download()
+        runs, noop = s.handle.counter("spec_runs"), s.handle.counter("spec_fails")
+        res.append((s.rows(), d["x"][:d["nlocal"]].copy(), d["v"].copy(), d["f"].copy(), d["tag"].copy()))
+        s.close()
+        if mode == "off":
+            assert runs == 0
+        elif mode == "on":
+            assert runs >= 4 and noop <= 1, (runs, noop)       # (thermo steps are launched the ordinary way: step 100 is one of the six)
+        elif mode == "on_borders_overflow":
+            assert runs >= 1 and noop >= 1, (runs, noop)
+        else:
+            assert runs >= 4 and noop >= 1, (runs, noop)       # the largest union grows while the lattice melts (steps 20...60)
+    for other in res[1:]:
+        assert res[0][0] == other[0]
+        for a, b in zip(res[0][1:], other[1:]):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_bench_launches_itself_for_two_ranks(tmp_path):
     """`python bench.py --gpus 2` as a PLAIN process (the way the driver starts it): bench.py re-launches itself through
     torch.distributed.run on a free loop-back port; with one visible GPU the two ranks share it and the halos take the
