@@ -1279,87 +1279,104 @@ __global__ __launch_bounds__(256) void k_brd_scatter(real4* __restrict__ x, int 
                                                      int cap_atoms, int cap_ghost, int* __restrict__ ghost_image, int* __restrict__ ghost_root,
                                                      int* __restrict__ type)
 {
-  __shared__ int s_c[4][BRD_NL];
-  // ---- where every list starts among the ghosts, where every swap's ghosts start (uniform: the 27 totals through the scalar cache)
-  int lbase[BRD_NL], sw_first[7], sw_num[6];
-  {
+  __shared__ int s_c[4][BRD_NL];       // members of list l among wavefront w's 256 atoms
+  __shared__ int s_first[BRD_NL];      // ghost number of the first image this WORKGROUP adds to list l
+  __shared__ int s_sw[16];             // [q] first ghost of swap q (q = 6: all ghosts), [8 + q] ghosts of swap q
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
+  // every load whose address is known at the start goes out first: my atoms' slab bits; lane l < 27 of wavefront 0: total and scanned count of row l
+  int F[4];
+#pragma unroll
+  for(int r = 0; r < 4; r++) F[r] = base + r * 64 < nlocal ? (int)bits[base + r * 64] : 0;
+  int my_tot = 0, my_cnt = 0, next_any = 0;
+  if(wave == 0 && lane < BRD_ROWS) {
+    my_tot = tot[lane];
+    my_cnt = cnt[lane * nblk + blockIdx.x];
+    if(lane == BRD_NL) next_any = (int)blockIdx.x + 1 < nblk ? cnt[BRD_NL * nblk + blockIdx.x + 1] : my_tot;
+  }
+  const int Fany = F[0] | F[1] | F[2] | F[3];
+  const unsigned U = wave_or_u((unsigned)Fany);                     // slab bits that occur among this wavefront's atoms
+  // second round trip (issued before anything waits): the positions of my boundary atoms
+  real4 p0[4];
+#pragma unroll
+  for(int r = 0; r < 4; r++) p0[r] = F[r] != 0 ? x[base + r * 64] : real4{0, 0, 0, 0};
+  // ---- members of every list per wavefront
+  brd_for_lists([&](auto L) {
+    constexpr int l = decltype(L)::index, m = decltype(L)::mask;
+    int c = 0;
+    if((U & m) == m) {
+#pragma unroll
+      for(int r = 0; r < 4; r++) c += __popcll(__builtin_amdgcn_ballot_w64((F[r] & m) == m));
+    }
+    if(lane == 0) s_c[wave][l] = c;
+  });
+  // ---- where every list starts among the ghosts, where every swap's ghosts start: wavefront 0 from the 27 totals (lists laid end to end)
+  bool ovf = false, empty = false;
+  if(wave == 0) {
+    const int lt = lane < BRD_NL ? my_tot : 0;
+    const int lstart = wave_incl_scan(lt) - lt;                     // first ghost of list `lane`
+    int sw_num[6], sw_first[7];
 #pragma unroll
     for(int q = 0; q < 6; q++) sw_num[q] = 0;
-    int g = 0;
-    brd_for_lists([&](auto L) {
-      const int t = tot[decltype(L)::index];
-      lbase[decltype(L)::index] = g;
-      g += t;
-      sw_num[decltype(L)::swap] += t;
-    });
+    brd_for_lists([&](auto L) { sw_num[decltype(L)::swap] += __builtin_amdgcn_readlane(lt, decltype(L)::index); });
     sw_first[0] = 0;
 #pragma unroll
     for(int q = 0; q < 6; q++) sw_first[q + 1] = sw_first[q] + sw_num[q];
-  }
-  const int nghost = sw_first[6];
-  bool ovf = nghost > cap_ghost || nlocal + nghost > cap_atoms;
+    const int nghost = sw_first[6];
+    ovf = nghost > cap_ghost || nlocal + nghost > cap_atoms;
 #pragma unroll
-  for(int q = 0; q < 6; q++) ovf = ovf || sw_num[q] > W.cap_list[q];
-  if(blockIdx.x == 0 && threadIdx.x == 0) {
-    bst[BST_NB] = tot[BRD_NL];
-    bst[BST_OVF] = ovf ? 1 : 0;
+    for(int q = 0; q < 6; q++) ovf = ovf || sw_num[q] > W.cap_list[q];
+    if(lane < BRD_NL) s_first[lane] = lstart + my_cnt;
+    if(lane == 0) {
 #pragma unroll
-    for(int q = 0; q < 6; q++) { bst[BST_SEND + q] = sw_num[q]; bst[BST_RECV + q] = sw_num[q]; bst[BST_GHOSTS + q] = sw_first[q]; }
-    bst[BST_GHOSTS + 6] = nghost;
-  }
-  if(ovf) return;                                       // (the arrays were sized too small: the swap-by-swap path redoes the borders with grown ones)
-  {
-    const int a0 = cnt[BRD_NL * nblk + blockIdx.x], a1 = (int)blockIdx.x + 1 < nblk ? cnt[BRD_NL * nblk + blockIdx.x + 1] : tot[BRD_NL];
-    if(a0 == a1) return;                                // no boundary atom in this workgroup
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
-  int F[4];
-  int c[BRD_NL];
+      for(int q = 0; q < 7; q++) s_sw[q] = sw_first[q];
+      s_sw[7] = ovf ? 1 : 0;
+    }
+    const int any0 = __builtin_amdgcn_readlane(my_cnt, BRD_NL), any1 = __builtin_amdgcn_readlane(next_any, BRD_NL);
+    if(lane == 0) s_sw[15] = any0 == any1 ? 1 : 0;                  // no boundary atom in this workgroup
+    if(blockIdx.x == 0 && lane == 0) {
+      bst[BST_NB] = __builtin_amdgcn_readlane(my_tot, BRD_NL);
+      bst[BST_OVF] = ovf ? 1 : 0;
 #pragma unroll
-  for(int l = 0; l < BRD_NL; l++) c[l] = 0;
-#pragma unroll
-  for(int r = 0; r < 4; r++) {
-    const int i = base + r * 64;
-    F[r] = i < nlocal ? (int)bits[i] : 0;
-    if(__builtin_amdgcn_ballot_w64(F[r] != 0) == 0ull) continue;
-    const int Fr = F[r];
-    brd_for_lists([&](auto L) {
-      constexpr int l = decltype(L)::index, m = decltype(L)::mask;
-      c[l] += __popcll(__builtin_amdgcn_ballot_w64((Fr & m) == m));
-    });
-  }
-  if(lane == 0) {
-#pragma unroll
-    for(int l = 0; l < BRD_NL; l++) s_c[wave][l] = c[l];
+      for(int q = 0; q < 6; q++) { bst[BST_SEND + q] = sw_num[q]; bst[BST_RECV + q] = sw_num[q]; bst[BST_GHOSTS + q] = sw_first[q]; }
+      bst[BST_GHOSTS + 6] = nghost;
+    }
   }
   __syncthreads();
-  // members of list l in front of this wavefront's first atom: the workgroup's scanned count + the earlier wavefronts of the workgroup
-  int off[BRD_NL];
-#pragma unroll
-  for(int l = 0; l < BRD_NL; l++) {
-    int o = lbase[l] + cnt[l * nblk + blockIdx.x];
-    for(int w = 0; w < wave; w++) o += s_c[w][l];
-    off[l] = o;
-  }
+  ovf = s_sw[7] != 0; empty = s_sw[15] != 0;
+  if(ovf || empty || U == 0u) return;       // (arrays sized too small: the swap-by-swap path redoes the borders with grown ones) / nothing to add
   const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  // ghost number of the first image THIS WAVEFRONT adds to list l
+  auto first_of = [&](int l) {
+    int o = s_first[l];
+    for(int w = 0; w < wave; w++) o += s_c[w][l];
+    return __builtin_amdgcn_readfirstlane(o);
+  };
+  brd_for_lists([&](auto L) {
+    using LL = decltype(L);
+    constexpr int l = LL::index, m = LL::mask, q = LL::swap, src = LL::source;
+    if((U & m) != m) return;
+    int o = first_of(l);
+    // (the image a member is copied from sits in list `src`: its ghost number is recounted here rather than kept from that list's turn)
+    constexpr int ms = src < 0 ? 0 : brd_mask_of(src < 0 ? 0 : src);
+    int os = src < 0 ? 0 : first_of(src < 0 ? 0 : src);
+    const int swf = s_sw[q];
 #pragma unroll
-  for(int r = 0; r < 4; r++) {
-    if(__builtin_amdgcn_ballot_w64(F[r] != 0) == 0ull) continue;
-    const int i = base + r * 64;
-    const int Fr = F[r];
-    const real4 p0 = Fr != 0 ? x[i] : real4{0, 0, 0, 0};
-    int g[BRD_NL];                                     // ghost number of my image in list l (valid where I am a member)
-    brd_for_lists([&](auto L) {
-      using LL = decltype(L);
-      constexpr int l = LL::index, m = LL::mask, q = LL::swap, src = LL::source;
-      const bool in = (Fr & m) == m;
+    for(int r = 0; r < 4; r++) {
+      const bool in = (F[r] & m) == m;
       const unsigned long long mm = __builtin_amdgcn_ballot_w64(in);
-      g[l] = off[l] + __popcll(mm & below);
-      off[l] += __popcll(mm);
+      const int g = o + __popcll(mm & below);
+      o += __popcll(mm);
+      int gs = 0;
+      if(src >= 0) {
+        const unsigned long long ss = __builtin_amdgcn_ballot_w64((F[r] & ms) == ms);
+        gs = os + __popcll(ss & below);
+        os += __popcll(ss);
+      }
       if(in) {
+        const int i = base + r * 64;
         // the chain of swaps this image went through, in order: position and image code exactly as pack_border accumulates them
-        real4 p = p0;
+        real4 p = p0[r];
         int code = IMAGE_NONE;
 #pragma unroll
         for(int s = 0; s < 6; s++) {
@@ -1368,14 +1385,14 @@ __global__ __launch_bounds__(256) void k_brd_scatter(real4* __restrict__ x, int 
             code = image_add(code, W.px[s], W.py[s], W.pz[s]);
           }
         }
-        x[nlocal + g[l]] = p;
-        ghost_image[g[l]] = code;
-        ghost_root[g[l]] = i;
-        type[nlocal + g[l]] = (int)p.w;
-        W.sendlist[q][g[l] - sw_first[q]] = src < 0 ? i : nlocal + g[src < 0 ? 0 : src];
+        x[nlocal + g] = p;
+        ghost_image[g] = code;
+        ghost_root[g] = i;
+        type[nlocal + g] = (int)p.w;
+        W.sendlist[q][g - swf] = src < 0 ? i : nlocal + gs;
       }
-    });
-  }
+    }
+  });
 }
 
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path

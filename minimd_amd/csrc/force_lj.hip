@@ -226,7 +226,8 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   constexpr int QR = 4;
   const int per = ((kmax / QR + LJ_TILE_WAVES - 1) / LJ_TILE_WAVES) * QR;
   const int k0 = min(wv * per, kmax), k1 = min(k0 + per, kmax);
-  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
+  // (profiling build, ablate 4: every tile walks the rows of one of 64 tiles — the slot stream comes from the L2 instead of the HBM; results invalid)
+  const unsigned short* __restrict__ np = nl16 + ((size_t)((ablate & 4) ? (tile & 63) : tile) * maxneighs + k0) * 64 + lane;
   int s[UNR];
 #pragma unroll
   for(int u = 0; u < UNR; u++) s[u] = 0;
@@ -268,8 +269,12 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   auto trip = [&](auto nu, int k) {
     constexpr int U = decltype(nu)::value;
     real xj[U], yj[U], zj[U];
+    if(ablate & 8) {        // (profiling build: a slot pattern without LDS bank conflicts — 32 consecutive records per lane group; results invalid)
 #pragma unroll
-    for(int u = 0; u < U; u++) lds_read3<(RD == 1 ? 1 : 0)>((unsigned)s[u], xj[u], yj[u], zj[u]);
+      for(int u = 0; u < U; u++) s[u] = (int)(((unsigned)(lane + 7 * (k + u)) & 255u) * (unsigned)(3 * sizeof(real)));
+    }
+#pragma unroll
+    for(int u = 0; u < U; u++) lds_read3<((RD == 1 || RD == 3) ? 1 : 0)>((unsigned)s[u], xj[u], yj[u], zj[u]);
     np += U * 64;
     if(k + U < k1) {
 #pragma unroll
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     // every multiply-add is written as an explicit fma: with -ffp-contract=fast the compiler would otherwise be
     // free to pick WHICH product of a sum it fuses, and the instantiations of this template must round alike
     // pairs are worked off in groups of four (register pressure: the second group's positions wait in their LDS-read registers)
-    constexpr bool BATCH = RD == 2 && !EXACT && (U % 4) == 0 && sizeof(real) == 8;
+    constexpr bool BATCH = (RD == 2 || RD == 3) && !EXACT && (U % 4) == 0 && sizeof(real) == 8;
     constexpr int GRP = BATCH ? 4 : 1;
     static_for_groups<U, GRP>([&](auto g0c) {
       constexpr int g0 = decltype(g0c)::value;
@@ -729,7 +734,7 @@ int mmd_lj_half_tiles_available(mmd_handle* h)
 // the production tile kernel can carry finalIntegrate(n) + initialIntegrate(n+1) (no energy/virial on that step)
 int mmd_lj_can_fuse_integrate(mmd_handle* h)
 {
-  return mmd_lj_tiles_available(h) && h->opt_tile_waves == 2 && h->opt_tile_unroll == 8 && (h->opt_tile_read == 0 || h->opt_tile_read == 2) && !h->opt_exact_div;
+  return mmd_lj_tiles_available(h) && h->opt_tile_waves == 2 && h->opt_tile_unroll == 8 && (h->opt_tile_read == 0 || h->opt_tile_read == 2 || h->opt_tile_read == 3) && !h->opt_exact_div;
 }
 
 // launch the tile kernel over `count` tiles: tile ids from `list` (device) or 0..count-1
@@ -757,6 +762,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
                        h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce, G, SP); }
   const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = ex ? (h->opt_tile_read == 1 ? 1 : 0) : h->opt_tile_read;   // (exact division: one divide per pair)
   TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
+  TK(0, 0, 2, 8, 3, 1); TK(0, 0, 2, 8, 3, 0); TK(1, 0, 2, 8, 3, 0);                              // tile_read=3: the same with three separate 8-byte LDS reads per pair
   TK(0, 0, 2, 8, 0, 1);                                                                          // production, integrator fused
   TK(0, 0, 2, 8, 0, 0); TK(1, 0, 2, 8, 0, 0); TK(0, 1, 2, 8, 0, 0); TK(1, 1, 2, 8, 0, 0);        // production shape (+ exact-division check)
   TK(0, 0, 2, 8, 1, 0); TK(1, 0, 2, 8, 1, 0);

@@ -196,7 +196,8 @@ struct mmd_handle {
   int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
   int opt_safe_exchange = 0;                      // Comm::do_safeexchange (ref/comm.h:87): Comm::exchange offers leavers to every rank within `need` sub-domains
   int opt_check_exchange = 0;                     // --check_exchange: warn when an atom moved further than a sub-domain
-  int opt_tile_read = 2;                          // 2: one reciprocal per four pairs (default); 0: one per pair; 1: + three separate 8-byte LDS reads per pair (A/B knobs)
+  int opt_tile_read = MMD_PRECISION == 2 ? 3 : 2;  // LJ full-list tile kernel: 3 (DP default): one reciprocal per four pairs + three separate 8-byte LDS reads per pair; 2: the same with the
+                                                  // compiler's paired read (SP default: one reciprocal per pair there); 0: one reciprocal per pair; 1: 0 + separate reads (A/B knobs)
   int opt_fuse = 2;          // >=1: fused final+initial integrate, single-kernel ghost update on one rank; 2: integrator inside the LJ tile kernel
   int fuse_now = 0;          // transient: the next tile launch carries the integrator
   bool halo_pending = false; // transient: this step's position halo is in flight on the communication stream (ev_halo_done behind it)
