@@ -89,6 +89,8 @@ int mmd_neighbor_info(mmd_handle* h, int* maxneighs, int* mbins, long long* tota
 int mmd_neighbor_tile_stats(mmd_handle* h, long long out[6]);
 /* diagnostics: histograms (nb bins of `width`, the last one open-ended) of the tiles' candidate-union sizes and padded row counts */
 int mmd_neighbor_tile_histogram(mmd_handle* h, int nb, int width, long long* hist_ncand, long long* hist_rows);
+/* diagnostic: raw tile form of one tile (padded rows of 16-bit LDS record offsets [k][64], the atoms of its 64 lanes, its candidate union) */
+int mmd_neighbor_tile_rows(mmd_handle* h, int tile, unsigned short* rows, int rows_cap, int* kmax, int* atoms64, int* cand, int cand_cap, int* ncand);
 /* rows in REFERENCE layout neighbors[i*maxneighs + k] (ref/neighbor.cpp:128); maxneighs = caller's stride.
  * Download: valid directly after mmd_neighbor_build (half lists with ghost newton are re-derived with the reference's partition rule from the
  * current positions). Upload: the rows are also turned into the library's tile form where they fit it (every entry within the cutoff the bins

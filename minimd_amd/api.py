@@ -62,7 +62,8 @@ def load_library(precision="dp"):
         "mmd_atom_upload_f": [P, rp, I], "mmd_atom_counts": [P, ip, ip, ip], "mmd_atom_pbc": [P], "mmd_atom_sort": [P],
         "mmd_neighbor_setup": [P, ip, creal, I, I, I], "mmd_neighbor_build": [P],
         "mmd_neighbor_geometry": [P, ip, ip, ip, ip],
-        "mmd_neighbor_info": [P, ip, ip, C.POINTER(C.c_longlong), ip], "mmd_neighbor_tile_stats": [P, C.POINTER(C.c_longlong)], "mmd_neighbor_tile_histogram": [P, I, I, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "mmd_neighbor_download": [P, ip, I, ip],
+        "mmd_neighbor_info": [P, ip, ip, C.POINTER(C.c_longlong), ip], "mmd_neighbor_tile_stats": [P, C.POINTER(C.c_longlong)], "mmd_neighbor_tile_histogram": [P, I, I, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
+        "mmd_neighbor_tile_rows": [P, I, C.POINTER(C.c_ushort), I, ip, ip, ip, I, ip], "mmd_neighbor_download": [P, ip, I, ip],
         "mmd_neighbor_upload": [P, ip, I, ip, I],
         "mmd_force_lj_setup": [P, I, rp, rp, rp],
         "mmd_force_eam_setup": [P, I, I, I, I, I, creal, creal, rp, rp, rp, rp],
@@ -239,6 +240,16 @@ class Handle:
         a, b = (C.c_longlong * nb)(), (C.c_longlong * nb)()
         self._chk(self.L.mmd_neighbor_tile_histogram(self.h, nb, width, a, b))
         return [int(v) for v in a], [int(v) for v in b]
+
+    def neighbor_tile_rows(self, tile, rows_cap=256, cand_cap=4096):
+        """diagnostic: (rows[kmax][64] of 16-bit LDS record offsets, atoms of the 64 lanes (-1: none), candidate union) of one tile"""
+        rows = np.zeros(rows_cap * 64, np.uint16)
+        atoms = np.zeros(64, np.int32)
+        cand = np.zeros(cand_cap, np.int32)
+        km, nc = C.c_int(), C.c_int()
+        self._chk(self.L.mmd_neighbor_tile_rows(self.h, tile, rows.ctypes.data_as(C.POINTER(C.c_ushort)), rows_cap * 64, C.byref(km),
+                                                atoms.ctypes.data_as(C.POINTER(C.c_int)), cand.ctypes.data_as(C.POINTER(C.c_int)), cand_cap, C.byref(nc)))
+        return rows[:km.value * 64].reshape(km.value, 64).copy(), atoms, cand[:nc.value].copy()
 
     def neighbor_download(self):
         nl = self.counts()[0]

@@ -1346,20 +1346,21 @@ __global__ __launch_bounds__(256) void k_brd_scatter(real4* __restrict__ x, int 
   ovf = s_sw[7] != 0; empty = s_sw[15] != 0;
   if(ovf || empty || U == 0u) return;       // (arrays sized too small: the swap-by-swap path redoes the borders with grown ones) / nothing to add
   const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  // ghost number of the first image THIS WAVEFRONT adds to list l
-  auto first_of = [&](int l) {
-    int o = s_first[l];
-    for(int w = 0; w < wave; w++) o += s_c[w][l];
-    return __builtin_amdgcn_readfirstlane(o);
-  };
+  // ghost number of the first image THIS WAVEFRONT adds to list l: lane l works it out for all 26 lists at once (one pass over the LDS counts);
+  // the list loop below fetches its two numbers with v_readlane
+  int myoff = 0;
+  if(lane < BRD_NL) {
+    myoff = s_first[lane];
+    for(int w = 0; w < wave; w++) myoff += s_c[w][lane];
+  }
   brd_for_lists([&](auto L) {
     using LL = decltype(L);
     constexpr int l = LL::index, m = LL::mask, q = LL::swap, src = LL::source;
     if((U & m) != m) return;
-    int o = first_of(l);
+    int o = __builtin_amdgcn_readlane(myoff, l);
     // (the image a member is copied from sits in list `src`: its ghost number is recounted here rather than kept from that list's turn)
     constexpr int ms = src < 0 ? 0 : brd_mask_of(src < 0 ? 0 : src);
-    int os = src < 0 ? 0 : first_of(src < 0 ? 0 : src);
+    int os = src < 0 ? 0 : __builtin_amdgcn_readlane(myoff, src < 0 ? 0 : src);
     const int swf = s_sw[q];
 #pragma unroll
     for(int r = 0; r < 4; r++) {

@@ -1854,6 +1854,28 @@ extern "C" int mmd_neighbor_tile_stats(mmd_handle* h, long long out[6])
   return 0;
 }
 
+// diagnostics: the raw tile form of ONE tile — its padded rows (16-bit LDS offsets of the candidates' records, [k][64 lanes], kmax rows),
+// the atoms of its lanes, its candidate union (tools/lds_conflicts.py prices the LDS bank conflicts of the force kernels' gathers with it)
+extern "C" int mmd_neighbor_tile_rows(mmd_handle* h, int tile, unsigned short* rows, int rows_cap, int* kmax, int* atoms64, int* cand, int cand_cap, int* ncand)
+{
+  if(!h || !rows || !kmax || !atoms64 || !cand || !ncand) { mmd_set_error("mmd_neighbor_tile_rows: bad arguments"); return -1; }
+  if(!h->tiles_ready || tile < 0 || tile >= h->ntiles) { mmd_set_error("mmd_neighbor_tile_rows: no such tile"); return -1; }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(mmd_stream_sync(h));
+  int km = 0, nc = 0, first = 0, cnt = 0;
+  HIP_TRY(hipMemcpy(&km, h->tile_max.p + tile, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&nc, h->tile_ncand.p + tile, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&first, h->tile_first.p + tile, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&cnt, h->tile_cnt.p + tile, sizeof(int), hipMemcpyDeviceToHost));
+  if(km * 64 > rows_cap || nc > cand_cap) { mmd_set_error("mmd_neighbor_tile_rows: buffers too small (%d rows, %d candidates)", km, nc); return -1; }
+  if(km) HIP_TRY(hipMemcpy(rows, h->nl16.p + (size_t)tile * h->maxneighs * 64, sizeof(unsigned short) * 64 * km, hipMemcpyDeviceToHost));
+  if(nc) HIP_TRY(hipMemcpy(cand, h->tile_cand.p + (size_t)tile * h->tile_cstride, sizeof(int) * nc, hipMemcpyDeviceToHost));
+  for(int l = 0; l < 64; l++) atoms64[l] = -1;
+  if(cnt) HIP_TRY(hipMemcpy(atoms64, h->binned.p + first, sizeof(int) * std::min(cnt, 64), hipMemcpyDeviceToHost));
+  *kmax = km; *ncand = nc;
+  return 0;
+}
+
 // diagnostics: histograms (bins of `width`, `nb` bins, the last one open-ended) of the tiles' union sizes and padded row counts
 extern "C" int mmd_neighbor_tile_histogram(mmd_handle* h, int nb, int width, long long* hist_ncand, long long* hist_rows)
 {

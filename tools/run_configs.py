@@ -26,7 +26,7 @@ for name, args, prec in CONFIGS:
         k, v = kv.split("=")
         s.handle.set_option(k, int(v))
     s.initial()
-    s.run_steps(20)
+    s.run_steps(20 if s.natoms() > 500000 else 200)      # (small systems: list capacities and the device-resident borders settle over the first re-neighborings)
     # the chip's clocks keep ramping for >100 ms after idling and a small configuration is over in a few ms: keep the GPU busy with
     # force-kernel launches that leave the state untouched first (the set-up bench.py uses), then time 100 steps
     t_w = time.time()
