@@ -62,7 +62,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->bin_count.release(); h->bin_start.release(); h->binned.release(); h->scan_tmp.release(); h->atom_bin.release(); h->atom_rank.release();
   h->neigh.release(); h->numneigh.release(); h->wave_max.release(); h->ghost_image.release(); h->ghost_root.release();
   h->tile_of_block.release(); h->pencil_range.release(); h->tile_block.release(); h->tile_first.release(); h->tile_max.release();
-  h->tile_cand.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
+  h->tile_cand.release(); h->tile_cand_src.release(); h->box_dev.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
   for(auto& s : h->swaps) s.sendlist.release();
   h->buf_send.release(); h->buf_recv.release(); h->est.release(); h->ex_list.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->brd_bits.release(); h->partials.release();
@@ -283,6 +283,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // one rank, LJ over full lists in tile form: no per-step ghost update at all (the tile kernel resolves ghosts itself)
   const bool resolve = h->opt_ghost_resolve && !overlap && h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport &&
                        h->style == 0 && !h->halfneigh && h->nprocs == 1;
+  // EAM over full lists on one rank: the same, where the build left the ghosts named by owner + image code (both sweeps stage them from their
+  // owners, the force sweep reads their fp through the owners: no Comm::communicate, no ForceEAM::communicate launch on such a step)
+  const bool resolve_eam = h->opt_ghost_resolve && !overlap && h->opt_fuse && !h->opt_force_transport && h->style == 1 && !h->halfneigh && h->nprocs == 1;
   bool fused_force = false;          // this step's force launch carries finalIntegrate + the next initialIntegrate
   if(overlap && !h->ev_x_ready) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_x_ready, hipEventDisableTiming));
@@ -341,8 +344,10 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
           evflag_pending = ev_now;
         } else
           h->halo_pending = true;                // ForceEAM::compute / the half-list LJ dispatch split their launches themselves
-      } else if(resolve && mmd_lj_tiles_available(h) && (h->opt_ghost_resolve >= 2 || h->ntiles <= 8192)) {
+      } else if(resolve && mmd_lj_tiles_available(h) && (h->opt_ghost_resolve >= 2 || h->cand_src_ready || h->ntiles <= 8192)) {
         h->ghosts_stale = true;                  // this step's force kernel reads the ghosts through their owners (tile_lds.hpp)
+      } else if(resolve_eam && h->ghost_chain_ok && h->cand_src_ready && mmd_eam_can_fuse_integrate(h)) {
+        h->ghosts_stale = true;                  // (both EAM sweeps stage the ghosts from their owners)
       } else {
         if(time_halo) MMD_TRY(ev_begin(h, 1));
         MMD_TRY(mmd_comm_communicate(h));

@@ -27,6 +27,7 @@ extern "C" int mmd_atom_set_box(mmd_handle* h, const mmd_float prd[3], const mmd
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
   for(int d = 0; d < 3; d++) { h->prd[d] = prd[d]; h->lo[d] = lo[d]; h->hi[d] = hi[d]; }
+  h->box_dev_valid = false;
   return 0;
 }
 

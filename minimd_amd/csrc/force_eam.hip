@@ -453,14 +453,15 @@ __device__ __forceinline__ bool eam_use_core(const EamCore& C, int lane)
 // in registers and to its PARTNER through an LDS accumulator per candidate (ds_add_f64); at the end of the tile the accumulators
 // of the owned candidates are flushed to rho[] with one global atomic each, in memory order (whole lines per wave instruction,
 // see k_lj_half_tile). rho was zeroed beforehand; fp = F'(rho) is a separate pass (k_eam_half_fp) once every tile has flushed.
-template <int EV, int HALF>
+template <int EV, int HALF, int SRC = 0>
 __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, int cmax, real rdr, real rdrho, real* __restrict__ fp,
-    double* __restrict__ partials, int mlo, const unsigned short* __restrict__ tile_self, real* __restrict__ rho, EamCore C)
+    double* __restrict__ partials, int mlo, const unsigned short* __restrict__ tile_self, real* __restrict__ rho, EamCore C,
+    const int* __restrict__ cand_src, const real* __restrict__ box_dev)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_TW;
@@ -490,7 +491,10 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   // together; then the positions. (2-3 workgroups per CU — the knot table bounds the occupancy — hide little of a longer chain.)
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
-  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  // one rank, full lists (G.cand_src): ghosts are staged from their OWNERS' current positions + the box shift of their image code — the step has
+  // no Comm::communicate launch (tile_lds.hpp: GhostResolve); for owned atoms and the dummy the two lists hold the same index
+  constexpr bool packed = SRC != 0 && !HALF;
+  const int* __restrict__ cl = (packed ? cand_src : tile_cand) + (size_t)tile * cstride;
   const bool stage = !(MMD_ABLATE(C.ablate) & 1);
   int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
@@ -508,10 +512,14 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   }
   real4 pp[EAM_STAGE];
 #pragma unroll
-  for(int u = 0; u < EAM_STAGE; u++) pp[u] = x[jj[u]];
+  for(int u = 0; u < EAM_STAGE; u++) pp[u] = x[packed ? (jj[u] & MMD_SRC_MASK) : jj[u]];
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   if(stage) {
+    if(packed) {
+#pragma unroll
+      for(int u = 0; u < EAM_STAGE; u++) pp[u] = ghost_shifted(pp[u], jj[u], box_dev);
+    }
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) {
       s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z;
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     }
     for(int t0 = EAM_STAGE * NT; t0 <= ncand; t0 += NT) {          // (a union beyond EAM_STAGE * NT candidates: rare)
       const int t = min(t0 + tid, ncand), j = cl[t];
-      const real4 p = x[j];
+      const real4 p = packed ? ghost_shifted(x[j & MMD_SRC_MASK], j, box_dev) : x[j];
       s_pos[3 * t] = p.x; s_pos[3 * t + 1] = p.y; s_pos[3 * t + 2] = p.z;
       if(HALF) { s_racc[t] = 0; s_idx[t] = j; }
     }
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
 // pair goes to three LDS accumulators per candidate, flushed for the owned candidates at the end of the tile (see
 // k_eam_density_tile); a ghost partner gets no force and the pair counts half in energy and virial (:244-257). f was zeroed
 // beforehand; partials = {sum phi, virial} per tile.
-template <int EV, int FUSE, int HALF>
+template <int EV, int FUSE, int HALF, int SRC = 0>
 __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HALF ? 2 : EAM_FWAVES))) void k_eam_force_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first, const int* __restrict__ tile_cnt,
     const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
@@ -608,7 +616,8 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
     double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, int mlo,
-    const unsigned short* __restrict__ tile_self, EamCore C, const int* __restrict__ fp_root)
+    const unsigned short* __restrict__ tile_self, EamCore C, const int* __restrict__ fp_root,
+    const int* __restrict__ cand_src, const real* __restrict__ box_dev)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_FW;
@@ -643,11 +652,12 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   // three round trips (see k_eam_density_tile): header; indices + own atom + first slots; positions + fp
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
-  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  constexpr bool packed = SRC != 0 && !HALF;       // (see k_eam_density_tile: ghosts named by owner + image code)
+  const int* __restrict__ cl = (packed ? cand_src : tile_cand) + (size_t)tile * cstride;
   const bool stage = !(MMD_ABLATE(C.ablate) & 1);
   // one rank: a ghost is an image of an owned atom, its fp is its owner's (ForceEAM::communicate, ref/force_eam.cpp:851-913, folded
   // into the staging: no fp halo launch between the two sweeps)
-  auto fp_index = [&](int j) { return (fp_root != nullptr && j >= nlocal && j < nall) ? fp_root[j - nlocal] : j; };
+  auto fp_index = [&](int j) { return packed ? (j & MMD_SRC_MASK) : ((fp_root != nullptr && j >= nlocal && j < nall) ? fp_root[j - nlocal] : j); };
   int tt[EAM_STAGE], jj[EAM_STAGE];
 #pragma unroll
   for(int u = 0; u < EAM_STAGE; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = EAM_F_LOAD(cl + tt[u]); }
@@ -656,7 +666,11 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   // wavefront is the tile's critical path
   const int hq = kmax >> 1, hbase = hq / EAM_FW, hrem = hq - hbase * EAM_FW;
   const int k0 = 2 * (wv * hbase + min(wv, hrem)), k1 = k0 + 2 * (hbase + (wv < hrem ? 1 : 0));
-  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane;
+  // (the lane offset is made opaque per tile: hoisted out of the tile loop, `nl16 + lane` and its +512-byte twin are two 64-bit register pairs that
+  //  live through the pair loop — in the variant that stages ghosts from their owners they were spilled and reloaded behind a full vmcnt(0))
+  int lane_o = lane;
+  asm volatile("" : "+v"(lane_o));
+  const unsigned short* __restrict__ np = nl16 + ((size_t)tile * maxneighs + k0) * 64 + lane_o;
   int sl[EAM_FU];
 #pragma unroll
   for(int u = 0; u < EAM_FU; u++) sl[u] = 0;
@@ -667,11 +681,15 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   real4 pp[EAM_STAGE];
   real ff[EAM_STAGE];
 #pragma unroll
-  for(int u = 0; u < EAM_STAGE; u++) { pp[u] = x[jj[u]]; ff[u] = fp[fp_index(jj[u])]; }
+  for(int u = 0; u < EAM_STAGE; u++) { pp[u] = x[packed ? (jj[u] & MMD_SRC_MASK) : jj[u]]; ff[u] = fp[fp_index(jj[u])]; }
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   const real fpi = fp[i >= 0 ? i : 0];
   if(stage) {
+    if(packed) {
+#pragma unroll
+      for(int u = 0; u < EAM_STAGE; u++) pp[u] = ghost_shifted(pp[u], jj[u], box_dev);
+    }
 #pragma unroll
     for(int u = 0; u < EAM_STAGE; u++) {
       s_pos[3 * tt[u]] = pp[u].x; s_pos[3 * tt[u] + 1] = pp[u].y; s_pos[3 * tt[u] + 2] = pp[u].z; s_fp[tt[u]] = ff[u];
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
     }
     for(int t0 = EAM_STAGE * NT; t0 <= ncand; t0 += NT) {          // (a union beyond EAM_STAGE * NT candidates: rare)
       const int t = min(t0 + tid, ncand), j = cl[t];
-      const real4 p = x[j];
+      const real4 p = packed ? ghost_shifted(x[j & MMD_SRC_MASK], j, box_dev) : x[j];
       const real fj = fp[fp_index(j)];
       s_pos[3 * t] = p.x; s_pos[3 * t + 1] = p.y; s_pos[3 * t + 2] = p.z; s_fp[t] = fj;
       if(HALF) { s_acc[3 * t] = 0; s_acc[3 * t + 1] = 0; s_acc[3 * t + 2] = 0; s_idx[t] = j; }
@@ -1003,7 +1021,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     hipLaunchKernelGGL((k_eam_density_tile<0, 1>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p, h->tile_first.p,
                        h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,
                        h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr, h->nrho, h->tile_cmax, h->rdr, h->rdrho,
-                       h->fp.p, (double*)nullptr, mlo, h->tile_self.p, h->rho.p, EamCore{});
+                       h->fp.p, (double*)nullptr, mlo, h->tile_self.p, h->rho.p, EamCore{}, (const int*)nullptr, (const real*)nullptr);
     if(evflag) hipLaunchKernelGGL((k_eam_half_fp<1>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p, 1, h->nrho,
                                   h->nrho_tot, h->rdrho, h->fp.p, p_embed);
     else hipLaunchKernelGGL((k_eam_half_fp<0>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p, 1, h->nrho,
@@ -1013,7 +1031,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define FH(EVv) hipLaunchKernelGGL((k_eam_force_tile<EVv, 0, 1>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p, h->tile_first.p, \
                        h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,   \
                        h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr, h->tile_cmax, h->rdr, h->fp.p, h->f.p, p_pair,          \
-                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p, EamCore{}, (const int*)nullptr)
+                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p, EamCore{}, (const int*)nullptr, (const int*)nullptr, (const real*)nullptr)
     if(evflag) FH(1); else FH(0);
 #undef FH
     HIP_TRY(hipGetLastError());
@@ -1086,6 +1104,11 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<0, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_force_tile<1, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_eam_density_tile<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       h->eam_attr_set = true;
     }
     // rows in two parts (CoreRows): the run loop says which part this call may walk; a fused launch tracks the displacement for the next
@@ -1102,19 +1125,41 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
         core.words_zero = h->core_words.p + 64 * ((h->core.step + 1) % 3);
       }
     }
-#define DT(EVv, LIST, CNT) hipLaunchKernelGGL((k_eam_density_tile<EVv, 0>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
+#define DT(EVv, Sv, LIST, CNT) hipLaunchKernelGGL((k_eam_density_tile<EVv, 0, Sv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
-                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo, (const unsigned short*)nullptr, (real*)nullptr, core)
-#define FT(EVv, Fv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv, 0>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p,       \
+                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo, (const unsigned short*)nullptr, (real*)nullptr, core, src_p, box_p)
+#define FT(EVv, Fv, Sv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv, 0, Sv>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p,       \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
-                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr, core, fp_root)
+                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr, core, fp_root, src_p, box_p)
     // one rank: the force sweep reads a ghost's fp through its owner (no fp halo launch); mmd_force_eam_download_fp completes the array
-    const bool fold_fp = h->opt_eam_fold_fp && (h->opt_eam_fold_fp >= 2 || nt <= 8192) && !h->halo_pending && h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport;
-    const int* fp_root = fold_fp ? (const int*)h->ghost_root.p : (const int*)nullptr;
-    auto density = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) DT(1, list, cnt); else DT(0, list, cnt); } };
-    auto force = [&](const int* list, int cnt) { if(cnt > 0) { if(evflag) FT(1, 0, list, cnt); else if(h->fuse_now) FT(0, 1, list, cnt); else FT(0, 0, list, cnt); } };
+    // one rank, ghosts named by owner + image code in the candidate lists (Integrate::run sets resolve_now on steps without re-neighboring):
+    // both sweeps stage the ghosts from their owners — no Comm::communicate launch in front, no fp halo between them
+    const int* src_p = (h->resolve_now && h->cand_src_ready && !h->halo_pending) ? (const int*)h->tile_cand_src.p : (const int*)nullptr;
+    const real* box_p = nullptr;
+    if(src_p != nullptr) {
+      if(!h->box_dev_valid) {
+        MMD_TRY(h->box_dev.ensure(4, false, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->box_dev.p, h->prd, 3 * sizeof(real), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(mmd_stream_sync(h));
+        h->box_dev_valid = true;
+      }
+      box_p = h->box_dev.p;
+    }
+    const bool fold_fp = src_p != nullptr ||
+                         (h->opt_eam_fold_fp && (h->opt_eam_fold_fp >= 2 || nt <= 8192) && !h->halo_pending && h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport);
+    const int* fp_root = (fold_fp && src_p == nullptr) ? (const int*)h->ghost_root.p : (const int*)nullptr;
+    auto density = [&](const int* list, int cnt) {
+      if(cnt <= 0) return;
+      if(src_p) { if(evflag) DT(1, 1, list, cnt); else DT(0, 1, list, cnt); }
+      else { if(evflag) DT(1, 0, list, cnt); else DT(0, 0, list, cnt); }
+    };
+    auto force = [&](const int* list, int cnt) {
+      if(cnt <= 0) return;
+      if(src_p) { if(evflag) FT(1, 0, 1, list, cnt); else if(h->fuse_now) FT(0, 1, 1, list, cnt); else FT(0, 0, 1, list, cnt); }
+      else { if(evflag) FT(1, 0, 0, list, cnt); else if(h->fuse_now) FT(0, 1, 0, list, cnt); else FT(0, 0, 0, list, cnt); }
+    };
     if(h->halo_pending) {
       // overlapped step (several ranks): the position halo of this step is in flight on the communication stream (the caller
       // recorded ev_halo_done behind it). Interior tiles — no ghost among their candidates — run under it, the boundary tiles

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   // ---- stage the positions of the tile's candidate union (+1 dummy slot) into LDS: {x,y,z} records of
   // 3 reals (stride 3 is coprime with the bank count: random slots spread over all banks, one address per pair)
   real* sp = (real*)s_raw;
-  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  const bool packed = ghosted && G.cand_src != nullptr;      // (boundary tile whose ghosts are named by owner + image code: no look-up in front of the position load)
+  const int* __restrict__ cl = (packed ? G.cand_src : tile_cand) + (size_t)tile * cstride;
   // Branch-free: the build stores the dummy atom's index at cl[ncand], lanes past the end clamp to that entry
   // and (re)write the same dummy record, so one pass of 512 records covers almost every tile (unions hold ~450 atoms at LJ liquid density).
   constexpr int STG = 512 / LJ_TILE_THREADS;
@@ -236,7 +237,10 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     for(int u = 0; u < UNR; u++) s[u] = stream_load(np + u * 64);
   }
   real4 pp[STG];
-  if(ghosted) {
+  if(packed) {
+#pragma unroll
+    for(int u = 0; u < STG; u++) pp[u] = x[jj[u] & MMD_SRC_MASK];
+  } else if(ghosted) {
 #pragma unroll
     for(int u = 0; u < STG; u++) pp[u] = ghost_resolved(x, jj[u], nlocal, nall, G);
   } else {
@@ -246,11 +250,15 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
   if(!(ablate & 1)) {
+    if(packed) {
+#pragma unroll
+      for(int u = 0; u < STG; u++) pp[u] = ghost_shifted(pp[u], jj[u], G);
+    }
 #pragma unroll
     for(int u = 0; u < STG; u++) { sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z; }
     for(int t0 = 512; t0 <= ncand; t0 += LJ_TILE_THREADS) {        // (a union beyond 512 candidates: 2 % of the tiles at -s 80)
       const int t = min(t0 + tid, ncand), j = cl[t];
-      const real4 p = ghosted ? ghost_resolved(x, j, nlocal, nall, G) : x[j];
+      const real4 p = packed ? ghost_shifted(x[j & MMD_SRC_MASK], j, G) : (ghosted ? ghost_resolved(x, j, nlocal, nall, G) : x[j]);
       sp[3 * t] = p.x; sp[3 * t + 1] = p.y; sp[3 * t + 2] = p.z;
     }
   }
@@ -750,8 +758,8 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   // stream no marker packets (a bracketing hipEventRecord pair costs ~6 us per step, 15 % of a -s 32 step)
   hipEvent_t kev_a = h->launch_ev_a, kev_b = h->launch_ev_b;
   h->launch_ev_a = h->launch_ev_b = nullptr;
-  GhostResolve G{nullptr, nullptr, nullptr, {h->prd[0], h->prd[1], h->prd[2]}};
-  if(h->resolve_now) { G.root = h->ghost_root.p; G.image = h->ghost_image.p; G.tile_ghost = h->tile_ghost.p; }
+  GhostResolve G{nullptr, nullptr, nullptr, {h->prd[0], h->prd[1], h->prd[2]}, nullptr};
+  if(h->resolve_now) { G.root = h->ghost_root.p; G.image = h->ghost_image.p; G.tile_ghost = h->tile_ghost.p; G.cand_src = h->cand_src_ready ? h->tile_cand_src.p : nullptr; }
   const SpecLaunch SP = list == nullptr ? h->spec : SpecLaunch{nullptr, nullptr, nullptr};
   if(SP.gate != nullptr) { h->spec_launches++; h->spec_fused = fz != 0; }
 #define TK(EVv, Xv, Wv, Uv, Rv, Fv) if(!launched && ev == EVv && ex == Xv && tw == Wv && tu == Uv && rd == Rv && fz == Fv) { launched = true;  \

@@ -162,6 +162,10 @@ struct mmd_handle {
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
   DevArr<int> pencil_range;               // per pencil (row of blocks along x): [first, last) entry of binned[] between its first and last owned bin
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
+  DevArr<int> tile_cand_src;              // one-rank runs: tile_cand with every ghost named by its owner + image code (GhostResolve, tile_lds.hpp)
+  bool cand_src_ready = false;
+  DevArr<real> box_dev;                   // the box lengths in device memory (ghost_shifted fetches them inside its rare branch)
+  bool box_dev_valid = false;
   DevArr<unsigned short> tile_self;       // half lists: union slot of each tile atom itself (0xffff: not in the union)
   // Rows in two parts (full lists, one rank): pairs closer than `radius` = cutforce + margin at the build come first ("core"), the rest of
   // the skin behind them; tile_kcore = padded length of the core part. A pair of the rest can only come inside the force cutoff after
@@ -238,8 +242,9 @@ struct mmd_handle {
   bool borders_general_done = false;   // a swap-by-swap Comm::borders has run (several ranks: the collective condition for the fixed-size-message path)
   bool big_bins = false;       // some bin holds more than NB_BIGBIN atoms: binning runs the grid-wide rank sort too
   bool in_reneighbor = false;  // inside Integrate::run's re-neighboring: Comm::borders follows Atom::sort, ghosts need not ride along
-  // one-rank LJ full-list steps: the tile kernel stages ghosts from their owners, no per-step Comm::communicate. 1 = where it
-  // pays (small systems: the saved launch is ~3 us, the extra indirection of the boundary tiles costs ~3 us at -s 80), 2 = always
+  // one-rank LJ full-list steps: the tile kernel stages ghosts from their owners, no per-step Comm::communicate. 1 = where it pays: whenever the
+  // build left the candidate lists with the ghosts named by owner + image code (tile_cand_src: no look-up in front of the position load: +0.9 % at
+  // -s 80, +4.6 % at -s 32), otherwise on small systems only (the look-up costs the boundary tiles a round trip); 2 = always; 0 = never
   int opt_ghost_resolve = 1;
   // one-rank half-list LJ steps with ghost newton: the tile kernel adds a ghost's share to its owner (no Comm::reverse_communicate)
   int opt_fold_reverse = 1;

@@ -20,6 +20,7 @@
 #include "device_utils.hpp"
 #include <algorithm>
 #include "mmd_internal.hpp"
+#include "tile_lds.hpp"
 #include <vector>
 
 #define NB_SMALL 1.0e-6
@@ -899,7 +900,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    unsigned short* __restrict__ tile_self, int* __restrict__ tile_rowmax,
                                                    int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate_arg,
                                                    const int* __restrict__ ntiles_dev, const int* __restrict__ nghost_dev,
-                                                   float core_thr, real4* __restrict__ xbuild, int* __restrict__ tile_kcore)
+                                                   float core_thr, real4* __restrict__ xbuild, int* __restrict__ tile_kcore,
+                                                   int* __restrict__ cand_src, const int* __restrict__ ghost_root)
 {
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   nall = deferred_count(nall, nlocal, nghost_dev);
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   unsigned short* __restrict__ rowp = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
   const size_t cbase = (size_t)tile * cstride;
   if(own_mask == 0ull || (ablate & 32)) {                        // (second tile of a block that holds only ghosts)
-    if(lane == 0) { tile_max[tile] = 0; tile_ncand[tile] = 0; tile_cand[cbase] = nall; tile_ghost[tile] = 0; tile_rowmax[tile] = 0; tile_rowsum[tile] = 0; }
+    if(lane == 0) { tile_max[tile] = 0; tile_ncand[tile] = 0; tile_cand[cbase] = nall; if(cand_src != nullptr) cand_src[cbase] = nall; tile_ghost[tile] = 0; tile_rowmax[tile] = 0; tile_rowsum[tile] = 0; }
     if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = (unsigned short)0xffff;
     return;
   }
@@ -1195,7 +1197,12 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         const int bq = G - 1 - lane;
         if((used >> bq) & 1u) {
           const int slot = S + __popc(used >> 1 >> bq);           // used candidates before mine
-          if(slot < cstride - 1) tile_cand[cbase + slot] = __float_as_int(s_buf[NB2_IDX + gq + lane]);
+          if(slot < cstride - 1) {
+            const int cj = __float_as_int(s_buf[NB2_IDX + gq + lane]);
+            tile_cand[cbase + slot] = cj;
+            // (one rank: the same list with a ghost named by its owner and image code, for tile kernels that stage ghosts from their owners)
+            if(cand_src != nullptr) cand_src[cbase + slot] = cj >= nlocal && cj < nall ? (ghost_root[cj - nlocal] | ((ghost_image[cj - nlocal] + 1) << MMD_SRC_BITS)) : cj;
+          }
           if(MODE != 0) { const unsigned own = s_own[gq + lane]; if(own != 0xffu) s_self[own] = (unsigned short)slot; }
         }
       }
@@ -1344,6 +1351,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     if(kneed > maxneighs) atomicMax(&flags[7], kneed);       // (rare) the two padded parts do not fit the row capacity: the host grows it
     tile_ncand[tile] = S;
     tile_cand[cbase + min(S, cstride - 1)] = nall;          // the dummy atom closes the list
+    if(cand_src != nullptr) cand_src[cbase + min(S, cstride - 1)] = nall;
     tile_ghost[tile] = any_ghost ? 1 : 0;
     // per-tile results, reduced by k_tile_reduce: 36 k workgroups hammering three global words with atomics cost
     // 0.8 ms at -s 80 (same-address atomics retire one at a time, ~10 ns each)
@@ -1627,6 +1635,15 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
+    // one rank, full lists (LJ, EAM with one table set): the candidate lists once more with every ghost named by its owner + image code (the tile kernels can
+    // then stage ghosts from their owners' current positions without a look-up: GhostResolve, tile_lds.hpp)
+    int* cand_src_p = nullptr;
+    h->cand_src_ready = false;
+    if(h->opt_build == 1 && h->opt_ghost_resolve && (h->style == 0 || h->eam_uniform) && !h->halfneigh && h->nprocs == 1 && !h->opt_force_transport && (h->nghost_dev != nullptr || h->ghost_chain_ok) &&
+       !h->ghosts_uploaded && nlocal + h->nghost < (1 << MMD_SRC_BITS) && h->ghost_root.p != nullptr) {
+      MMD_TRY(h->tile_cand_src.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
+      cand_src_p = h->tile_cand_src.p;
+    }
     if(fill_scans)
       hipLaunchKernelGGL(k_pencil_fill_scan, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
                          h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev);
@@ -1659,7 +1676,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
                      h->ghost_image.p, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
                      h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
                      h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate, nt_dev, h->nghost_dev, \
-                     core_thr, h->xbuild.p, h->tile_kcore.p)
+                     core_thr, h->xbuild.p, h->tile_kcore.p, cand_src_p, (const int*)h->ghost_root.p)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         hipLaunchKernelGGL(k_tile_reduce, dim3(std::min(32, std::max(1, div_up(h->ntiles, 1024)))), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
@@ -1766,6 +1783,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       h->ntiles_hint = h->ntiles;
       h->neigh_nlocal = nlocal;
       h->ntiles_interior = order_here ? h->h_flags[13] : -1;    // (-1: the interior/boundary order is derived on demand, mmd_order_tiles)
+      h->cand_src_ready = cand_src_p != nullptr && h->ghost_chain_ok;
       h->spec_done = verdict != 0;
       if(verdict && h->spec_fused)           // the gated kernel wrote the dummy atom of the second position buffer behind the last ghost
         for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x_alt.p) h->xalt_dummy_slot[k] = nlocal + h->nghost;

@@ -58,7 +58,26 @@ template <typename T> __device__ __forceinline__ T stream_load(const T* p) { ret
 // Comm::communicate (k_ghost_update, ref/comm.cpp:276-317 with self swaps) and its launch gap disappear from the step.
 // root == nullptr: off (ghost slots of x are read as usual). The shift is applied one box length at a time, exactly like
 // the swap-by-swap packing does (pack_comm adds pbc*prd once per swap).
-struct GhostResolve { const int* root; const int* image; const int* tile_ghost; real prd[3]; };
+struct GhostResolve { const int* root; const int* image; const int* tile_ghost; real prd[3]; const int* cand_src; };
+// cand_src (k_build_rows, one-rank runs): the tile's candidate list once more, a ghost entry replaced by its OWNER and its image code
+// (owner | (code + 1) << 25; owned atoms and the dummy: the plain index) — staging a boundary tile then needs no root / image look-up
+// in front of the position load (one dependent round trip less than ghost_resolved)
+#define MMD_SRC_BITS 25
+#define MMD_SRC_MASK ((1 << MMD_SRC_BITS) - 1)
+__device__ __forceinline__ real4 ghost_shifted(real4 p, int src, const real* __restrict__ prd)
+{
+  const int c1 = (int)((unsigned)src >> MMD_SRC_BITS);
+  if(c1 != 0) {                                    // (the box lengths are fetched inside the branch: nothing of them lives in registers on the common path)
+    const int code = c1 - 1;
+    const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
+    const real bx = prd[0], by = prd[1], bz = prd[2];
+    for(int q = 0; q < (sx < 0 ? -sx : sx); q++) p.x += sx < 0 ? -bx : bx;
+    for(int q = 0; q < (sy < 0 ? -sy : sy); q++) p.y += sy < 0 ? -by : by;
+    for(int q = 0; q < (sz < 0 ? -sz : sz); q++) p.z += sz < 0 ? -bz : bz;
+  }
+  return p;
+}
+__device__ __forceinline__ real4 ghost_shifted(real4 p, int src, const GhostResolve& G) { return ghost_shifted(p, src, G.prd); }
 
 __device__ __forceinline__ real4 ghost_resolved(const real4* __restrict__ x, int j, int nlocal, int nall, const GhostResolve& G)
 {

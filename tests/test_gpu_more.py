@@ -428,6 +428,28 @@ def test_ghosts_staged_from_their_owners_equal_the_ghost_update(args):
         np.testing.assert_array_equal(out[0][k], out[2][k])
 
 
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("args", [["-s", 10], ["-s", 4], ["-nx", 3, "-ny", 6, "-nz", 4]])
+def test_eam_ghosts_staged_from_their_owners_equal_the_halos(args, prec):
+    """EAM over full lists on one rank: the build leaves the candidate lists a second time with every ghost named by its owner and image code,
+    and on steps without re-neighboring both sweeps stage the ghosts from their owners (position + box shift; fp of the owner) — no
+    Comm::communicate launch, no ForceEAM::communicate between the sweeps. Same bits as with the two halos (ghost_resolve 0): thermo rows,
+    positions (ghosts refreshed when the run returns), velocities, forces. -s 4 and 3x6x4 cells have images of images."""
+    m = mm()
+    out = {}
+    for mode in (0, 1):
+        s = m.Sim(["-i", "in.eam.miniMD"] + args + ["-n", 60, "--half_neigh", 0], precision=prec)
+        s.handle.set_option("ghost_resolve", mode)
+        s.handle.set_option("eam_fold_fp", 0)
+        s.initial(); s.run()
+        d = s.handle.download()
+        out[mode] = (s.rows(), d["x"].copy(), d["v"].copy(), d["f"].copy())
+        s.close()
+    assert out[0][0] == out[1][0]
+    for k in (1, 2, 3):
+        np.testing.assert_array_equal(out[0][k], out[1][k])
+
+
 @pytest.mark.parametrize("args", [["-s", 12], ["-s", 3], ["-nx", 2, "-ny", 5, "-nz", 3]])
 def test_reverse_communicate_folded_into_the_half_kernel(args):
     """One rank, half lists with ghost newton: the tile kernel adds a ghost's share of a pair to the ghost's owner directly
