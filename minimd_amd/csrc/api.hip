@@ -286,6 +286,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // EAM over full lists on one rank: the same, where the build left the ghosts named by owner + image code (both sweeps stage them from their
   // owners, the force sweep reads their fp through the owners: no Comm::communicate, no ForceEAM::communicate launch on such a step)
   const bool resolve_eam = h->opt_ghost_resolve && !overlap && h->opt_fuse && !h->opt_force_transport && h->style == 1 && !h->halfneigh && h->nprocs == 1;
+  // LJ over half lists on one rank: the same; with ghost newton only where the reverse communication is folded into the kernel
+  const bool resolve_half = h->opt_ghost_resolve && !overlap && h->opt_fuse && !h->opt_force_transport && h->style == 0 && h->halfneigh && h->nprocs == 1 &&
+                            !h->opt_lj_original && (!h->ghost_newton || fold);
   bool fused_force = false;          // this step's force launch carries finalIntegrate + the next initialIntegrate
   if(overlap && !h->ev_x_ready) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_x_ready, hipEventDisableTiming));
@@ -348,6 +351,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         h->ghosts_stale = true;                  // this step's force kernel reads the ghosts through their owners (tile_lds.hpp)
       } else if(resolve_eam && h->ghost_chain_ok && h->cand_src_ready && mmd_eam_can_fuse_integrate(h)) {
         h->ghosts_stale = true;                  // (both EAM sweeps stage the ghosts from their owners)
+      } else if(resolve_half && h->ghost_chain_ok && h->cand_src_ready && mmd_lj_half_tiles_available(h)) {
+        h->ghosts_stale = true;                  // (the half-list tile kernel stages the ghosts from their owners; their shares go to the owners)
       } else {
         if(time_halo) MMD_TRY(ev_begin(h, 1));
         MMD_TRY(mmd_comm_communicate(h));

@@ -1139,12 +1139,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     const int* src_p = (h->resolve_now && h->cand_src_ready && !h->halo_pending) ? (const int*)h->tile_cand_src.p : (const int*)nullptr;
     const real* box_p = nullptr;
     if(src_p != nullptr) {
-      if(!h->box_dev_valid) {
-        MMD_TRY(h->box_dev.ensure(4, false, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->box_dev.p, h->prd, 3 * sizeof(real), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(mmd_stream_sync(h));
-        h->box_dev_valid = true;
-      }
+      MMD_TRY(mmd_box_dev(h));
       box_p = h->box_dev.p;
     }
     const bool fold_fp = src_p != nullptr ||

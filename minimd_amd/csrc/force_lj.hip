@@ -470,16 +470,21 @@ __device__ __forceinline__ void ljh_unpack_xy(unsigned long long v, double& x, d
   y = (double)lo * (1.0 / (double)LJH_FIX_SCALE);
 }
 
-template <int EV, int GN>
+// SRC=1 (one rank): the candidates come from the second list the build wrote, a ghost named by its owner + image code (GhostResolve, tile_lds.hpp):
+// it is staged from the owner's current position (no Comm::communicate launch on the step) and, with ghost newton, its share goes to the owner
+// at the flush without a look-up; without ghost newton it is flagged and gets none.
+template <int EV, int GN, int SRC = 0>
 __global__ __launch_bounds__(128) void k_lj_half_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, const unsigned short* __restrict__ tile_self, int nlocal, int nall, int maxneighs, int pos_bytes,
-    LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate_arg, const int* __restrict__ ghost_root)
+    LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate_arg, const int* __restrict__ ghost_root,
+    const int* __restrict__ cand_src, const real* __restrict__ box_dev)
 {
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   constexpr int UNR = 8, NT = 128, STG = 4;
+  constexpr bool packed = SRC != 0;
   extern __shared__ __align__(16) unsigned char s_raw[];
   real* sp = (real*)s_raw;
   // accumulators are doubles in both precisions: ds_add_f64 runs ~8x faster than ds_add_f32 on this part (measured: 0.10 vs
@@ -499,7 +504,10 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   const int tile = tile_list ? tile_list[witem] : witem;
   // three round trips (see k_lj_full_tile): header scalars; candidate indices + own atom index + first slots; positions
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile], kmax = tile_max[tile];
-  const int* __restrict__ cl = tile_cand + (size_t)tile * cstride;
+  const int* __restrict__ cl = (packed ? cand_src : tile_cand) + (size_t)tile * cstride;
+  // what the flush needs of a candidate: the atom whose force collects its share (packed: the owner; a ghost without ghost newton: nobody = nall)
+  auto flush_index = [&](int j) { return !packed ? j : ((GN || ((unsigned)j >> MMD_SRC_BITS) == 0u) ? (j & MMD_SRC_MASK) : nall); };
+  auto is_ghost = [&](int j) { return packed ? ((unsigned)j >> MMD_SRC_BITS) != 0u : j >= nlocal; };
   int tt[STG], jj[STG];
 #pragma unroll
   for(int u = 0; u < STG; u++) { tt[u] = min(u * NT + tid, ncand); jj[u] = stream_load(cl + tt[u]); }
@@ -517,23 +525,27 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   }
   real4 pp[STG];
 #pragma unroll
-  for(int u = 0; u < STG; u++) pp[u] = x[jj[u]];
+  for(int u = 0; u < STG; u++) pp[u] = x[packed ? (jj[u] & MMD_SRC_MASK) : jj[u]];
   if(i >= nlocal) i = -1;
   const real4 xi = x[i >= 0 ? i : 0];
+  if(packed) {
+#pragma unroll
+    for(int u = 0; u < STG; u++) pp[u] = ghost_shifted(pp[u], jj[u], box_dev);
+  }
 #pragma unroll
   for(int u = 0; u < STG; u++) {                              // positions in, accumulators cleared
     sp[3 * tt[u]] = pp[u].x; sp[3 * tt[u] + 1] = pp[u].y; sp[3 * tt[u] + 2] = pp[u].z;
     s_acc[3 * tt[u]] = 0; s_acc[3 * tt[u] + 1] = 0; s_acc[3 * tt[u] + 2] = 0;
-    s_idx[tt[u]] = jj[u];
-    if(EV && !GN) s_ghost[tt[u]] = jj[u] >= nlocal ? 1 : 0;
+    s_idx[tt[u]] = flush_index(jj[u]);
+    if(EV && !GN) s_ghost[tt[u]] = is_ghost(jj[u]) ? 1 : 0;
   }
   for(int t0 = STG * NT; t0 <= ncand; t0 += NT) {             // (a union beyond STG * NT candidates: rare)
     const int t = min(t0 + tid, ncand), j = cl[t];
-    const real4 p = x[j];
+    const real4 p = packed ? ghost_shifted(x[j & MMD_SRC_MASK], j, box_dev) : x[j];
     sp[3 * t] = p.x; sp[3 * t + 1] = p.y; sp[3 * t + 2] = p.z;
     s_acc[3 * t] = 0; s_acc[3 * t + 1] = 0; s_acc[3 * t + 2] = 0;
-    s_idx[t] = j;
-    if(EV && !GN) s_ghost[t] = j >= nlocal ? 1 : 0;
+    s_idx[t] = flush_index(j);
+    if(EV && !GN) s_ghost[t] = is_ghost(j) ? 1 : 0;
   }
   __syncthreads();
   drain_loads();
@@ -850,11 +862,17 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     const size_t pos_bytes = lj_tile_pos_bytes(h);
     const size_t lds = lj_half_tile_lds(h);
     const int gn = h->ghost_newton ? 1 : 0;
-#define HT(EVv, Gv, LIST, CNT) if(ev == EVv && gn == Gv && (CNT) > 0)                                                                \
-      hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv>), dim3(xcd_grid(CNT)), dim3(128), lds, h->stream, h->x.p, h->binned.p,              \
+    // one rank, ghosts named by owner + image code (Integrate::run sets resolve_now on steps without re-neighboring; with ghost newton only together
+    // with the folded reverse communication: the shares of the ghosts then go to their owners)
+    const int* src_p = (h->resolve_now && h->cand_src_ready && !h->halo_pending && (!gn || h->fold_reverse_now)) ? (const int*)h->tile_cand_src.p : (const int*)nullptr;
+    const real* box_p = nullptr;
+    if(src_p != nullptr) { MMD_TRY(mmd_box_dev(h)); box_p = h->box_dev.p; }
+#define HTS(EVv, Gv, Sv, LIST, CNT)                                                                                                   \
+      hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv, Sv>), dim3(xcd_grid(CNT)), dim3(128), lds, h->stream, h->x.p, h->binned.p,          \
                          h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,  \
                          h->nl16.p, h->tile_self.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,            \
-                         h->partials.p, h->opt_ablate, h->fold_reverse_now ? (const int*)h->ghost_root.p : (const int*)nullptr)
+                         h->partials.p, h->opt_ablate, h->fold_reverse_now ? (const int*)h->ghost_root.p : (const int*)nullptr, src_p, box_p)
+#define HT(EVv, Gv, LIST, CNT) if(ev == EVv && gn == Gv && (CNT) > 0) { if(src_p) HTS(EVv, Gv, 1, LIST, CNT); else HTS(EVv, Gv, 0, LIST, CNT); }
 #define HT4(LIST, CNT) { HT(0, 0, LIST, CNT); HT(0, 1, LIST, CNT); HT(1, 0, LIST, CNT); HT(1, 1, LIST, CNT); }
     if(h->halo_pending) {
       // overlapped step (several ranks): interior tiles (no ghost among their candidates) run while the position halo is in
@@ -869,6 +887,7 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       HT4((const int*)nullptr, h->ntiles);
 #undef HT4
 #undef HT
+#undef HTS
   } else {
     MMD_TRY(mmd_ensure_rows(h));
     MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));     // ref/force_lj.cpp:286-291

@@ -325,6 +325,7 @@ struct mmd_handle {
 // ---- shared device/host helpers implemented across the .hip files
 int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve);
 int mmd_set_dummy(mmd_handle* h);
+int mmd_box_dev(mmd_handle* h);
 int mmd_borders_deferred_finish(mmd_handle* h);
 int mmd_borders_deferred_resolve(mmd_handle* h);
 int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host);   // in-place, returns total

@@ -1639,7 +1639,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     // then stage ghosts from their owners' current positions without a look-up: GhostResolve, tile_lds.hpp)
     int* cand_src_p = nullptr;
     h->cand_src_ready = false;
-    if(h->opt_build == 1 && h->opt_ghost_resolve && (h->style == 0 || h->eam_uniform) && !h->halfneigh && h->nprocs == 1 && !h->opt_force_transport && (h->nghost_dev != nullptr || h->ghost_chain_ok) &&
+    if(h->opt_build == 1 && h->opt_ghost_resolve && (h->style == 0 || (h->eam_uniform && !h->halfneigh)) && h->nprocs == 1 && !h->opt_force_transport && (h->nghost_dev != nullptr || h->ghost_chain_ok) &&
        !h->ghosts_uploaded && nlocal + h->nghost < (1 << MMD_SRC_BITS) && h->ghost_root.p != nullptr) {
       MMD_TRY(h->tile_cand_src.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
       cand_src_p = h->tile_cand_src.p;

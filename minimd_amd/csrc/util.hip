@@ -167,6 +167,17 @@ int mmd_prepare_x_alt(mmd_handle* h)
   return 0;
 }
 
+// the box lengths in device memory (ghost_shifted, tile_lds.hpp)
+int mmd_box_dev(mmd_handle* h)
+{
+  if(h->box_dev_valid) return 0;
+  MMD_TRY(h->box_dev.ensure(4, false, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->box_dev.p, h->prd, 3 * sizeof(real), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(mmd_stream_sync(h));
+  h->box_dev_valid = true;
+  return 0;
+}
+
 int mmd_set_dummy(mmd_handle* h)
 {
   hipLaunchKernelGGL(k_set_dummy, dim3(1), dim3(1), 0, h->stream, h->x.p, h->nlocal + h->nghost);

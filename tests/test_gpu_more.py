@@ -429,6 +429,30 @@ def test_ghosts_staged_from_their_owners_equal_the_ghost_update(args):
 
 
 @pytest.mark.parametrize("prec", ["dp", "sp"])
+@pytest.mark.parametrize("gn", [0, 1])
+@pytest.mark.parametrize("args", [["-s", 12], ["-s", 3], ["-nx", 2, "-ny", 5, "-nz", 3]])
+def test_half_list_ghosts_staged_from_their_owners(args, gn, prec):
+    """LJ over half lists on one rank: on steps without re-neighboring the tile kernel stages the ghosts from their owners (second candidate
+    list of the build: owner + image code) — no Comm::communicate launch; with ghost newton a ghost's share goes to its owner at the flush,
+    without it a ghost partner gets none and the pair counts half. Same sums in the same order as with the ghost update (ghost_resolve 0):
+    rows to 1e-10 (atomics: the order inside a launch is not fixed), positions of the owned atoms to 1e-9 after 60 steps."""
+    m = mm()
+    out = {}
+    for mode in (0, 1):
+        s = m.Sim(args + ["-n", 60, "--half_neigh", 1, "-gn", gn], precision=prec)
+        s.handle.set_option("ghost_resolve", mode)
+        s.initial(); s.run()
+        d = s.handle.download()
+        nl = s.handle.counts()[0]
+        out[mode] = (s.rows(), d["x"][:nl].copy(), d["f"][:nl].copy(), d["tag"].copy())
+        s.close()
+    tol = 1e-10 if prec == "dp" else 2e-5
+    rows_close(out[0][0], out[1][0], tol)
+    np.testing.assert_array_equal(out[0][3], out[1][3])
+    assert np.abs(out[0][1] - out[1][1]).max() <= (1e-9 if prec == "dp" else 1e-3)
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
 @pytest.mark.parametrize("args", [["-s", 10], ["-s", 4], ["-nx", 3, "-ny", 6, "-nz", 4]])
 def test_eam_ghosts_staged_from_their_owners_equal_the_halos(args, prec):
     """EAM over full lists on one rank: the build leaves the candidate lists a second time with every ghost named by its owner and image code,
