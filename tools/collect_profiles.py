@@ -76,10 +76,10 @@ N80, N64, N160, N32 = 2048000, 1048576, 16384000, 131072
 row("B LJ full -s 80 DP (fused integrator)", "k_lj_full_tile<0, false, 2, 8, 3, 1>", "kernel_stats_bench.md", N80, rf["bytes_per_atom"], "pmc_lj_full.txt", "k_lj_full_tile<0, false, 2, 8, 3, 1>", "the roofline kernel of bench.py")
 row("B LJ full -s 80 DP (force only)", "k_lj_full_tile<0, false, 2, 8, 3, 0>", "kernel_stats_bench.md", N80, rf["bytes_per_atom"], "pmc_lj_full.txt", "k_lj_full_tile<0, false, 2, 8, 3, 0>", "kernel-only launches (mmd_profile_kernel)")
 row("A LJ full -s 32 DP", "k_lj_full_tile<0, false, 2, 8, 3, 1>", "kernel_stats_A.md", N32, 4 * 76.3 + 60 + 0.365 * 28, note="2 081 pencil tiles: less than one full wave of workgroups")
-row("B' LJ half -s 80 DP", "k_lj_half_tile<0, 1>", "kernel_stats_Bh.md", N80, 269, "pmc_lj_half.txt", "k_lj_half_tile<0, 1>", "LDS + L2 atomics, not HBM, bound it")
-row("C EAM -s 64 DP: density sweep", "k_eam_density_tile<0, 0>", "kernel_stats_C.md", N64, 4 * 60.25 + 4 + 28 + 8 + 0.167 * 28, "pmc_eam.txt", "k_eam_density_tile<0, 0>", "")
-row("C EAM -s 64 DP: force sweep (fused integrator)", "k_eam_force_tile<0, 1, 0>", "kernel_stats_C.md", N64, 4 * 60.25 + 4 + 28 + 8 + 24 + 0.167 * 8, "pmc_eam.txt", "k_eam_force_tile<0, 1, 0>", "both sweeps + fp halo: 592 B/atom; rows in two parts, core part on 18 of 20 steps")
-row("E LJ half -s 160 SP", "k_lj_half_tile<0, 1>", "kernel_stats_E.md", N160, 211, note="")
+row("B' LJ half -s 80 DP", "k_lj_half_tile<0, 1", "kernel_stats_Bh.md", N80, 269, "pmc_lj_half.txt", "k_lj_half_tile<0, 1", "LDS + L2 atomics, not HBM, bound it")
+row("C EAM -s 64 DP: density sweep", "k_eam_density_tile<0, 0", "kernel_stats_C.md", N64, 4 * 60.25 + 4 + 28 + 8 + 0.167 * 28, "pmc_eam.txt", "k_eam_density_tile<0, 0", "")
+row("C EAM -s 64 DP: force sweep (fused integrator)", "k_eam_force_tile<0, 1, 0", "kernel_stats_C.md", N64, 4 * 60.25 + 4 + 28 + 8 + 24 + 0.167 * 8, "pmc_eam.txt", "k_eam_force_tile<0, 1, 0", "both sweeps + fp halo: 592 B/atom; rows in two parts, core part on 18 of 20 steps")
+row("E LJ half -s 160 SP", "k_lj_half_tile<0, 1", "kernel_stats_E.md", N160, 211, note="")
 row("Neighbor build -s 80 DP (per rebuild)", "k_build_rows<0, 0>", "kernel_stats_bench.md", N80, 347, "pmc_build.txt", "k_build_rows<0, 0>", "instruction-issue bound (%s VALU + %s SALU + %s LDS wave-instructions per launch)" % tuple(
         ("%.2e" % v) if v else "?" for v in (pmc("pmc_build.txt", "k_build_rows<0, 0>", "SQ_INSTS_VALU"), pmc("pmc_build.txt", "k_build_rows<0, 0>", "SQ_INSTS_SALU"),
                                              pmc("pmc_build.txt", "k_build_rows<0, 0>", "SQ_INSTS_LDS"))))
