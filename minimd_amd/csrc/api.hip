@@ -61,7 +61,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->type.release(); h->type_alt.release(); h->tag.release(); h->tag_alt.release();
   h->bin_count.release(); h->bin_start.release(); h->binned.release(); h->scan_tmp.release(); h->atom_bin.release(); h->atom_rank.release();
   h->neigh.release(); h->numneigh.release(); h->wave_max.release(); h->ghost_image.release(); h->ghost_root.release();
-  h->tile_of_block.release(); h->pencil_range.release(); h->tile_block.release(); h->tile_first.release(); h->tile_max.release();
+  h->tile_of_block.release(); h->pencil_range.release(); h->pencil_lohi.release(); h->tile_block.release(); h->tile_first.release(); h->tile_max.release();
   h->tile_cand.release(); h->tile_cand_src.release(); h->box_dev.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
   for(auto& s : h->swaps) s.sendlist.release();
@@ -117,6 +117,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
   else if(!strcmp(name, "spin_readback")) h->opt_spin_readback = value;
   else if(!strcmp(name, "spec")) h->opt_spec = value;
+  else if(!strcmp(name, "fold_pencil")) h->opt_fold_pencil = value;
   else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) {

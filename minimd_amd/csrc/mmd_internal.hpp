@@ -160,6 +160,9 @@ struct mmd_handle {
   bool rows_ready = false;               // the wave-interleaved 32-bit rows (`neigh`, wave_max) are materialised
   int ntiles = 0, tile_tmax = 0;          // tile_tmax: largest candidate count of any block (LDS sizing)
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
+  DevArr<unsigned> pencil_lohi;           // per pencil: first / last (+1) bin holding an owned atom, collected by k_bin_sort when a build asks for it
+  bool pencil_lohi_req = false, pencil_lohi_ready = false;
+  int opt_fold_pencil = 1;
   DevArr<int> pencil_range;               // per pencil (row of blocks along x): [first, last) entry of binned[] between its first and last owned bin
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
   DevArr<int> tile_cand_src;              // one-rank runs: tile_cand with every ghost named by its owner + image code (GhostResolve, tile_lds.hpp)

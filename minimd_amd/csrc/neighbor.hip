@@ -201,11 +201,14 @@ __global__ __launch_bounds__(256) void k_bin_count(real4* __restrict__ x, int n,
 }
 
 __global__ void k_bin_fill(const int* __restrict__ atom_bin, const int* __restrict__ atom_rank, int n, const int* __restrict__ bin_start,
-                           int* __restrict__ binned, int* __restrict__ big_flag, int nlocal, const int* __restrict__ nghost_dev)
+                           int* __restrict__ binned, int* __restrict__ big_flag, int nlocal, const int* __restrict__ nghost_dev,
+                           unsigned* __restrict__ pencil_lohi, int npencils)
 {
   n = deferred_count(n, nlocal, nghost_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i == 0) *big_flag = 0;                                    // (set by k_bin_sort, the next kernel on the stream)
+  // (first / last owned bin of every pencil: collected by k_bin_sort, the next kernel on the stream — see there)
+  if(pencil_lohi != nullptr) for(int q = i; q < 2 * npencils; q += gridDim.x * blockDim.x) pencil_lohi[q] = (q & 1) ? 0u : 0xffffffffu;
   if(i >= n) return;
   binned[bin_start[atom_bin[i]] + atom_rank[i]] = i;
 }
@@ -213,21 +216,37 @@ __global__ void k_bin_fill(const int* __restrict__ atom_bin, const int* __restri
 // one thread per bin: insertion sort of its (short) slice -> ascending atom index, run-to-run identical.
 // Bins longer than NB_BIGBIN (e.g. `-b 1`: every atom in one bin) are left to k_bin_sort_big.
 #define NB_BIGBIN 96
+// pencil_lohi != nullptr (the binning of a neighbor build inside a run): the pass also collects, per pencil (row of blocks along x = bins_per_pencil
+// consecutive bins), the first and the last bin (+1) that holds an owned atom — what k_pencil_count used to find in a launch of its own. A wavefront's 64
+// bins nearly always lie in one pencil: it reduces them and issues ONE atomic pair (1 k atomics on the same two words retire one at a time).
 __global__ void k_bin_sort(const int* __restrict__ bin_start, int mbins, int* __restrict__ binned, int* __restrict__ big_flag,
-                           int* __restrict__ bin_count)
+                           int* __restrict__ bin_count, unsigned* __restrict__ pencil_lohi, int bins_per_pencil, int nlocal)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if(b > mbins) return;
-  bin_count[b] = 0;                                           // the histogram has been scanned: leave it zeroed for the next binning
-  if(b == mbins) return;
-  const int s = bin_start[b], e = bin_start[b + 1];
-  if(e - s > NB_BIGBIN) { *big_flag = 1; return; }
-  for(int a = s + 1; a < e; a++) {
-    const int key = binned[a];
-    int c = a - 1;
-    while(c >= s && binned[c] > key) { binned[c + 1] = binned[c]; c--; }
-    binned[c + 1] = key;
+  bool owned = false;
+  if(b <= mbins) bin_count[b] = 0;                            // the histogram has been scanned: leave it zeroed for the next binning
+  if(b < mbins) {
+    const int s = bin_start[b], e = bin_start[b + 1];
+    if(e - s > NB_BIGBIN) *big_flag = 1;                      // (left to k_bin_rank_big; the build is redone with that pass switched on)
+    else {
+      for(int a = s + 1; a < e; a++) {
+        const int key = binned[a];
+        int c = a - 1;
+        while(c >= s && binned[c] > key) { binned[c + 1] = binned[c]; c--; }
+        binned[c + 1] = key;
+      }
+      owned = e > s && binned[s] < nlocal;                    // (a bin's entries ascend now: owned atoms first)
+    }
   }
+  if(pencil_lohi == nullptr) return;
+  const int p = b < mbins ? b / bins_per_pencil : -1, q = b < mbins ? b - p * bins_per_pencil : 0;
+  const int p0 = __builtin_amdgcn_readfirstlane(p);
+  const bool uniform = __builtin_amdgcn_ballot_w64(p != p0) == 0ull;
+  if(uniform) {
+    if(p0 < 0) return;
+    const unsigned lo = wave_min_u(owned ? (unsigned)q : 0xffffffffu), hi = wave_max_u(owned ? (unsigned)q + 1u : 0u);
+    if((threadIdx.x & 63) == 0 && hi > 0u) { atomicMin(&pencil_lohi[2 * p0], lo); atomicMax(&pencil_lohi[2 * p0 + 1], hi); }
+  } else if(owned) { atomicMin(&pencil_lohi[2 * p], (unsigned)q); atomicMax(&pencil_lohi[2 * p + 1], (unsigned)q + 1u); }
 }
 // long bins: every entry finds its rank by counting the smaller entries of its bin (O(n^2) compares spread over the whole
 // grid instead of one thread's insertion sort); `scratch` holds as many ints as `binned`; a second launch copies the
@@ -277,8 +296,19 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   if(n && h->clk_slot >= 0) { h->clk_written |= 1 << h->clk_slot; h->clk_slot = -1; }
   h->pbc_pending = false;
   MMD_TRY(mmd_exclusive_scan_from(h, h->bin_count.p, h->bin_start.p, g.mbins, nullptr));
-  hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n > 0 ? n : 1, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p, h->d_flags + 12, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr);
-  hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins + 1, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->d_flags + 12, h->bin_count.p);
+  // (a neighbor build that folds k_pencil_count into this pass asked for it: pencil_lohi_req, cleared here)
+  unsigned* lohi = nullptr;
+  const int npencils = g.nblk[1] * g.nblk[2];
+  if(h->pencil_lohi_req && count < 0 && !h->big_bins) {
+    MMD_TRY(h->pencil_lohi.ensure((size_t)2 * npencils + 2, false, h->stream));
+    lohi = h->pencil_lohi.p;
+  }
+  h->pencil_lohi_req = false;
+  h->pencil_lohi_ready = lohi != nullptr;
+  hipLaunchKernelGGL(k_bin_fill, dim3(div_up(n > 0 ? n : 1, 256)), dim3(256), 0, h->stream, h->atom_bin.p, h->atom_rank.p, n, h->bin_start.p, h->binned.p, h->d_flags + 12, h->nlocal, count < 0 ? h->nghost_dev : (const int*)nullptr,
+                     lohi, npencils);
+  hipLaunchKernelGGL(k_bin_sort, dim3(div_up(g.mbins + 1, 256)), dim3(256), 0, h->stream, h->bin_start.p, g.mbins, h->binned.p, h->d_flags + 12, h->bin_count.p,
+                     lohi, g.nblk[0] * NB_SUB, h->nlocal);
   // bins longer than NB_BIGBIN are ordered by the grid-wide rank count (atom_bin is free again after the fill: its scratch).
   // The two launches are skipped while no such bin has been seen: the neighbor build reads the flag k_bin_sort raises
   // (with its own result flags) and then switches them on and bins again.
@@ -526,21 +556,40 @@ __global__ void k_pencil_fill(const int* __restrict__ pencil_range, int npencils
 
 // the same with the scan of the per-pencil tile counts folded in (re-neighborings inside a run, where nobody needs the count on the host before the
 // build has run): every workgroup sums the counts in front of it itself, the last one stores the total behind the counts (ntiles_dev of the build)
+// pencil_lohi != nullptr: no k_pencil_count ran — every pencil's entry range and tile count come from the first / last owned bin k_bin_sort collected
 __global__ __launch_bounds__(256) void k_pencil_fill_scan(const int* __restrict__ pencil_range, int npencils, int nblk0, int* __restrict__ ntile_of_pencil,
                                                           int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags,
-                                                          int cap, real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev)
+                                                          int cap, real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev,
+                                                          const unsigned* __restrict__ pencil_lohi, const int* __restrict__ bin_start)
 {
   __shared__ int lds[17];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if(p == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[7] = 0; }
   if(p == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};    // the dummy atom, see k_tile_fill
-  const int before = block_prefix_total(ntile_of_pencil, blockIdx.x * 256, lds);
-  const int mine = p < npencils ? ntile_of_pencil[p] : 0;
+  auto range_of = [&](int pp, int& a0, int& a1) {
+    a0 = 0; a1 = 0;
+    if(pencil_lohi != nullptr) {
+      const unsigned lo = pencil_lohi[2 * pp], hi = pencil_lohi[2 * pp + 1];
+      const int b0 = pp * nblk0 * NB_SUB;
+      if(hi > 0u) { a0 = bin_start[b0 + (int)lo]; a1 = bin_start[b0 + (int)hi]; }
+    } else { a0 = pencil_range[2 * pp]; a1 = pencil_range[2 * pp + 1]; }
+  };
+  int before;
+  if(pencil_lohi != nullptr) {
+    int v = 0;
+    for(int t = threadIdx.x; t < (int)blockIdx.x * 256; t += 256) { int a0, a1; range_of(t, a0, a1); v += (a1 - a0 + 63) >> 6; }
+    int tot0;
+    block_incl_scan(v, lds, &tot0);
+    before = tot0;
+  } else before = block_prefix_total(ntile_of_pencil, blockIdx.x * 256, lds);
+  int ma0 = 0, ma1 = 0;
+  if(p < npencils) range_of(p, ma0, ma1);
+  const int mine = p < npencils ? (pencil_lohi != nullptr ? (ma1 - ma0 + 63) >> 6 : ntile_of_pencil[p]) : 0;
   int tot;
   const int inc = block_incl_scan(mine, lds, &tot);
   const int t0 = before + inc - mine, t1 = t0 + mine;
   if(p < npencils) {
-    const int a0 = pencil_range[2 * p], a1 = pencil_range[2 * p + 1];
+    const int a0 = ma0, a1 = ma1;
     for(int t = t0; t < t1 && t < cap; t++) {
       tile_block[t] = p * nblk0;
       tile_first[t] = a0 + (t - t0) * 64;
@@ -1516,9 +1565,28 @@ int mmd_ensure_rows(mmd_handle* h)
 // what that launch was sized for. Word 15 of the flags, published with the others.
 struct BuildVerdict { int on, maxneighs, ntiles_cap, nt_async, cmax, has_bst, est_nb, big_bins, core_rows; };
 #define NB_GATE_WORD 15
-__global__ __launch_bounds__(64) void k_publish_flags(int* __restrict__ src, int* __restrict__ dst, int n, int seq, BuildVerdict V)
+// Small systems (<= 4096 tiles): this one wavefront also does k_tile_reduce's work (one dependent launch less in a window that is nothing but
+// dependent 5 us launches; the words it accumulates into were zeroed by k_pencil_fill_scan)
+struct TileReduceArgs { int on; const int* rowmax; const int* rowsum; const int* ncand; int ntiles; const int* ntiles_dev; const int* bst; };
+__global__ __launch_bounds__(64) void k_publish_flags(int* __restrict__ src, int* __restrict__ dst, int n, int seq, BuildVerdict V, TileReduceArgs R)
 {
   const int t = threadIdx.x;
+  if(R.on) {
+    int nt = R.ntiles;
+    if(R.ntiles_dev) nt = min(nt, *R.ntiles_dev);
+    if(t == 0) *(long long*)(src + 60) = wall_clock64();                     // end of the build phase (see k_bin_count)
+    if(R.bst && t < 40) src[16 + t] = R.bst[t];                              // deferred one-rank borders: its counts travel with the flags
+    int a = 0, b = 0;
+    long long c = 0;
+    for(int q = t; q < nt; q += 64) { a = max(a, R.rowmax[q]); b = max(b, R.ncand[q]); c += R.rowsum[q]; }
+    a = wave_max_i(a); b = wave_max_i(b); c = wave_sum(c);
+    if(t == 0) {
+      if(R.ntiles_dev) src[6] = *R.ntiles_dev;
+      src[0] = max(src[0], a); src[2] = max(src[2], b);
+      *(unsigned long long*)(src + 4) += (unsigned long long)c;
+    }
+    __syncthreads();
+  }
   if(V.on && t == 0) {
     const int maxn = src[0], need = V.core_rows ? max(maxn, src[7]) : maxn;
     bool ok = !(maxn >= V.maxneighs || need > V.maxneighs) && src[3] == 0 && !(src[12] != 0 && !V.big_bins) && src[2] <= V.cmax;
@@ -1534,11 +1602,11 @@ __global__ __launch_bounds__(64) void k_publish_flags(int* __restrict__ src, int
 }
 // (Publishing from the last workgroup of k_tile_reduce instead — one launch less — was built and measured: the 1024-thread workgroup's system-scope
 //  fence makes that kernel 14 instead of 6 us and bench.py --size 32 loses 2.7 %: 4480 against 4600 Matom-steps/s. A one-wavefront kernel it stays.)
-static int flags_publish(mmd_handle* h, int n, const BuildVerdict& V)
+static int flags_publish(mmd_handle* h, int n, const BuildVerdict& V, const TileReduceArgs& R)
 {
   if(!h->h_flags_dev) HIP_TRY(hipHostGetDevicePointer((void**)&h->h_flags_dev, h->h_flags, 0));
   const int seq = ++h->flag_seq;
-  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, h->stream, h->d_flags, h->h_flags_dev, n, seq, V);
+  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, h->stream, h->d_flags, h->h_flags_dev, n, seq, V, R);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1572,6 +1640,8 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   const int nlocal = h->nlocal, nall = h->nlocal + h->nghost;
   const int nwaves = div_up(nlocal, 64);
   const BinGeom& g = h->bg;
+  // (re-neighborings inside a run with the production build: the binning pass also collects what k_pencil_count would — one dependent launch less)
+  h->pencil_lohi_req = h->opt_tiles && nlocal > 0 && h->opt_build == 1 && h->opt_async_counts && h->ntiles_hint > 0 && h->opt_fold_pencil;
   MMD_TRY(mmd_bin_atoms(h, -1));
   MMD_TRY(h->numneigh.ensure((size_t)nlocal + 64, false, h->stream));
   const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
@@ -1586,9 +1656,11 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     const bool pencil = h->opt_build == 1;
     const int nunits = pencil ? g.nblk[1] * g.nblk[2] : nblocks;
     MMD_TRY(h->tile_of_block.ensure((size_t)nblocks + 2, false, h->stream));
+    const bool lohi = pencil && h->pencil_lohi_ready && h->opt_async_counts && h->ntiles_hint > 0;           // (k_bin_sort collected the pencils' owned bins: no k_pencil_count)
+    h->pencil_lohi_ready = false;
     if(pencil) {
       MMD_TRY(h->pencil_range.ensure((size_t)2 * nunits + 2, false, h->stream));
-      hipLaunchKernelGGL(k_pencil_count, dim3(nunits), dim3(64), 0, h->stream, h->binned.p, h->bin_start.p, nunits, g.nblk[0], nlocal, h->tile_of_block.p, h->pencil_range.p);
+      if(!lohi) hipLaunchKernelGGL(k_pencil_count, dim3(nunits), dim3(64), 0, h->stream, h->binned.p, h->bin_start.p, nunits, g.nblk[0], nlocal, h->tile_of_block.p, h->pencil_range.p);
     } else
     hipLaunchKernelGGL(k_tile_count, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->binned.p, h->bin_start.p, nblocks, nlocal, h->tile_of_block.p);
     // the tile count sizes the lists. Once a build has succeeded the previous count (+3 %) does that and the count itself
@@ -1646,7 +1718,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     }
     if(fill_scans)
       hipLaunchKernelGGL(k_pencil_fill_scan, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
-                         h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev);
+                         h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev, lohi ? (const unsigned*)h->pencil_lohi.p : (const unsigned*)nullptr, (const int*)h->bin_start.p);
     else if(pencil)
       hipLaunchKernelGGL(k_pencil_fill, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
                          h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev);
@@ -1654,7 +1726,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags, nt,
                        h->x.p, nlocal, h->nghost, h->nghost_dev);
     HIP_TRY(hipGetLastError());
-    bool order_here = false;
+    bool order_here = false, reduce_in_publish = false;
     for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
       MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 16 * 64, false, h->stream));   // (+ prefetch overrun of the last tile)
       if(h->opt_build == 1 && attempt > 0) HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));     // (a relaunch with longer rows: k_pencil_fill's zeroes are used up)
@@ -1679,6 +1751,8 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
                      core_thr, h->xbuild.p, h->tile_kcore.p, cand_src_p, (const int*)h->ghost_root.p)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
+        reduce_in_publish = h->opt_spin_readback && h->in_run && h->ntiles <= 4096;
+        if(!reduce_in_publish)
         hipLaunchKernelGGL(k_tile_reduce, dim3(std::min(32, std::max(1, div_up(h->ntiles, 1024)))), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
                            h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr);
         order_here = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport || h->opt_overlap >= 2) && h->ntiles > 0;
@@ -1722,7 +1796,9 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
           if(!spec) { h->tile_cmax = save_cmax; h->tiles_ready = false; h->neigh_nlocal = 0; }
         }
         if(spec) V = BuildVerdict{1, h->maxneighs, h->ntiles, 1, spec_cmax, h->nghost_dev != nullptr ? 1 : 0, h->bf_est_nb, h->big_bins ? 1 : 0, core_rows ? 1 : 0};
-        MMD_TRY(flags_publish(h, 62, V));
+        TileReduceArgs R{};
+        if(reduce_in_publish) R = TileReduceArgs{1, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles, nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr};
+        MMD_TRY(flags_publish(h, 62, V, R));
         if(spec) {
           h->spec = SpecLaunch{h->d_flags + NB_GATE_WORD, nt_dev, h->nghost_dev};
           h->spec_fused = false;
