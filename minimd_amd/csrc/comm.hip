@@ -1578,6 +1578,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
     if(rc >= 1) {
       h->neigh_nlocal = 0;
       h->tiles_ready = false;
+      h->cand_src_ready = false;
       return 0;
     }
     h->nghost = 0;
@@ -1710,6 +1711,7 @@ static int borders_general(mmd_handle* h)
   h->borders_general_runs++;
   h->neigh_nlocal = 0;                 // any existing neighbor list is stale now
   h->tiles_ready = false;
+  h->cand_src_ready = false;
   return 0;
 }
 

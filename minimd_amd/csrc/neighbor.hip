@@ -1646,6 +1646,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   MMD_TRY(h->numneigh.ensure((size_t)nlocal + 64, false, h->stream));
   const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
   h->tiles_ready = false;
+  h->cand_src_ready = false;
   h->rows_ready = false;
   h->rows_uploaded = false;
   h->neigh_nlocal = 0;
@@ -2259,6 +2260,7 @@ __global__ __launch_bounds__(64) void k_rows_to_tiles(const real4* __restrict__ 
 static int tiles_from_rows(mmd_handle* h)
 {
   h->tiles_ready = false;
+  h->cand_src_ready = false;
   const int nlocal = h->nlocal, nall = h->nlocal + h->nghost;
   if(!h->opt_tiles || !h->opt_upload_tiles || !h->neigh_ready || nlocal == 0 || h->opt_build != 1) return 0;
   const BinGeom& g = h->bg;
