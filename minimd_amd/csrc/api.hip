@@ -35,12 +35,20 @@ extern "C" int mmd_create(int device, mmd_handle** out)
   h->device = device;
   HIP_TRY(hipGetDeviceProperties(&h->prop, device));
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  {
+    // the communication stream carries a step's halo (pack, RCCL p2p kernel, unpack: a few workgroups) while the compute stream floods the CUs with the
+    // interior tiles: at the highest priority its workgroups are dispatched as soon as slots free up instead of queueing behind 30 k tiles
+    int lo_p = 0, hi_p = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+    HIP_TRY(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi_p));
+  }
   HIP_TRY(hipHostMalloc((void**)&h->h_result, 32 * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&h->d_result, 32 * sizeof(double)));
   HIP_TRY(hipHostMalloc((void**)&h->h_flags, 64 * sizeof(int), hipHostMallocDefault));
   { int khz = 0; if(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) == hipSuccess && khz > 0) h->clk_rate_hz = 1.0e3 * khz; (void)hipGetLastError(); }
   HIP_TRY(hipHostMalloc((void**)&h->h_flags_big, 64 * sizeof(int), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&h->dh.h_counts, 32 * 30 * sizeof(int), hipHostMallocDefault));
+  memset(h->dh.h_counts, 0, 32 * 30 * sizeof(int));
   HIP_TRY(hipMalloc((void**)&h->d_flags, 64 * sizeof(int)));
   HIP_TRY(hipMemset(h->d_result, 0, 32 * sizeof(double)));
   HIP_TRY(hipMemset(h->d_flags, 0, 64 * sizeof(int)));
@@ -73,6 +81,8 @@ extern "C" int mmd_destroy(mmd_handle* h)
   if(h->d_result) (void)hipFree(h->d_result);
   if(h->h_flags) (void)hipHostFree(h->h_flags);
   if(h->h_flags_big) (void)hipHostFree(h->h_flags_big);
+  if(h->dh.h_counts) (void)hipHostFree(h->dh.h_counts);
+  h->dh.idx.release(); h->dh.counts.release(); h->dh.scratch.release();
   if(h->d_flags) (void)hipFree(h->d_flags);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   if(h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
@@ -118,6 +128,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "spin_readback")) h->opt_spin_readback = value;
   else if(!strcmp(name, "spec")) h->opt_spec = value;
   else if(!strcmp(name, "fold_pencil")) h->opt_fold_pencil = value;
+  else if(!strcmp(name, "direct_halo")) h->dh.opt = value;
   else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) {
@@ -160,6 +171,31 @@ static int ev_end(mmd_handle* h)
   h->ev_used++;
   return 0;
 }
+// the bracket around the two force launches of an overlapped step stays open while the step's halo (with its own pair) is enqueued: a pair of its own,
+// read when the next one is about to be recorded (four steps later: long complete) or at the end of the run
+static int ovf_harvest(mmd_handle* h)
+{
+  if(!h->ovf_open) return 0;
+  HIP_TRY(hipEventSynchronize(h->ovf_b));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ovf_a, h->ovf_b));
+  h->force_ms_all += ms; h->force_launches_all++;
+  h->ovf_open = false;
+  return 0;
+}
+static int ovf_begin(mmd_handle* h)
+{
+  MMD_TRY(ovf_harvest(h));
+  if(!h->ovf_a) { HIP_TRY(hipEventCreate(&h->ovf_a)); HIP_TRY(hipEventCreate(&h->ovf_b)); }
+  HIP_TRY(hipEventRecord(h->ovf_a, h->stream));
+  return 0;
+}
+static int ovf_end(mmd_handle* h)
+{
+  HIP_TRY(hipEventRecord(h->ovf_b, h->stream));
+  h->ovf_open = true;
+  return 0;
+}
 // kinds 2 / 3: the Comm (exchange + sort + borders) and Neighbor::build phases of a re-neighboring (TIME_COMM + TIME_TEST / TIME_NEIGH).
 // sync = false collects only the pairs that have already completed (no host wait) and keeps the others in the pool.
 static int ev_collect(mmd_handle* h, bool sync = true)
@@ -179,7 +215,8 @@ static int ev_collect(mmd_handle* h, bool sync = true)
     HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
     switch(h->ev_pool[i].kind) {
       case 0: h->force_ms += ms; h->force_launches++; break;
-      case 4: h->force_ms_all += ms; h->force_launches_all++; break;      // Force::compute calls that are timed EVERY time (overlapped steps)
+      case 4: h->force_ms_all += ms; h->force_launches_all++; break;      // Force::compute of overlapped steps (its two launches bracketed; every 4th such step)
+      case 5: h->halo_ms += ms; break;                                    // forward halo of a step (every 4th step: an event pair costs the stream two marker packets)
       case 1: h->comm_ms += ms; break;
       case 2: h->timer[1] += ms * 1e-3; h->timer[4] += ms * 1e-3; break;     // ref/integrate.cpp:155-166
       default: h->timer[3] += ms * 1e-3; break;
@@ -244,7 +281,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   HIP_TRY(hipSetDevice(h->device));
   for(int i = 0; i < 5; i++) h->timer[i] = 0;
   h->force_ms = 0; h->comm_ms = 0; h->force_launches = 0; h->force_calls = 0; h->ev_used = 0;
-  h->force_ms_all = 0; h->force_launches_all = 0;
+  h->force_ms_all = 0; h->force_launches_all = 0; h->halo_ms = 0;
+  long long halo_calls = 0, halo_timed = 0, ovf_calls = 0;
   h->host_syncs = 0; h->halo_bytes = 0; h->transport_syncs = 0;
   // the step loop steers the kernels through transient flags of the handle; whatever way this function is left (an overflowing
   // build, a transport error), they are cleared, so a later call on the same handle never waits on a stale event or skips a halo
@@ -255,6 +293,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       h->halo_pending = false; h->in_reneighbor = false; h->pbc_defer = false; h->launch_ev_a = h->launch_ev_b = nullptr;
       h->in_run = false;
       h->spec_fn = nullptr; h->spec = SpecLaunch{nullptr, nullptr, nullptr}; h->spec_done = false;
+      h->ovf_open = false;
     }
   } transient_guard{h};
   h->in_run = true;
@@ -272,7 +311,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   bool initial_done = false;        // initialIntegrate of this step already ran fused with the previous finalIntegrate
   // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
   const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport || h->opt_overlap >= 2);     // (2: also on one rank — the ghost update under the interior tiles)
-  bool halo_pending = false, collect_pending = false;
+  bool halo_pending = false, collect_pending = false, ovf_timed_now = false;
   int core_next = 0;                 // CoreRows: what the next force call may assume about the displacement since the build
   // the per-step halos are timed (into TIME_COMM) only where they are more than one tiny kernel: an event pair costs the stream
   // two markers, ~5 us per step that a -s 32 run would notice
@@ -327,23 +366,35 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       if(overlap && (h->style == 0 ? (mmd_lj_tiles_available(h) || mmd_lj_half_tiles_available(h)) : mmd_eam_can_fuse_integrate(h))) {
         // halo of this step on the communication stream, interior tiles (no ghost among their candidates)
         // concurrently on the compute stream
+        // (the clocks of such a step — halo on its stream, the two force launches on theirs — are read on every 4th one: each event pair costs its stream
+        //  two marker packets, ~5 us of idle GPU apiece, and a step has two pairs)
+        const bool timed_step = time_halo && (halo_calls % 4 == 0);
+        halo_calls++;
+        if(timed_step) halo_timed++;
         HIP_TRY(hipEventRecord(h->ev_x_ready, h->stream));
         HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_x_ready, 0));
-        std::swap(h->stream, h->comm_stream);
-        int rc = time_halo ? ev_begin(h, 1) : 0;
-        if(rc >= 0) rc = mmd_comm_communicate(h);
-        if(rc >= 0 && time_halo) rc = ev_end(h);
-        std::swap(h->stream, h->comm_stream);
-        MMD_TRY(rc);
-        HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
-        if(h->style == 0 && !h->halfneigh) {
-          if(h->time_force_events) MMD_TRY(ev_begin(h, 4));       // (its two launches are bracketed on every step: not part of the sampled subset)
+        const bool lj_full = h->style == 0 && !h->halfneigh;
+        ovf_timed_now = false;
+        if(lj_full) {
+          // the interior tiles go onto the compute stream FIRST: enqueuing the halo (an ncclGroup costs the host ~15 us) must not hold them up
+          ovf_calls++;
+          ovf_timed_now = h->time_force_events && timed_step;
+          if(ovf_timed_now) MMD_TRY(ovf_begin(h));
           fused_force = fuse_force && !ev_now && n + 1 < ntimes && mmd_lj_can_fuse_integrate(h);
           if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
           h->fuse_now = fused_force;
           const int rc0 = mmd_lj_compute_tiles_split(h, ev_now, 0);
           h->fuse_now = 0;
           MMD_TRY(rc0);
+        }
+        std::swap(h->stream, h->comm_stream);
+        int rc = timed_step ? ev_begin(h, 5) : 0;
+        if(rc >= 0) rc = mmd_comm_communicate(h);
+        if(rc >= 0 && timed_step) rc = ev_end(h);
+        std::swap(h->stream, h->comm_stream);
+        MMD_TRY(rc);
+        HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
+        if(lj_full) {
           halo_pending = true;
           evflag_pending = ev_now;
         } else
@@ -355,9 +406,11 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       } else if(resolve_half && h->ghost_chain_ok && h->cand_src_ready && mmd_lj_half_tiles_available(h)) {
         h->ghosts_stale = true;                  // (the half-list tile kernel stages the ghosts from their owners; their shares go to the owners)
       } else {
-        if(time_halo) MMD_TRY(ev_begin(h, 1));
+        const bool timed_step = time_halo && (halo_calls % 4 == 0);
+        halo_calls++;
+        if(timed_step) { halo_timed++; MMD_TRY(ev_begin(h, 5)); }
         MMD_TRY(mmd_comm_communicate(h));
-        if(time_halo) MMD_TRY(ev_end(h));
+        if(timed_step) MMD_TRY(ev_end(h));
       }
     } else {
       h->ghosts_stale = false;                   // (borders rebuilds every ghost)
@@ -428,7 +481,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       const int rc1 = mmd_lj_compute_tiles_split(h, evflag_pending, 1);
       h->fuse_now = 0;
       MMD_TRY(rc1);
-      if(h->time_force_events) MMD_TRY(ev_end(h));
+      if(ovf_timed_now) MMD_TRY(ovf_end(h));
+      ovf_timed_now = false;
       halo_pending = false;
     } else if(h->spec_done) {
       h->spec_done = false;                        // (the neighbor build issued this step's launch behind its own kernels, and its verdict let it run)
@@ -462,12 +516,14 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   }
   if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }     // leave x consistent for the caller
   MMD_TRY(ev_collect(h));
+  MMD_TRY(ovf_harvest(h));
   h->timer[0] = mmd_wall() - t_start;
   // TIME_FORCE: GPU time between the events around Force::compute (scaled from the sampled calls to all of them)
   // force_calls / force_launches count the SAMPLED path only (force_compute_async); calls that are bracketed every time add their time as it is
   h->timer[2] = h->force_ms * 1e-3 * (h->force_launches > 0 && h->force_calls > h->force_launches ? (double)h->force_calls / h->force_launches : 1.0) +
-                h->force_ms_all * 1e-3;
-  h->timer[1] += h->comm_ms * 1e-3;          // TIME_COMM also counts the per-step halos (GPU time between their events)
+                h->force_ms_all * 1e-3 * (h->force_launches_all > 0 && ovf_calls > h->force_launches_all ? (double)ovf_calls / h->force_launches_all : 1.0);
+  // TIME_COMM also counts the per-step halos (GPU time between their events; the forward halos scaled from the sampled steps to all of them)
+  h->timer[1] += h->comm_ms * 1e-3 + h->halo_ms * 1e-3 * (halo_timed > 0 ? (double)halo_calls / (double)halo_timed : 1.0);
   return 0;
 }
 

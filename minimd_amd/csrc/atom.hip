@@ -209,6 +209,7 @@ extern "C" int mmd_atom_sort(mmd_handle* h)
   std::swap(h->type, h->type_alt);
   std::swap(h->tag, h->tag_alt);
   h->neigh_nlocal = 0;            // atom indices changed: any neighbor list is stale
+  h->dh.ready = false;
   h->tiles_ready = false;
   h->cand_src_ready = false;
   return 0;

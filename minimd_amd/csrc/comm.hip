@@ -425,6 +425,7 @@ extern "C" int mmd_comm_communicate(mmd_handle* h)
     HIP_TRY(hipGetLastError());
     return 0;
   }
+  if(h->dh.ready) return mmd_dh_exchange(h, 0);           // one exchange with the up to 26 neighbours (DirectHalo, mmd_internal.hpp)
   // swap by swap (later dimensions forward ghosts received by earlier ones); the two swaps of one dimension are
   // independent of each other, so with RCCL they share one ncclGroup: 3 instead of 6 p2p rounds per step
   const size_t nsw = h->swaps.size();
@@ -788,6 +789,7 @@ extern "C" int mmd_comm_exchange(mmd_handle* h)
   HIP_TRY(hipSetDevice(h->device));
   MMD_TRY(mmd_atom_pbc(h));
   h->nghost = 0;                       // ghost slots are reused by arrivals; borders() rebuilds them next
+  h->dh.ready = false; h->dh.pending = false;
   int d_first = 0;                     // (> 0: the handshake-free path stopped at an overflowing dimension; finish from there)
   {
     const int rc = exchange_multi_fast(h, &d_first);
@@ -1396,6 +1398,299 @@ __global__ __launch_bounds__(256) void k_brd_scatter(real4* __restrict__ x, int 
   });
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Direct halo (DirectHalo, mmd_internal.hpp): Comm::communicate of a step on several ranks as ONE exchange.
+// ---------------------------------------------------------------------------------------------------
+// the 26 send lists of this rank, end to end in list order: owned atoms inside all slabs of the list, ascending (k_brd_count / k_brd_scan went before)
+__global__ __launch_bounds__(256) void k_dh_lists(int nlocal, const unsigned char* __restrict__ bits, const int* __restrict__ cnt, int nblk,
+                                                  const int* __restrict__ tot, int* __restrict__ idx, int* __restrict__ counts)
+{
+  __shared__ int s_c[4][BRD_NL];
+  __shared__ int s_first[BRD_NL];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = blockIdx.x * CP_TILE + wave * 256 + lane;
+  int F[4];
+#pragma unroll
+  for(int r = 0; r < 4; r++) F[r] = base + r * 64 < nlocal ? (int)bits[base + r * 64] : 0;
+  int my_tot = 0, my_cnt = 0;
+  if(wave == 0 && lane < BRD_NL) { my_tot = tot[lane]; my_cnt = cnt[lane * nblk + blockIdx.x]; }
+  const unsigned U = wave_or_u((unsigned)(F[0] | F[1] | F[2] | F[3]));
+  brd_for_lists([&](auto L) {
+    constexpr int l = decltype(L)::index, m = decltype(L)::mask;
+    int c = 0;
+    if((U & m) == m) {
+#pragma unroll
+      for(int r = 0; r < 4; r++) c += __popcll(__builtin_amdgcn_ballot_w64((F[r] & m) == m));
+    }
+    if(lane == 0) s_c[wave][l] = c;
+  });
+  if(wave == 0) {
+    const int lt = lane < BRD_NL ? my_tot : 0;
+    const int lstart = wave_incl_scan(lt) - lt;
+    if(lane < BRD_NL) s_first[lane] = lstart + my_cnt;
+    if(blockIdx.x == 0 && lane < BRD_NL) counts[lane] = my_tot;
+  }
+  __syncthreads();
+  if(U == 0u) return;
+  int myoff = 0;
+  if(lane < BRD_NL) {
+    myoff = s_first[lane];
+    for(int w = 0; w < wave; w++) myoff += s_c[w][lane];
+  }
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  brd_for_lists([&](auto L) {
+    constexpr int l = decltype(L)::index, m = decltype(L)::mask;
+    if((U & m) != m) return;
+    int o = __builtin_amdgcn_readlane(myoff, l);
+#pragma unroll
+    for(int r = 0; r < 4; r++) {
+      const bool in = (F[r] & m) == m;
+      const unsigned long long mm = __builtin_amdgcn_ballot_w64(in);
+      if(in) idx[o + __popcll(mm & below)] = base + r * 64;
+      o += __popcll(mm);
+    }
+  });
+}
+
+struct DhMeta { int soff[27]; int self_base[26]; int sdst[26]; real sx[26], sy[26], sz[26]; };       // self_base >= 0: the list's target is this rank itself
+// what = 0: positions {x + shift, type} of the listed atoms into the send buffer (the lists of one partner end to end); a list whose target is this
+// rank goes straight into its ghost slots
+__global__ __launch_bounds__(256) void k_dh_pack_x(real4* __restrict__ x, const int* __restrict__ idx, int total, DhMeta M, real4* __restrict__ buf, int nlocal)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= total) return;
+  int l = 0;
+#pragma unroll
+  for(int q = 1; q < 26; q++) l += e >= M.soff[q] ? 1 : 0;
+  real4 p = x[idx[e]];
+  p.x += M.sx[l]; p.y += M.sy[l]; p.z += M.sz[l];
+  if(M.self_base[l] >= 0) x[nlocal + M.self_base[l] + (e - M.soff[l])] = p; else buf[M.sdst[l] + (e - M.soff[l])] = p;
+}
+__global__ __launch_bounds__(256) void k_dh_pack_f(real* __restrict__ fp, const int* __restrict__ idx, int total, DhMeta M, real* __restrict__ buf, int nlocal)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= total) return;
+  int l = 0;
+#pragma unroll
+  for(int q = 1; q < 26; q++) l += e >= M.soff[q] ? 1 : 0;
+  const real v = fp[idx[e]];
+  if(M.self_base[l] >= 0) fp[nlocal + M.self_base[l] + (e - M.soff[l])] = v; else buf[M.sdst[l] + (e - M.soff[l])] = v;
+}
+// the received lists (one message per partner) into the ghost slots: ghost g belongs to list l (rbase[l] <= g < rbase[l+1]), entry g - rbase[l] of it
+struct DhUnpack { int rbase[27]; int rsrc[26]; };
+template <typename T>
+__global__ __launch_bounds__(256) void k_dh_unpack(T* __restrict__ dst, const T* __restrict__ rbuf, int nghost, DhUnpack U)
+{
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= nghost) return;
+  int l = 0;
+#pragma unroll
+  for(int q = 1; q < 26; q++) l += g >= U.rbase[q] ? 1 : 0;
+  if(U.rsrc[l] >= 0) dst[g] = rbuf[U.rsrc[l] + (g - U.rbase[l])];
+}
+
+static bool dh_applies(const mmd_handle* h)
+{
+  if(!h->dh.opt || h->swaps.size() != 6 || !(h->nprocs > 1 || h->opt_force_transport) || !(h->rccl || h->host_sr)) return false;
+  for(int q = 0; q < 6; q++) if(h->swaps[q].dim != q / 2) return false;
+  return true;
+}
+
+// lists + lengths of this rank on the stream, the lengths of the lists it will receive exchanged with the neighbours, both copied to pinned memory
+// (no host synchronisation here with RCCL: the neighbor build's own read-back comes later on the same stream)
+static int dh_enqueue(mmd_handle* h)
+{
+  DirectHalo& D = h->dh;
+  D.ready = false; D.pending = false;
+  if(!dh_applies(h)) return 0;
+  const int nlocal = h->nlocal;
+  SelfSwaps W;
+  for(int q = 0; q < 6; q++) {
+    const Swap& sw = h->swaps[q];
+    W.lo[q] = sw.slablo; W.hi[q] = sw.slabhi;
+    W.sx[q] = sw.pbc[0] * h->prd[0]; W.sy[q] = sw.pbc[1] * h->prd[1]; W.sz[q] = sw.pbc[2] * h->prd[2];
+    W.pbc_any[q] = sw.pbc_any; W.px[q] = sw.pbc[0]; W.py[q] = sw.pbc[1]; W.pz[q] = sw.pbc[2];
+    W.cap_list[q] = 0; W.sendlist[q] = nullptr;
+  }
+  // where every list goes and comes from: a list travels one step along each of its swaps' send directions (swap 2d towards -1, 2d+1 towards +1)
+  {
+    int l = 0;
+    const int masks[26] = {0x01, 0x02, 0x04, 0x05, 0x06, 0x08, 0x09, 0x0a, 0x10, 0x11, 0x12, 0x14, 0x15, 0x16, 0x18, 0x19, 0x1a,
+                           0x20, 0x21, 0x22, 0x24, 0x25, 0x26, 0x28, 0x29, 0x2a};
+    for(l = 0; l < 26; l++) {
+      int off[3] = {0, 0, 0};
+      D.shift[l][0] = D.shift[l][1] = D.shift[l][2] = 0;
+      for(int q = 0; q < 6; q++) if(masks[l] & (1 << q)) {
+        off[q / 2] += (q & 1) ? 1 : -1;
+        const Swap& sw = h->swaps[q];
+        if(sw.pbc_any) for(int d = 0; d < 3; d++) D.shift[l][d] += sw.pbc[d] * h->prd[d];
+      }
+      D.target[l] = cart_rank(h->procgrid, h->myloc[0] + off[0], h->myloc[1] + off[1], h->myloc[2] + off[2]);
+      D.source[l] = cart_rank(h->procgrid, h->myloc[0] - off[0], h->myloc[1] - off[1], h->myloc[2] - off[2]);
+    }
+  }
+  const int nblk = std::max(1, div_up(nlocal, CP_TILE));
+  MMD_TRY(h->flag_tmp.ensure((size_t)BRD_ROWS * nblk + BRD_ROWS + 8, false, h->stream));
+  MMD_TRY(h->brd_bits.ensure((size_t)nlocal + 64, false, h->stream));
+  MMD_TRY(D.scratch.ensure(64, false, h->stream));
+  MMD_TRY(D.counts.ensure(32 * 30, false, h->stream));
+  MMD_TRY(D.idx.ensure((size_t)h->nlocal + (size_t)h->nghost + h->nghost / 2 + 4096, false, h->stream));       // (a rank sends about as many images as it receives)
+  int* tot = h->flag_tmp.p + (size_t)BRD_ROWS * nblk;
+  hipLaunchKernelGGL(k_brd_count, dim3(nblk), dim3(256), 0, h->stream, h->x.p, nlocal, W, h->brd_bits.p, h->flag_tmp.p, nblk, D.scratch.p);
+  hipLaunchKernelGGL(k_brd_scan, dim3(BRD_ROWS), dim3(256), 0, h->stream, h->flag_tmp.p, nblk, tot);
+  HIP_TRY(hipGetLastError());
+  const bool forced = h->opt_force_transport != 0;
+  if(h->rccl) {
+    hipLaunchKernelGGL(k_dh_lists, dim3(nblk), dim3(256), 0, h->stream, nlocal, h->brd_bits.p, h->flag_tmp.p, nblk, tot, D.idx.p, D.counts.p);
+    HIP_TRY(hipGetLastError());
+    // the lengths travel as ONE message per distinct partner: all 26 words to each (a p2p operation costs ~3 us whatever its size)
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    NCCL_TRY(ncclGroupStart());
+    int seen_t[26], seen_s[26], nt_ = 0, ns_ = 0;
+    for(int l = 0; l < 26; l++) {
+      if(D.target[l] == h->me && !forced) continue;
+      bool dup = false;
+      for(int k = 0; k < nt_; k++) dup = dup || seen_t[k] == D.target[l];
+      if(!dup) { seen_t[nt_++] = D.target[l]; NCCL_TRY(ncclSend(D.counts.p, 26, ncclInt, D.target[l], c, h->stream)); }
+      dup = false;
+      for(int k = 0; k < ns_; k++) dup = dup || seen_s[k] == D.source[l];
+      if(!dup) { NCCL_TRY(ncclRecv(D.counts.p + 32 * (2 + ns_), 26, ncclInt, D.source[l], c, h->stream)); seen_s[ns_++] = D.source[l]; }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    D.nsrc = ns_;
+    for(int k = 0; k < ns_; k++) D.src_rank[k] = seen_s[k];
+    // (device layout of counts: [0..25] mine, then one block of 32 per distinct source, from word 64 on)
+    HIP_TRY(hipMemcpyAsync(D.h_counts, D.counts.p, (size_t)32 * (2 + ns_) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    D.pending = true;
+    return 0;
+  }
+  D.nsrc = 0;
+  // host-staged test transport: the lengths go through the host anyway
+  hipLaunchKernelGGL(k_dh_lists, dim3(nblk), dim3(256), 0, h->stream, nlocal, h->brd_bits.p, h->flag_tmp.p, nblk, tot, D.idx.p, D.counts.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(D.h_counts, D.counts.p, 64 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(mmd_stream_sync_transport(h));
+  for(int l = 0; l < 26; l++) {
+    if(D.target[l] == h->me && !forced) continue;
+    int out = 0;
+    const long long got = h->host_sr(h->host_ctx, &D.h_counts[l], sizeof(int), D.target[l], &out, sizeof(int), D.source[l]);
+    if(got != (long long)sizeof(int)) { mmd_set_error("direct halo: count exchange failed"); return -1; }
+    D.h_counts[32 + l] = out;
+  }
+  D.pending = true;
+  return 0;
+}
+
+// the lengths are in pinned memory (the caller synchronised, or read the neighbor build's result words, which were published behind them)
+static int dh_finish(mmd_handle* h)
+{
+  DirectHalo& D = h->dh;
+  if(!D.pending) return 0;
+  D.pending = false;
+  const bool forced = h->opt_force_transport != 0;
+  int so = 0, rb = 0;
+  for(int l = 0; l < 26; l++) {
+    D.ns[l] = D.h_counts[l];
+    if(D.target[l] == h->me && !forced) D.nr[l] = D.ns[l];
+    else if(D.nsrc > 0) {                 // RCCL: every source sent all its 26 lengths; mine is its list l
+      int k = 0;
+      while(k < D.nsrc && D.src_rank[k] != D.source[l]) k++;
+      D.nr[l] = D.h_counts[32 * (2 + k) + l];
+    } else D.nr[l] = D.h_counts[32 + l];
+    D.soff[l] = so; so += D.ns[l];
+    D.rbase[l] = rb; rb += D.nr[l];
+  }
+  D.soff[26] = so; D.rbase[26] = rb;
+  D.total_send = so;
+  // one message per distinct partner, its lists end to end in list order (sender and receiver agree: target_l(A) = B <=> source_l(B) = A)
+  D.npeer_s = D.npeer_r = 0;
+  int ps = 0, pr = 0;
+  for(int l = 0; l < 26; l++) { D.sdst[l] = -1; D.rsrc[l] = -1; }
+  for(int l = 0; l < 26; l++) {
+    if(D.target[l] == h->me && !forced) continue;
+    bool seen = false;
+    for(int k = 0; k < D.npeer_s; k++) seen = seen || D.peer_s[k] == D.target[l];
+    if(!seen) {
+      D.peer_s[D.npeer_s] = D.target[l]; D.peer_soff[D.npeer_s] = ps;
+      for(int m = l; m < 26; m++) if(D.target[m] == D.target[l] && !(D.target[m] == h->me && !forced)) { D.sdst[m] = ps; ps += D.ns[m]; }
+      D.npeer_s++;
+    }
+    seen = false;
+    for(int k = 0; k < D.npeer_r; k++) seen = seen || D.peer_r[k] == D.source[l];
+    if(!seen) {
+      D.peer_r[D.npeer_r] = D.source[l]; D.peer_roff[D.npeer_r] = pr;
+      for(int m = l; m < 26; m++) if(D.source[m] == D.source[l] && !(D.target[m] == h->me && !forced)) { D.rsrc[m] = pr; pr += D.nr[m]; }
+      D.npeer_r++;
+    }
+  }
+  D.peer_soff[D.npeer_s] = ps; D.peer_roff[D.npeer_r] = pr;
+  D.total_recv = pr;
+  if(rb != h->nghost) { mmd_set_error("direct halo: the 26 lists hold %d ghosts, Comm::borders made %d", rb, h->nghost); return -1; }
+  if((size_t)so > D.idx.cap) { mmd_set_error("direct halo: send lists longer than provided for (%d)", so); return -1; }
+  D.ready = true;
+  return 0;
+}
+
+int mmd_dh_exchange(mmd_handle* h, int what)
+{
+  DirectHalo& D = h->dh;
+  if(!D.ready) { mmd_set_error("direct halo: no plan"); return -1; }
+  const bool forced = h->opt_force_transport != 0;
+  DhMeta M;
+  DhUnpack U;
+  for(int l = 0; l < 26; l++) {
+    M.soff[l] = D.soff[l];
+    const bool self = D.target[l] == h->me && !forced;
+    M.self_base[l] = self ? D.rbase[l] : -1;
+    M.sdst[l] = D.sdst[l];
+    M.sx[l] = D.shift[l][0]; M.sy[l] = D.shift[l][1]; M.sz[l] = D.shift[l][2];
+    U.rbase[l] = D.rbase[l]; U.rsrc[l] = D.rsrc[l];
+  }
+  M.soff[26] = D.soff[26]; U.rbase[26] = D.rbase[26];
+  const size_t esz = what == 0 ? sizeof(real4) : sizeof(real);
+  const size_t per = what == 0 ? 4 : 1;
+  const int nsend_remote = D.peer_soff[D.npeer_s];
+  MMD_TRY(h->buf_send.ensure(per * (size_t)nsend_remote + 16, false, h->stream));
+  MMD_TRY(h->buf_recv.ensure(per * (size_t)D.total_recv + 16, false, h->stream));
+  if(D.total_send) {
+    if(what == 0) hipLaunchKernelGGL(k_dh_pack_x, dim3(div_up(D.total_send, 256)), dim3(256), 0, h->stream, h->x.p, D.idx.p, D.total_send, M, (real4*)h->buf_send.p, h->nlocal);
+    else hipLaunchKernelGGL(k_dh_pack_f, dim3(div_up(D.total_send, 256)), dim3(256), 0, h->stream, h->fp.p, D.idx.p, D.total_send, M, h->buf_send.p, h->nlocal);
+    HIP_TRY(hipGetLastError());
+  }
+  unsigned char* sbuf = (unsigned char*)h->buf_send.p;
+  unsigned char* rbuf = (unsigned char*)h->buf_recv.p;
+  if(h->rccl) {
+    h->halo_bytes += (long long)((size_t)nsend_remote * esz);
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    NCCL_TRY(ncclGroupStart());
+    for(int k = 0; k < D.npeer_s; k++) {
+      const size_t n = (size_t)(D.peer_soff[k + 1] - D.peer_soff[k]);
+      if(n) NCCL_TRY(ncclSend(sbuf + (size_t)D.peer_soff[k] * esz, n * esz, ncclChar, D.peer_s[k], c, h->stream));
+    }
+    for(int k = 0; k < D.npeer_r; k++) {
+      const size_t n = (size_t)(D.peer_roff[k + 1] - D.peer_roff[k]);
+      if(n) NCCL_TRY(ncclRecv(rbuf + (size_t)D.peer_roff[k] * esz, n * esz, ncclChar, D.peer_r[k], c, h->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+  } else {
+    // host-staged test transport: a send to peer k is matched by the receive from the rank that has this rank as ITS k-th target; pairing send k with
+    // receive k is a shift pattern every rank follows alike only when both enumerate their partners in the same list order — which they do
+    const int np = std::max(D.npeer_s, D.npeer_r);
+    for(int k = 0; k < np; k++) {
+      const bool hs = k < D.npeer_s, hr = k < D.npeer_r;
+      const size_t nsb = hs ? (size_t)(D.peer_soff[k + 1] - D.peer_soff[k]) * esz : 0, nrb = hr ? (size_t)(D.peer_roff[k + 1] - D.peer_roff[k]) * esz : 0;
+      MMD_TRY(mmd_transport_sendrecv(h, sbuf + (hs ? (size_t)D.peer_soff[k] * esz : 0), nsb, hs ? D.peer_s[k] : h->me, rbuf + (hr ? (size_t)D.peer_roff[k] * esz : 0), nrb,
+                                     hr ? D.peer_r[k] : h->me));
+    }
+  }
+  if(D.total_recv && h->nghost) {
+    if(what == 0) hipLaunchKernelGGL((k_dh_unpack<real4>), dim3(div_up(h->nghost, 256)), dim3(256), 0, h->stream, h->x.p + h->nlocal, (const real4*)h->buf_recv.p, h->nghost, U);
+    else hipLaunchKernelGGL((k_dh_unpack<real>), dim3(div_up(h->nghost, 256)), dim3(256), 0, h->stream, h->fp.p + h->nlocal, (const real*)h->buf_recv.p, h->nghost, U);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
 static int borders_fast_finish(mmd_handle* h);
 
@@ -1570,12 +1865,16 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   h->nghost = 0;
   h->ghosts_uploaded = false;
   h->nghost_dev = nullptr;
+  h->dh.ready = false; h->dh.pending = false;
   {
     const bool defer = h->in_reneighbor && h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && h->neigh_ready;
     const int rc = borders_device_resident(h, defer);
     if(rc < 0) return rc;
     if(rc == 1) MMD_TRY(mmd_set_dummy(h));
     if(rc >= 1) {
+      // several ranks: the lists of the direct per-step halo; their lengths arrive with the next host synchronisation (deferred: the neighbor build's)
+      MMD_TRY(dh_enqueue(h));
+      if(rc == 1 && h->dh.pending) { HIP_TRY(mmd_stream_sync(h)); MMD_TRY(dh_finish(h)); }
       h->neigh_nlocal = 0;
       h->tiles_ready = false;
       h->cand_src_ready = false;
@@ -1592,8 +1891,10 @@ int mmd_borders_deferred_finish(mmd_handle* h)
 {
   h->nghost_dev = nullptr;
   const int rc = borders_fast_finish(h);
+  if(rc == 1) MMD_TRY(dh_finish(h));
   if(rc != 0) return rc;
   h->nghost = 0;
+  h->dh.ready = false; h->dh.pending = false;
   const int rg = borders_general(h);
   return rg < 0 ? rg : 0;
 }
@@ -1709,6 +2010,8 @@ static int borders_general(mmd_handle* h)
   h->prev_nghost = h->nghost;
   h->borders_general_done = true;
   h->borders_general_runs++;
+  MMD_TRY(dh_enqueue(h));
+  if(h->dh.pending) { HIP_TRY(mmd_stream_sync(h)); MMD_TRY(dh_finish(h)); }
   h->neigh_nlocal = 0;                 // any existing neighbor list is stale now
   h->tiles_ready = false;
   h->cand_src_ready = false;

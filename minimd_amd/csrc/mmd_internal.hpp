@@ -121,6 +121,28 @@ struct EventPair { hipEvent_t a, b; int kind = 0; };
 // the ghost count from device memory. gate == nullptr: an ordinary launch.
 struct SpecLaunch { const int* gate; const int* ntiles_dev; const int* nghost_dev; };
 
+// Direct halo (several ranks, need = 1 in every dimension): the forward communication of a step as ONE exchange with the up to 26 neighbours instead
+// of three dependent rounds (one per dimension, the later ones forwarding what the earlier ones received). The ghosts of a rank are 26 lists — one
+// per combination (x swap | none, y swap | none, z swap | none) — and list L holds, in ascending index order, the OWNED atoms of the rank at grid
+// offset -dir(L) that lie in all slabs of L (comm.hip: BrdList); the swap-by-swap order of ref/comm.cpp:364-597 is these lists laid end to end. Once
+// per re-neighboring every rank compacts its 26 send lists and exchanges their lengths; per step it packs once and receives straight into the ghost slots.
+struct DirectHalo {
+  bool ready = false, pending = false;
+  int opt = 1;
+  int ns[26], nr[26], soff[27], rbase[27], target[26], source[26];
+  // one message per distinct partner: the lists that go to (come from) the same rank travel end to end, in list order
+  int sdst[26], rsrc[26];     // offset of list l inside the send / receive buffer (entries); -1: the list stays on this rank
+  int npeer_s = 0, npeer_r = 0, peer_s[26], peer_r[26], peer_soff[27], peer_roff[27];
+  int total_recv = 0;         // entries that arrive in the receive buffer
+  int nsrc = 0, src_rank[26]; // RCCL: the distinct ranks whose 26 list lengths arrived (block k of the pinned copy)
+  real shift[26][3];
+  int total_send = 0;
+  DevArr<int> idx;            // the 26 send lists, end to end
+  DevArr<int> counts;         // device: [0..25] lengths of my send lists, [32..57] of the lists I receive
+  DevArr<int> scratch;
+  int* h_counts = nullptr;    // pinned copy of `counts` (32 x 30 ints)
+};
+
 struct mmd_handle {
   int device = 0;
   bool host_only = false;    // geometry-only handle (mmd_create(-2)): no GPU, host functions only
@@ -235,6 +257,7 @@ struct mmd_handle {
   void* host_ctx = nullptr;
   std::vector<char> stage_send, stage_recv;
   DevArr<int> flag_tmp, bnd_list, bstate;
+  DirectHalo dh;
   DevArr<unsigned char> brd_bits;      // one-rank borders in three launches: per owned atom, which of the six send slabs hold it
   DevArr<int> est, ex_list;            // handshake-free Comm::exchange (comm.hip): device-resident counts / leaver list
   int ex_prev_send[3] = {0, 0, 0}, ex_prev_recv[3][2] = {{0, 0}, {0, 0}, {0, 0}};     // migration counts of the last exchange (size the fixed messages)
@@ -312,6 +335,9 @@ struct mmd_handle {
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   double force_ms = 0, comm_ms = 0;
+  double halo_ms = 0;                  // forward halos of the sampled steps (every 4th)
+  hipEvent_t ovf_a = nullptr, ovf_b = nullptr;   // bracket of an overlapped step's two force launches
+  bool ovf_open = false;
   int force_launches = 0;
   double force_ms_all = 0;             // Force::compute calls timed on every step (overlapped multi-rank steps), not sampled
   int force_launches_all = 0;
@@ -329,6 +355,7 @@ struct mmd_handle {
 int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve);
 int mmd_set_dummy(mmd_handle* h);
 int mmd_box_dev(mmd_handle* h);
+int mmd_dh_exchange(mmd_handle* h, int what);      // direct halo of a step: 0 positions (x), 1 EAM fp; only when h->dh.ready
 int mmd_borders_deferred_finish(mmd_handle* h);
 int mmd_borders_deferred_resolve(mmd_handle* h);
 int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host);   // in-place, returns total

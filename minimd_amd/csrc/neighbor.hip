@@ -239,14 +239,19 @@ __global__ void k_bin_sort(const int* __restrict__ bin_start, int mbins, int* __
     }
   }
   if(pencil_lohi == nullptr) return;
+  // (a pencil has more than 64 bins: a wavefront's 64 consecutive bins lie in at most two pencils, p0 and p0 + 1 — one reduction and one atomic pair each)
   const int p = b < mbins ? b / bins_per_pencil : -1, q = b < mbins ? b - p * bins_per_pencil : 0;
   const int p0 = __builtin_amdgcn_readfirstlane(p);
-  const bool uniform = __builtin_amdgcn_ballot_w64(p != p0) == 0ull;
-  if(uniform) {
-    if(p0 < 0) return;
-    const unsigned lo = wave_min_u(owned ? (unsigned)q : 0xffffffffu), hi = wave_max_u(owned ? (unsigned)q + 1u : 0u);
-    if((threadIdx.x & 63) == 0 && hi > 0u) { atomicMin(&pencil_lohi[2 * p0], lo); atomicMax(&pencil_lohi[2 * p0 + 1], hi); }
-  } else if(owned) { atomicMin(&pencil_lohi[2 * p], (unsigned)q); atomicMax(&pencil_lohi[2 * p + 1], (unsigned)q + 1u); }
+  if(p0 < 0) return;
+#pragma unroll
+  for(int seg = 0; seg < 2; seg++) {
+    const int ps = p0 + seg;
+    const bool mine = owned && p == ps;
+    if(__builtin_amdgcn_ballot_w64(mine) == 0ull) continue;
+    const unsigned lo = wave_min_u(mine ? (unsigned)q : 0xffffffffu), hi = wave_max_u(mine ? (unsigned)q + 1u : 0u);
+    if((threadIdx.x & 63) == 0) { atomicMin(&pencil_lohi[2 * ps], lo); atomicMax(&pencil_lohi[2 * ps + 1], hi); }
+  }
+  if(owned && p > p0 + 1) { atomicMin(&pencil_lohi[2 * p], (unsigned)q); atomicMax(&pencil_lohi[2 * p + 1], (unsigned)q + 1u); }     // (pencils shorter than 64 bins: tiny boxes)
 }
 // long bins: every entry finds its rank by counting the smaller entries of its bin (O(n^2) compares spread over the whole
 // grid instead of one thread's insertion sort); `scratch` holds as many ints as `binned`; a second launch copies the

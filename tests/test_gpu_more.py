@@ -409,6 +409,36 @@ def test_overlap_split_equals_single_launch(deck):
     np.testing.assert_array_equal(rows[0][2], rows[1][2])
 
 
+@pytest.mark.parametrize("deck,half", [("in.lj.miniMD", 0), ("in.lj.miniMD", 1), ("in.eam.miniMD", 0)])
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_direct_halo_equals_the_swap_by_swap_halo(deck, half, overlap):
+    """Several ranks (here: one rank whose periodic self swaps are forced through RCCL, the code path of a rank inside a multi-GPU run): the forward
+    communication of a step — positions, and fp between the EAM sweeps — as ONE exchange with the up to 26 neighbours (26 lists of owned atoms per
+    rank, one message per partner, option direct_halo) against the three dependent rounds of ref/comm.cpp:276-317. Same ghosts in the same slots:
+    bit-identical rows, positions and forces (half lists: to the order of the atomics) after 60 steps with 2 re-neighborings."""
+    m = mm()
+    out = {}
+    for dh in (0, 1):
+        s = m.Sim(["-i", deck, "-s", 12 if "lj" in deck else 8, "-n", 60, "--half_neigh", half])
+        h = s.handle
+        h.init_rccl(h.unique_id(), 0, 1)
+        h.set_option("force_transport", 1)
+        h.set_option("overlap", overlap)
+        h.set_option("direct_halo", dh)
+        s.initial(); s.run()
+        d = h.download()
+        out[dh] = (s.rows(), d["x"].copy(), d["f"].copy(), h.run_stats()["bytes_sent"])
+        s.close()
+    assert out[0][3] > 0 and out[1][3] > 0
+    if half:
+        rows_close(out[0][0], out[1][0], 1e-10)
+        assert np.abs(out[0][1] - out[1][1]).max() <= 1e-9
+    else:
+        assert out[0][0] == out[1][0]
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+        np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
 @pytest.mark.parametrize("args", [["-s", 12], ["-s", 3], ["-nx", 2, "-ny", 5, "-nz", 3]])
 def test_ghosts_staged_from_their_owners_equal_the_ghost_update(args):
     """One rank: the tile kernel reads a ghost candidate as owner position + box shift (no per-step Comm::communicate) — the
