@@ -95,6 +95,11 @@ class stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:                                   # (the C library's own stdout buffer — a pipe is fully buffered — would otherwise be flushed at exit, behind the JSON line)
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
@@ -117,6 +122,33 @@ def perf_summary_cold(size):
         return {"value": None, "unit": "Matom-steps/s", "cmd": " ".join(cmd), "error": repr(e)}
 
 
+def rank_path_loopback(size, steps):
+    """What the multi-GPU step costs a rank apart from the wire, measured on THIS one GPU: the same workload on one rank whose periodic self swaps are
+    routed through RCCL (option force_transport: direct halo packed, sent to itself with ncclSend/ncclRecv, unpacked; borders and exchange through
+    their fixed-size messages; halo on the communication stream under the interior tiles) — the code path of a rank inside `--gpus 8`, xGMI transfer
+    time excepted. A diagnostic next to `value` (which is the production one-rank path), never instead of it."""
+    import minimd_amd
+    try:
+        s = minimd_amd.Sim(["-s", size, "--half_neigh", 0, "-n", steps], precision="dp", quiet=True)
+        h = s.handle
+        with stdout_to_stderr():          # (ncclCommInitRank prints RCCL's version banner: stdout carries the ONE JSON line only)
+            h.init_rccl(h.unique_id(), 0, 1)
+        h.set_option("force_transport", 1)
+        s.initial()
+        s.run_steps(40)
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) < 0.3:
+            h.profile_kernel(0, 50)
+        best = min(s.run_steps(steps) for _ in range(2))
+        st = h.run_stats()
+        nat = s.natoms()
+        s.close()
+        return {"value": nat * steps / best / 1e6, "unit": "Matom-steps/s", "ms_per_step": best * 1e3 / steps, "steps": steps,
+                "halo_bytes_per_step": st["bytes_sent"] / steps, "note": "one rank, self swaps through RCCL loop-back on one GPU (no xGMI transfer)"}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +160,7 @@ def main():
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each, back to back: the FIRST is `value` (the contract's "
                                                           "K steps), all of them are listed in `value_windows` so that a short window shows its spread")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold run of the drop-in executable (perf_summary_cold)")
+    ap.add_argument("--no-loopback", action="store_true", help="skip the one-GPU measurement of the multi-rank code path (rank_path_loopback)")
     ap.add_argument("--equil", type=int, default=100, help="untimed equilibration steps before the warm-up (set-up, see the module docstring)")
     ap.add_argument("--clock-warm-ms", type=float, default=400.0,
                     help="set-up: keep the GPU busy this long (force-kernel launches that leave the state untouched) so that the warm-up "
@@ -372,6 +405,7 @@ def main():
             out["cpu_baseline"] = None
     sim.close()
     if rank == 0:
+        out["rank_path_loopback"] = rank_path_loopback(args.size, args.steps) if (world == 1 and not args.no_loopback and not args.no_cold) else None
         out["perf_summary_cold"] = perf_summary_cold(args.size) if (world == 1 and not args.no_cold) else None
         print(json.dumps(out), flush=True)
     if dist is not None:
