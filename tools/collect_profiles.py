@@ -18,7 +18,8 @@ names = {"bench_n1.json": "bench_n1.json", "configs.txt": "configs.txt", "kernel
          "kernel_stats_C.md": "kernel_stats_C_eam_s64_full_dp.md", "kernel_stats_Ch.md": "kernel_stats_Chalf_eam_s64_half_dp.md",
          "kernel_stats_E.md": "kernel_stats_E_s160_half_sp.md", "pmc_lj_full.txt": "pmc_k_lj_full_tile.txt", "pmc_lj_half.txt": "pmc_k_lj_half_tile.txt",
          "pmc_eam.txt": "pmc_k_eam_tile.txt", "pmc_build.txt": "pmc_k_build_rows.txt",
-         "timeline_reneighboring_s80.txt": "timeline_reneighboring_s80.txt", "timeline_reneighboring_s32.txt": "timeline_reneighboring_s32.txt"}
+         "timeline_reneighboring_s80.txt": "timeline_reneighboring_s80.txt", "timeline_reneighboring_s32.txt": "timeline_reneighboring_s32.txt",
+         "timeline_rank_path_loopback_s80.txt": "timeline_rank_path_loopback_s80.txt", "rank_path_loopback.txt": "rank_path_loopback.txt"}
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (tag, b)))

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 for rnd in 1 2; do
 for o in "$@"; do
-  MMD_BENCH_OPTIONS="$o" python bench.py --no-cpu-baseline --steps 100 --warmup 20 2>/dev/null | python -c "
+  MMD_BENCH_OPTIONS="$o" python bench.py --no-cpu-baseline --no-loopback --steps 100 --warmup 20 2>/dev/null | python -c "
 import sys, json
 d = json.loads([l for l in sys.stdin if l.startswith('{')][0])
 r = d['roofline']

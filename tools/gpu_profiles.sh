@@ -16,7 +16,7 @@ stats() {   # name, command...
   python tools/rocpd_stats.py $(find $O/kt_$name -name "*.db" | head -1) $O/kernel_stats_$name.md > /dev/null
   head -8 $O/kernel_stats_$name.md
 }
-stats bench python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline
+stats bench python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-loopback
 for c in A Bh C Ch E; do stats $c python $GRAFT_REPO_ROOT/tools/run_one.py $c; done
 # PMC passes (each counter group its own rocprofv3 run, --kernel-trace only)
 bash tools/pmc_force.sh $O/pmc_lj_full  k_lj_full_tile   tools/prof_force.py --kernels 0 --reps 5 > $O/pmc_lj_full.txt 2>&1
@@ -28,6 +28,11 @@ tail -30 $O/pmc_lj_full.txt
 bash tools/gpu_timeline.sh 80 > $O/timeline_reneighboring_s80.txt 2>&1
 bash tools/gpu_timeline.sh 32 > $O/timeline_reneighboring_s32.txt 2>&1
 rm -rf gpurun_out/tl80 gpurun_out/tl32
+# the multi-rank code path on this one GPU (periodic self swaps through RCCL loop-back): kernels of two plain steps and of one re-neighboring
+(cd /tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/tllb -o t -- python $GRAFT_REPO_ROOT/tools/loopback_trace.py 80 1 > /dev/null 2>&1)
+{ echo "# tools/loopback_trace.py 80 1 under rocprofv3 --kernel-trace: one rank of in.lj.miniMD -s 80 whose self swaps go through RCCL (force_transport), overlap on"; echo "## two plain steps"; python tools/rocpd_steps.py $(find gpurun_out/tllb -name "*.db" | head -1) 1 | head -12; echo "## one re-neighboring"; python tools/rocpd_timeline.py $(find gpurun_out/tllb -name "*.db" | head -1); } > $O/timeline_rank_path_loopback_s80.txt 2>&1
+rm -rf gpurun_out/tllb
+timeout 300 python tools/loopback_probe.py 80 2>&1 | grep "^-s" > $O/rank_path_loopback.txt
 # keep the merge small: drop the raw rocprof trees, keep logs + summaries
 find $O -name "*.db" -delete; find $O -type d -name "kt_*" -exec rm -rf {} + 2>/dev/null; find $O -mindepth 1 -maxdepth 1 -type d -name "pmc_*" -exec rm -rf {} + 2>/dev/null
 ls -la $O
