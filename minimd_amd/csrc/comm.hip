@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(256) void k_brd_scatter(real4* __restrict__ x, int 
 // ---------------------------------------------------------------------------------------------------
 // the 26 send lists of this rank, end to end in list order: owned atoms inside all slabs of the list, ascending (k_brd_count / k_brd_scan went before)
 __global__ __launch_bounds__(256) void k_dh_lists(int nlocal, const unsigned char* __restrict__ bits, const int* __restrict__ cnt, int nblk,
-                                                  const int* __restrict__ tot, int* __restrict__ idx, int* __restrict__ counts)
+                                                  const int* __restrict__ tot, int* __restrict__ idx, int* __restrict__ counts, int cap)
 {
   __shared__ int s_c[4][BRD_NL];
   __shared__ int s_first[BRD_NL];
@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_dh_lists(int nlocal, const unsigned cha
     for(int r = 0; r < 4; r++) {
       const bool in = (F[r] & m) == m;
       const unsigned long long mm = __builtin_amdgcn_ballot_w64(in);
-      if(in) idx[o + __popcll(mm & below)] = base + r * 64;
+      if(in && o + __popcll(mm & below) < cap) idx[o + __popcll(mm & below)] = base + r * 64;          // (the host checks the total against cap when the lengths arrive)
       o += __popcll(mm);
     }
   });
@@ -1541,7 +1541,7 @@ static int dh_enqueue(mmd_handle* h)
   HIP_TRY(hipGetLastError());
   const bool forced = h->opt_force_transport != 0;
   if(h->rccl) {
-    hipLaunchKernelGGL(k_dh_lists, dim3(nblk), dim3(256), 0, h->stream, nlocal, h->brd_bits.p, h->flag_tmp.p, nblk, tot, D.idx.p, D.counts.p);
+    hipLaunchKernelGGL(k_dh_lists, dim3(nblk), dim3(256), 0, h->stream, nlocal, h->brd_bits.p, h->flag_tmp.p, nblk, tot, D.idx.p, D.counts.p, (int)std::min<size_t>(D.idx.cap, 0x7fffffff));
     HIP_TRY(hipGetLastError());
     // the lengths travel as ONE message per distinct partner: all 26 words to each (a p2p operation costs ~3 us whatever its size)
     ncclComm_t c = (ncclComm_t)h->rccl;
@@ -1566,7 +1566,7 @@ static int dh_enqueue(mmd_handle* h)
   }
   D.nsrc = 0;
   // host-staged test transport: the lengths go through the host anyway
-  hipLaunchKernelGGL(k_dh_lists, dim3(nblk), dim3(256), 0, h->stream, nlocal, h->brd_bits.p, h->flag_tmp.p, nblk, tot, D.idx.p, D.counts.p);
+  hipLaunchKernelGGL(k_dh_lists, dim3(nblk), dim3(256), 0, h->stream, nlocal, h->brd_bits.p, h->flag_tmp.p, nblk, tot, D.idx.p, D.counts.p, (int)std::min<size_t>(D.idx.cap, 0x7fffffff));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(D.h_counts, D.counts.p, 64 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(mmd_stream_sync_transport(h));
