@@ -167,6 +167,7 @@ static int ev_begin(mmd_handle* h, int kind = 0)
 }
 static int ev_end(mmd_handle* h)
 {
+  if(h->ev_used >= h->ev_pool.size()) { mmd_set_error("internal: event bracket closed without having been opened"); return -1; }
   HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used].b, h->stream));
   h->ev_used++;
   return 0;
@@ -452,7 +453,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       h->spec_done = false;
       {
         const int ev_rb = thermo_nstat > 0 && ((first_step + n + 1) % thermo_nstat == 0);
-        if(spec_static && had_tiles && !ev_rb) h->spec_fn = [&launch_force, n]() { return launch_force(n, 0); };
+        // (only with the device-side phase clocks: an event bracket around the build is open here, and the launch would attach its own pair inside it)
+        if(spec_static && had_tiles && !ev_rb && dev_clock) h->spec_fn = [&launch_force, n]() { return launch_force(n, 0); };
         const int rcb = mmd_neighbor_build(h);
         h->spec_fn = nullptr;
         MMD_TRY(rcb);

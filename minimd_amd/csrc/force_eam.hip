@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
     const unsigned short* __restrict__ nl16, int nlocal, int nall, int maxneighs, const real* __restrict__ rhor_spline,
     const real* __restrict__ frho_spline, real cutforcesq, int nr, int nrho, int cmax, real rdr, real rdrho, real* __restrict__ fp,
     double* __restrict__ partials, int mlo, const unsigned short* __restrict__ tile_self, real* __restrict__ rho, EamCore C,
-    const int* __restrict__ cand_src, const real* __restrict__ box_dev)
+    const int* __restrict__ cand_src, const real* __restrict__ box_dev, const int* __restrict__ tile_ghost)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_TW;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
   // one rank, full lists (G.cand_src): ghosts are staged from their OWNERS' current positions + the box shift of their image code — the step has
   // no Comm::communicate launch (tile_lds.hpp: GhostResolve); for owned atoms and the dummy the two lists hold the same index
-  constexpr bool packed = SRC != 0 && !HALF;
+  const bool packed = SRC != 0 && !HALF && tile_ghost[tile] != 0;      // (the second list exists for tiles with a ghost candidate only; workgroup-uniform)
   const int* __restrict__ cl = (packed ? cand_src : tile_cand) + (size_t)tile * cstride;
   const bool stage = !(MMD_ABLATE(C.ablate) & 1);
   int tt[EAM_STAGE], jj[EAM_STAGE];
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
     const real* __restrict__ z2r_spline, real cutforcesq, int nr, int cmax, real rdr, const real* __restrict__ fp, real* __restrict__ f,
     double* __restrict__ partials, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, int mlo,
     const unsigned short* __restrict__ tile_self, EamCore C, const int* __restrict__ fp_root,
-    const int* __restrict__ cand_src, const real* __restrict__ box_dev)
+    const int* __restrict__ cand_src, const real* __restrict__ box_dev, const int* __restrict__ tile_ghost)
 {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int NT = 64 * EAM_FW;
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   // three round trips (see k_eam_density_tile): header; indices + own atom + first slots; positions + fp
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
-  constexpr bool packed = SRC != 0 && !HALF;       // (see k_eam_density_tile: ghosts named by owner + image code)
+  const bool packed = SRC != 0 && !HALF && tile_ghost[tile] != 0;       // (see k_eam_density_tile: ghosts named by owner + image code)
   const int* __restrict__ cl = (packed ? cand_src : tile_cand) + (size_t)tile * cstride;
   const bool stage = !(MMD_ABLATE(C.ablate) & 1);
   // one rank: a ghost is an image of an owned atom, its fp is its owner's (ForceEAM::communicate, ref/force_eam.cpp:851-913, folded
@@ -1022,7 +1022,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     hipLaunchKernelGGL((k_eam_density_tile<0, 1>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p, h->tile_first.p,
                        h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,
                        h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr, h->nrho, h->tile_cmax, h->rdr, h->rdrho,
-                       h->fp.p, (double*)nullptr, mlo, h->tile_self.p, h->rho.p, EamCore{}, (const int*)nullptr, (const real*)nullptr);
+                       h->fp.p, (double*)nullptr, mlo, h->tile_self.p, h->rho.p, EamCore{}, (const int*)nullptr, (const real*)nullptr, (const int*)nullptr);
     if(evflag) hipLaunchKernelGGL((k_eam_half_fp<1>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p, 1, h->nrho,
                                   h->nrho_tot, h->rdrho, h->fp.p, p_embed);
     else hipLaunchKernelGGL((k_eam_half_fp<0>), dim3(nblocks), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->rho.p, nlocal, h->frho_spline.p, 1, h->nrho,
@@ -1032,7 +1032,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define FH(EVv) hipLaunchKernelGGL((k_eam_force_tile<EVv, 0, 1>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p, h->tile_first.p, \
                        h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, nt, (const int*)nullptr, h->nl16.p, nlocal, nall,   \
                        h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr, h->tile_cmax, h->rdr, h->fp.p, h->f.p, p_pair,          \
-                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p, EamCore{}, (const int*)nullptr, (const int*)nullptr, (const real*)nullptr)
+                       h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, h->tile_self.p, EamCore{}, (const int*)nullptr, (const int*)nullptr, (const real*)nullptr, (const int*)nullptr)
     if(evflag) FH(1); else FH(0);
 #undef FH
     HIP_TRY(hipGetLastError());
@@ -1129,11 +1129,11 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
 #define DT(EVv, Sv, LIST, CNT) hipLaunchKernelGGL((k_eam_density_tile<EVv, 0, Sv>), dim3(pgrid1), dim3(64 * EAM_TW), tl1, h->stream, h->x.p, h->binned.p,     \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->frho_spline.p, h->h_cutforcesq[0], h->nr,  \
-                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo, (const unsigned short*)nullptr, (real*)nullptr, core, src_p, box_p)
+                                   h->nrho, h->tile_cmax, h->rdr, h->rdrho, h->fp.p, h->partials.p, mlo, (const unsigned short*)nullptr, (real*)nullptr, core, src_p, box_p, (const int*)h->tile_ghost.p)
 #define FT(EVv, Fv, Sv, LIST, CNT) hipLaunchKernelGGL((k_eam_force_tile<EVv, Fv, 0, Sv>), dim3(pgrid2), dim3(64 * EAM_FW), tl2, h->stream, h->x.p, h->binned.p,       \
                                    h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,   \
                                    h->nl16.p, nlocal, nall, h->maxneighs, h->rhor_spline.p, h->z2r_spline.p, h->h_cutforcesq[0], h->nr,   \
-                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr, core, fp_root, src_p, box_p)
+                                   h->tile_cmax, h->rdr, h->fp.p, h->f.p, h->partials.p, h->v.p, h->x_alt.p, h->dt, h->dtforce, mlo, (const unsigned short*)nullptr, core, fp_root, src_p, box_p, (const int*)h->tile_ghost.p)
     // one rank: the force sweep reads a ghost's fp through its owner (no fp halo launch); mmd_force_eam_download_fp completes the array
     // one rank, ghosts named by owner + image code in the candidate lists (Integrate::run sets resolve_now on steps without re-neighboring):
     // both sweeps stage the ghosts from their owners — no Comm::communicate launch in front, no fp halo between them

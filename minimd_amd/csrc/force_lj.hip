@@ -480,11 +480,10 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     const int* __restrict__ tile_list,
     const unsigned short* __restrict__ nl16, const unsigned short* __restrict__ tile_self, int nlocal, int nall, int maxneighs, int pos_bytes,
     LJParams P, real* __restrict__ f, double* __restrict__ partials, int ablate_arg, const int* __restrict__ ghost_root,
-    const int* __restrict__ cand_src, const real* __restrict__ box_dev)
+    const int* __restrict__ cand_src, const real* __restrict__ box_dev, const int* __restrict__ tile_ghost)
 {
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   constexpr int UNR = 8, NT = 128, STG = 4;
-  constexpr bool packed = SRC != 0;
   extern __shared__ __align__(16) unsigned char s_raw[];
   real* sp = (real*)s_raw;
   // accumulators are doubles in both precisions: ds_add_f64 runs ~8x faster than ds_add_f32 on this part (measured: 0.10 vs
@@ -504,6 +503,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
   const int tile = tile_list ? tile_list[witem] : witem;
   // three round trips (see k_lj_full_tile): header scalars; candidate indices + own atom index + first slots; positions
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile], kmax = tile_max[tile];
+  const bool packed = SRC != 0 && tile_ghost[tile] != 0;      // (the second list exists for tiles with a ghost candidate only; workgroup-uniform)
   const int* __restrict__ cl = (packed ? cand_src : tile_cand) + (size_t)tile * cstride;
   // what the flush needs of a candidate: the atom whose force collects its share (packed: the owner; a ghost without ghost newton: nobody = nall)
   auto flush_index = [&](int j) { return !packed ? j : ((GN || ((unsigned)j >> MMD_SRC_BITS) == 0u) ? (j & MMD_SRC_MASK) : nall); };
@@ -871,7 +871,7 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       hipLaunchKernelGGL((k_lj_half_tile<EVv, Gv, Sv>), dim3(xcd_grid(CNT)), dim3(128), lds, h->stream, h->x.p, h->binned.p,          \
                          h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, CNT, LIST,  \
                          h->nl16.p, h->tile_self.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,            \
-                         h->partials.p, h->opt_ablate, h->fold_reverse_now ? (const int*)h->ghost_root.p : (const int*)nullptr, src_p, box_p)
+                         h->partials.p, h->opt_ablate, h->fold_reverse_now ? (const int*)h->ghost_root.p : (const int*)nullptr, src_p, box_p, (const int*)h->tile_ghost.p)
 #define HT(EVv, Gv, LIST, CNT) if(ev == EVv && gn == Gv && (CNT) > 0) { if(src_p) HTS(EVv, Gv, 1, LIST, CNT); else HTS(EVv, Gv, 0, LIST, CNT); }
 #define HT4(LIST, CNT) { HT(0, 0, LIST, CNT); HT(0, 1, LIST, CNT); HT(1, 0, LIST, CNT); HT(1, 1, LIST, CNT); }
     if(h->halo_pending) {

@@ -959,6 +959,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
 {
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   nall = deferred_count(nall, nlocal, nghost_dev);
+  const bool cand_src_wanted = cand_src != nullptr;
   __shared__ int rng_start[NB_MAX_ROWS], rng_len[NB_MAX_ROWS];
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
@@ -1025,6 +1026,13 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float by0 = key_float(wave_min_u(owned ? ky : 0xffffffffu)), by1 = key_float(wave_max_u(owned ? ky : 0u));
   const float bz0 = key_float(wave_min_u(owned ? kz : 0xffffffffu)), bz1 = key_float(wave_max_u(owned ? kz : 0u));
   const float cull = (float)cutneighsq * 1.001f + 1.0e-4f;
+  // the second candidate list (ghosts named by owner + image code) is written only for tiles that can have a ghost among their candidates: those
+  // whose atoms come within the cutoff of a face of the (one-rank) box — a superset of the tiles tile_ghost will flag; the tile kernels read it for those only
+  if(cand_src != nullptr) {
+    const float m = 1.001f * (float)cutneigh + 1.0e-3f * (float)g.prd[0] * 1.0e-3f + 1.0e-4f;
+    const bool near_face = bx0 - m < 0.0f || bx1 + m > (float)g.prd[0] || by0 - m < 0.0f || by1 + m > (float)g.prd[1] || bz0 - m < 0.0f || bz1 + m > (float)g.prd[2];
+    if(!near_face) cand_src = nullptr;
+  }
   // PF: local origin = the box's lower corner (exact in `real`); |local coordinate| of my atom and of every candidate that
   // survives the cull is <= Lmax, which bounds the float error of the pre-test's rsq
   // (DOT: the box's centre — halves the magnitudes that enter the products)
@@ -1407,6 +1415,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     tile_cand[cbase + min(S, cstride - 1)] = nall;          // the dummy atom closes the list
     if(cand_src != nullptr) cand_src[cbase + min(S, cstride - 1)] = nall;
     tile_ghost[tile] = any_ghost ? 1 : 0;
+    if(any_ghost && cand_src == nullptr && cand_src_wanted) atomicMax(&flags[3], 1);      // (cannot happen: a ghost candidate without a face in reach — the row build takes over)
     // per-tile results, reduced by k_tile_reduce: 36 k workgroups hammering three global words with atomics cost
     // 0.8 ms at -s 80 (same-address atomics retire one at a time, ~10 ns each)
     tile_rowmax[tile] = maxn;
