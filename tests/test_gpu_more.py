@@ -1427,6 +1427,22 @@ def _two_rank_run(args, port, tmp_path, options="", nprocs=2):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nprocs,args", [(2, ["-s", "12", "-n", "100", "--half_neigh", "0"]), (8, ["-s", "14", "-n", "60", "--half_neigh", "0"]),
+                                         (3, ["-i", "in.eam.miniMD", "-s", "10", "-n", "60", "--half_neigh", "0"]), (4, ["-s", "12", "-n", "60", "--half_neigh", "1"])])
+def test_direct_halo_on_several_ranks_equals_the_swap_by_swap_halo(nprocs, args, port, tmp_path):
+    """2 / 8 / 3 / 4 ranks (2x1x1, 2x2x2, 3x1x1, 2x2x1: partners that are the same rank twice, diagonal partners, dimensions that wrap onto the rank
+    itself): the per-step halo as one exchange with the distinct partners (direct_halo, default) against the three forwarding rounds — the same ghosts in
+    the same slots, so the same rows (half lists: to the order of the atomics) and the same atoms per rank."""
+    a = _two_rank_run(args, port, tmp_path, options="direct_halo=1", nprocs=nprocs)
+    b = _two_rank_run(args, port + 1, tmp_path, options="direct_halo=0", nprocs=nprocs)
+    assert a["counts"] == b["counts"]
+    if "1" == args[-1]:
+        rows_close([tuple(r) for r in a["rows"]], [tuple(r) for r in b["rows"]], 1e-10)
+    else:
+        assert a["rows"] == b["rows"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nprocs,cap", [(2, 8), (4, 2)])
 def test_overflowing_exchange_messages_fall_back_together(nprocs, cap, port, tmp_path):
     """the handshake-free Comm::exchange with messages far too small (exchange_cap records): the sender notices before any atom has
