@@ -122,29 +122,41 @@ def perf_summary_cold(size):
         return {"value": None, "unit": "Matom-steps/s", "cmd": " ".join(cmd), "error": repr(e)}
 
 
+def rank_path_loopback_child(size, steps):
+    """(child process of rank_path_loopback: prints one JSON object)"""
+    import minimd_amd
+    s = minimd_amd.Sim(["-s", size, "--half_neigh", 0, "-n", steps], precision="dp", quiet=True)
+    h = s.handle
+    with stdout_to_stderr():          # (ncclCommInitRank prints RCCL's version banner)
+        h.init_rccl(h.unique_id(), 0, 1)
+    h.set_option("force_transport", 1)
+    s.initial()
+    s.run_steps(40)
+    t_w = time.perf_counter()
+    while (time.perf_counter() - t_w) < 0.3:
+        h.profile_kernel(0, 50)
+    best = min(s.run_steps(steps) for _ in range(2))
+    st = h.run_stats()
+    nat = s.natoms()
+    s.close()
+    print(json.dumps({"value": nat * steps / best / 1e6, "unit": "Matom-steps/s", "ms_per_step": best * 1e3 / steps, "steps": steps,
+                      "halo_bytes_per_step": st["bytes_sent"] / steps,
+                      "note": "one rank, self swaps through RCCL loop-back on one GPU (no xGMI transfer)"}), flush=True)
+
+
 def rank_path_loopback(size, steps):
     """What the multi-GPU step costs a rank apart from the wire, measured on THIS one GPU: the same workload on one rank whose periodic self swaps are
     routed through RCCL (option force_transport: direct halo packed, sent to itself with ncclSend/ncclRecv, unpacked; borders and exchange through
     their fixed-size messages; halo on the communication stream under the interior tiles) — the code path of a rank inside `--gpus 8`, xGMI transfer
-    time excepted. A diagnostic next to `value` (which is the production one-rank path), never instead of it."""
-    import minimd_amd
+    time excepted. A diagnostic next to `value` (which is the production one-rank path), never instead of it. Runs as a process of its own with a
+    time limit: whatever happens in there, the bench line is printed."""
     try:
-        s = minimd_amd.Sim(["-s", size, "--half_neigh", 0, "-n", steps], precision="dp", quiet=True)
-        h = s.handle
-        with stdout_to_stderr():          # (ncclCommInitRank prints RCCL's version banner: stdout carries the ONE JSON line only)
-            h.init_rccl(h.unique_id(), 0, 1)
-        h.set_option("force_transport", 1)
-        s.initial()
-        s.run_steps(40)
-        t_w = time.perf_counter()
-        while (time.perf_counter() - t_w) < 0.3:
-            h.profile_kernel(0, 50)
-        best = min(s.run_steps(steps) for _ in range(2))
-        st = h.run_stats()
-        nat = s.natoms()
-        s.close()
-        return {"value": nat * steps / best / 1e6, "unit": "Matom-steps/s", "ms_per_step": best * 1e3 / steps, "steps": steps,
-                "halo_bytes_per_step": st["bytes_sent"] / steps, "note": "one rank, self swaps through RCCL loop-back on one GPU (no xGMI transfer)"}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--loopback-child", "--size", str(size), "--steps", str(steps)],
+                           capture_output=True, text=True, timeout=240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"value": None, "error": (r.stderr or r.stdout)[-300:]}
+        return json.loads(line[-1])
     except Exception as e:  # noqa: BLE001
         return {"value": None, "error": repr(e)[:300]}
 
@@ -161,11 +173,15 @@ def main():
                                                           "K steps), all of them are listed in `value_windows` so that a short window shows its spread")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold run of the drop-in executable (perf_summary_cold)")
     ap.add_argument("--no-loopback", action="store_true", help="skip the one-GPU measurement of the multi-rank code path (rank_path_loopback)")
+    ap.add_argument("--loopback-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--equil", type=int, default=100, help="untimed equilibration steps before the warm-up (set-up, see the module docstring)")
     ap.add_argument("--clock-warm-ms", type=float, default=400.0,
                     help="set-up: keep the GPU busy this long (force-kernel launches that leave the state untouched) so that the warm-up "
                          "and the timed steps run at settled clocks whatever W is (the chip ramps for >100 ms after idling)")
     args = ap.parse_args()
+    if args.loopback_child:
+        rank_path_loopback_child(args.size, args.steps)
+        return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher — one rank per GPU through torch.distributed.run on a free
