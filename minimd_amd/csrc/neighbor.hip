@@ -229,13 +229,15 @@ __global__ void k_bin_sort(const int* __restrict__ bin_start, int mbins, int* __
     const int s = bin_start[b], e = bin_start[b + 1];
     if(e - s > NB_BIGBIN) *big_flag = 1;                      // (left to k_bin_rank_big; the build is redone with that pass switched on)
     else {
+      int kmin = e > s ? binned[s] : 0x7fffffff;              // (smallest index of the bin, kept in a register: no load behind the sort's stores)
       for(int a = s + 1; a < e; a++) {
         const int key = binned[a];
+        kmin = min(kmin, key);
         int c = a - 1;
         while(c >= s && binned[c] > key) { binned[c + 1] = binned[c]; c--; }
         binned[c + 1] = key;
       }
-      owned = e > s && binned[s] < nlocal;                    // (a bin's entries ascend now: owned atoms first)
+      owned = kmin < nlocal;                                  // (a bin's entries ascend now: owned atoms first)
     }
   }
   if(pencil_lohi == nullptr) return;
@@ -582,7 +584,14 @@ __global__ __launch_bounds__(256) void k_pencil_fill_scan(const int* __restrict_
   int before;
   if(pencil_lohi != nullptr) {
     int v = 0;
-    for(int t = threadIdx.x; t < (int)blockIdx.x * 256; t += 256) { int a0, a1; range_of(t, a0, a1); v += (a1 - a0 + 63) >> 6; }
+    const int nprev = (int)blockIdx.x * 256;
+    for(int t0 = threadIdx.x; t0 < nprev; t0 += 4 * 256) {      // (four pencils per trip: their two dependent loads each overlap)
+      int a0[4], a1[4];
+#pragma unroll
+      for(int u = 0; u < 4; u++) { a0[u] = 0; a1[u] = 0; if(t0 + u * 256 < nprev) range_of(t0 + u * 256, a0[u], a1[u]); }
+#pragma unroll
+      for(int u = 0; u < 4; u++) v += (a1[u] - a0[u] + 63) >> 6;
+    }
     int tot0;
     block_incl_scan(v, lds, &tot0);
     before = tot0;
