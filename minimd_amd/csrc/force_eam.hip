@@ -493,7 +493,7 @@ __global__ __launch_bounds__(64 * EAM_TW) void k_eam_density_tile(
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
   // one rank, full lists (G.cand_src): ghosts are staged from their OWNERS' current positions + the box shift of their image code — the step has
   // no Comm::communicate launch (tile_lds.hpp: GhostResolve); for owned atoms and the dummy the two lists hold the same index
-  const bool packed = SRC != 0 && !HALF && tile_ghost[tile] != 0;      // (the second list exists for tiles with a ghost candidate only; workgroup-uniform)
+  constexpr bool packed = SRC != 0 && !HALF;      // (EAM: the build writes the second list for every tile, so the choice costs the sweeps no registers)
   const int* __restrict__ cl = (packed ? cand_src : tile_cand) + (size_t)tile * cstride;
   const bool stage = !(MMD_ABLATE(C.ablate) & 1);
   int tt[EAM_STAGE], jj[EAM_STAGE];
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   // three round trips (see k_eam_density_tile): header; indices + own atom + first slots; positions + fp
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];
   const int kmax = (MMD_ABLATE(C.ablate) & 2) ? 0 : (use_core ? C.tile_kcore[tile] : tile_max[tile]);
-  const bool packed = SRC != 0 && !HALF && tile_ghost[tile] != 0;       // (see k_eam_density_tile: ghosts named by owner + image code)
+  constexpr bool packed = SRC != 0 && !HALF;       // (see k_eam_density_tile: ghosts named by owner + image code)
   const int* __restrict__ cl = (packed ? cand_src : tile_cand) + (size_t)tile * cstride;
   const bool stage = !(MMD_ABLATE(C.ablate) & 1);
   // one rank: a ghost is an image of an owned atom, its fp is its owner's (ForceEAM::communicate, ref/force_eam.cpp:851-913, folded

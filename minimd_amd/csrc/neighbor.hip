@@ -964,7 +964,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
                                                    int* __restrict__ tile_rowsum, unsigned* __restrict__ tile_words, int* __restrict__ flags, int ablate_arg,
                                                    const int* __restrict__ ntiles_dev, const int* __restrict__ nghost_dev,
                                                    float core_thr, real4* __restrict__ xbuild, int* __restrict__ tile_kcore,
-                                                   int* __restrict__ cand_src, const int* __restrict__ ghost_root)
+                                                   int* __restrict__ cand_src, const int* __restrict__ ghost_root, int cand_src_all)
 {
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   nall = deferred_count(nall, nlocal, nghost_dev);
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float cull = (float)cutneighsq * 1.001f + 1.0e-4f;
   // the second candidate list (ghosts named by owner + image code) is written only for tiles that can have a ghost among their candidates: those
   // whose atoms come within the cutoff of a face of the (one-rank) box — a superset of the tiles tile_ghost will flag; the tile kernels read it for those only
-  if(cand_src != nullptr) {
+  if(cand_src != nullptr && !cand_src_all) {             // (EAM asks for every tile: its sweeps then need no per-tile choice, which costs them registers they do not have)
     const float m = 1.001f * (float)cutneigh + 1.0e-3f * (float)g.prd[0] * 1.0e-3f + 1.0e-4f;
     const bool near_face = bx0 - m < 0.0f || bx1 + m > (float)g.prd[0] || by0 - m < 0.0f || by1 + m > (float)g.prd[1] || bz0 - m < 0.0f || bz1 + m > (float)g.prd[2];
     if(!near_face) cand_src = nullptr;
@@ -1772,7 +1772,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
                      h->ghost_image.p, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
                      h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
                      h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate, nt_dev, h->nghost_dev, \
-                     core_thr, h->xbuild.p, h->tile_kcore.p, cand_src_p, (const int*)h->ghost_root.p)
+                     core_thr, h->xbuild.p, h->tile_kcore.p, cand_src_p, (const int*)h->ghost_root.p, h->style == 1 ? 1 : 0)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         reduce_in_publish = h->opt_spin_readback && h->in_run && h->ntiles <= 4096;
