@@ -216,8 +216,8 @@ static int ev_collect(mmd_handle* h, bool sync = true)
     HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
     switch(h->ev_pool[i].kind) {
       case 0: h->force_ms += ms; h->force_launches++; break;
-      case 4: h->force_ms_all += ms; h->force_launches_all++; break;      // Force::compute of overlapped steps (its two launches bracketed; every 4th such step)
-      case 5: h->halo_ms += ms; break;                                    // forward halo of a step (every 4th step: an event pair costs the stream two marker packets)
+      case 4: h->force_ms_all += ms; h->force_launches_all++; break;      // Force::compute of overlapped steps (its two launches bracketed; every 7th such step)
+      case 5: h->halo_ms += ms; break;                                    // forward halo of a step (every 7th step: an event pair costs the stream two marker packets)
       case 1: h->comm_ms += ms; break;
       case 2: h->timer[1] += ms * 1e-3; h->timer[4] += ms * 1e-3; break;     // ref/integrate.cpp:155-166
       default: h->timer[3] += ms * 1e-3; break;
@@ -232,11 +232,12 @@ static int ev_collect(mmd_handle* h, bool sync = true)
 static int force_compute_async(mmd_handle* h, int evflag, double* eng, double* vir, bool timed)
 {
   if(timed) {
-    // the kernel clock is read on every `time_force_sample`-th call of a run (3: coprime with the re-neighboring and thermo
+    // the kernel clock is read on every `time_force_sample`-th call of a run (3 or 7: coprime with the re-neighboring and thermo
     // periods, so every kind of step is sampled in proportion); TIME_FORCE = mean of the timed calls x number of calls
-    // (time_force_sample 0 = automatic: every call where a launch is long — the pair attached to a dispatch then costs nothing that
-    //  shows —, every 3rd call on small systems, where it is ~15 % of a step)
-    const int every = h->opt_time_sample > 0 ? h->opt_time_sample : (h->ntiles > 8192 || h->nlocal > 600000 ? 1 : 3);
+    // (time_force_sample 0 = automatic = every 7th call, coprime with both periods too: a dispatch that carries the pair sits 6.6 us behind its
+    //  predecessor and 4.5 us in front of its successor, which otherwise follow each other without a gap — its completion signal and time
+    //  stamps; tools/steps_probe.sh. On every call that is 5 % of a step at -s 80 and 40 % at -s 32, on every 7th 0.7 % and 6 %)
+    const int every = h->opt_time_sample > 0 ? h->opt_time_sample : 7;
     timed = every <= 1 || h->force_calls % every == 0;
     h->force_calls++;
   }
@@ -367,9 +368,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       if(overlap && (h->style == 0 ? (mmd_lj_tiles_available(h) || mmd_lj_half_tiles_available(h)) : mmd_eam_can_fuse_integrate(h))) {
         // halo of this step on the communication stream, interior tiles (no ghost among their candidates)
         // concurrently on the compute stream
-        // (the clocks of such a step — halo on its stream, the two force launches on theirs — are read on every 4th one: each event pair costs its stream
+        // (the clocks of such a step — halo on its stream, the two force launches on theirs — are read on every 7th one: each event pair costs its stream
         //  two marker packets, ~5 us of idle GPU apiece, and a step has two pairs)
-        const bool timed_step = time_halo && (halo_calls % 4 == 0);
+        const bool timed_step = time_halo && (halo_calls % 7 == 0);
         halo_calls++;
         if(timed_step) halo_timed++;
         HIP_TRY(hipEventRecord(h->ev_x_ready, h->stream));
@@ -407,7 +408,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       } else if(resolve_half && h->ghost_chain_ok && h->cand_src_ready && mmd_lj_half_tiles_available(h)) {
         h->ghosts_stale = true;                  // (the half-list tile kernel stages the ghosts from their owners; their shares go to the owners)
       } else {
-        const bool timed_step = time_halo && (halo_calls % 4 == 0);
+        const bool timed_step = time_halo && (halo_calls % 7 == 0);
         halo_calls++;
         if(timed_step) { halo_timed++; MMD_TRY(ev_begin(h, 5)); }
         MMD_TRY(mmd_comm_communicate(h));

@@ -294,7 +294,7 @@ struct mmd_handle {
   int opt_lj_original = 0;             // --half_neigh -1: ForceLJ::compute_original (ref/force_lj.cpp:118-176) = the row kernel k_lj_half, not the tile kernel
   int opt_async_counts = 1;            // re-neighboring: list sizes from the previous build, the counts return with the build's flags
   int ntiles_hint = 0;
-  int opt_time_sample = 0;             // force-kernel clock on every n-th Force::compute of a run (0: every call on large systems, every 3rd on small ones)
+  int opt_time_sample = 0;             // force-kernel clock on every n-th Force::compute of a run (0: every 7th)
   int force_calls = 0;
   bool resolve_now = false, ghosts_stale = false;
   hipEvent_t launch_ev_a = nullptr, launch_ev_b = nullptr;     // event pair the next tile-kernel launch attaches to its dispatch
