@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from oracle_lib import Oracle, fmt7, ref_pass_rule
+from conftest import free_port
 from test_gpu_parity import handle_from_oracle, mm, rows_close, sim_rows, REFRUNS, PUBLISHED
 
 pytestmark = pytest.mark.gpu
@@ -1361,7 +1362,7 @@ def test_exchange_all_moves_atoms_two_subdomains_like_the_oracle(port, tmp_path)
     env["MMD_TEST_SAFE"] = "0"
     out2 = str(tmp_path / "ex0.json")
     cmd[cmd.index(out)] = out2
-    cmd[cmd.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
+    cmd[cmd.index("--master-port") + 1] = str(free_port())           # (a port probed now: port + 1 may be somebody's)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert sum(len(q["x"]) for q in json.load(open(out2))) < total
@@ -1434,7 +1435,7 @@ def test_direct_halo_on_several_ranks_equals_the_swap_by_swap_halo(nprocs, args,
     itself): the per-step halo as one exchange with the distinct partners (direct_halo, default) against the three forwarding rounds — the same ghosts in
     the same slots, so the same rows (half lists: to the order of the atomics) and the same atoms per rank."""
     a = _two_rank_run(args, port, tmp_path, options="direct_halo=1", nprocs=nprocs)
-    b = _two_rank_run(args, port + 1, tmp_path, options="direct_halo=0", nprocs=nprocs)
+    b = _two_rank_run(args, free_port(), tmp_path, options="direct_halo=0", nprocs=nprocs)
     assert a["counts"] == b["counts"]
     if "1" == args[-1]:
         rows_close([tuple(r) for r in a["rows"]], [tuple(r) for r in b["rows"]], 1e-10)
