@@ -283,8 +283,8 @@ def main():
     for kv in filter(None, os.environ.get("MMD_BENCH_OPTIONS", "").split(",")):     # A/B knobs, e.g. "build_waves=1,fuse=1"
         k, v = kv.split("=")
         sim.handle.set_option(k, int(v))
-    # the force kernel's clock: every launch of a short timed region (<= 50 steps), every 7th one of a long run (library default; a launch that carries the pair costs 11 us of gaps)
-    timed_every = 1 if args.steps <= 50 else 7
+    # the force kernel's clock: every 7th launch (library default; a launch that carries the event pair costs 11 us of gaps around it: 20 steps are timed by launches 0, 7, 14), every launch of a region shorter than 14 steps
+    timed_every = 7 if args.steps >= 14 else 1
     sim.handle.set_option("time_force_sample", timed_every)
     sim.initial()
     if args.equil > 0:
@@ -388,7 +388,7 @@ def main():
         # new x: +80 B/atom, and skips the f store: -24 B); `achieved` still counts only SURVEY §8d's force-kernel bytes
         "roofline": {"bound": "hbm", "kernel": "k_lj_full_tile (ForceLJ::compute_fullneigh + fused Integrate)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
-                     # `frac` is the in-run figure (events on the timed region's own launches — every launch when --steps <= 50, else every 7th; these launches also carry the
+                     # `frac` is the in-run figure (events on the timed region's own launches — every 7th launch, every launch when --steps < 14; these launches also carry the
                      # integrator); `frac_kernel_only` = SURVEY 8(d)'s force kernel alone on the same thermalised state, 20 launches
                      "frac_in_run": (achieved / HBM_PEAK_GBS) if achieved else None, "launches_timed_every": timed_every,
                      "kernel_only_ms": k_only_ms,
