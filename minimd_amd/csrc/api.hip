@@ -102,7 +102,7 @@ extern "C" int mmd_device_info(mmd_handle* h, char* name, int name_len, int* cu_
 extern "C" int mmd_sync(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
-  HIP_TRY(hipStreamSynchronize(h->stream));        // (the caller's own wait: not one of the run's host synchronisations, mmd_run_stats)
+  HIP_TRY(mmd_stream_wait_polled(h->stream));      // (the caller's own wait: not one of the run's host synchronisations, mmd_run_stats)
   return 0;
 }
 
@@ -202,8 +202,8 @@ static int ovf_end(mmd_handle* h)
 static int ev_collect(mmd_handle* h, bool sync = true)
 {
   if(sync) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if(h->comm_stream) HIP_TRY(hipStreamSynchronize(h->comm_stream));
+    HIP_TRY(mmd_stream_wait_polled(h->stream));
+    if(h->comm_stream) HIP_TRY(mmd_stream_wait_polled(h->comm_stream));
   }
   size_t keep = 0;
   for(size_t i = 0; i < h->ev_used; i++) {

@@ -382,6 +382,19 @@ double mmd_wall();
 
 // every blocking wait on the handle's stream goes through here, so that a run can report how often the host stalled the GPU
 static inline hipError_t mmd_stream_sync(mmd_handle* h) { h->host_syncs++; return hipStreamSynchronize(h->stream); }
+// The caller's wait for the END of a run (Integrate::run's last kernel, mmd_sync): polled. hipStreamSynchronize parks the thread, and waking it
+// costs 20-40 us that the run's own wall clock (TIME_TOTAL, ref/integrate.cpp:84-207 is timed by the host) would count on every call — 1 % of a
+// 20-step slice at -s 80, 7 % at -s 32. A wait that outlasts `spin_s` falls back to the blocking form (nobody burns a core on a long queue).
+static inline hipError_t mmd_stream_wait_polled(hipStream_t st, double spin_s = 0.05)
+{
+  const double t0 = mmd_wall();
+  for(unsigned long spins = 1;; spins++) {
+    const hipError_t e = hipStreamQuery(st);
+    if(e != hipErrorNotReady) return e;
+    (void)hipGetLastError();                   // ("not ready" is reported through the sticky error too)
+    if((spins & 0xff) == 0 && mmd_wall() - t0 > spin_s) return hipStreamSynchronize(st);
+  }
+}
 // (waits of the host-staged test transport — staging a message through host memory — are counted apart: RCCL has none of them)
 static inline hipError_t mmd_stream_sync_transport(mmd_handle* h) { h->transport_syncs++; return hipStreamSynchronize(h->stream); }
 
