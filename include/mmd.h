@@ -171,8 +171,8 @@ typedef void (*mmd_thermo_fn)(void* ctx, int step, double sum_mv2, double eng_vd
 int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int thermo_nstat, mmd_thermo_fn cb, void* ctx);
 /* wall-clock buckets of the last run: TOTAL, COMM, FORCE, NEIGH, TEST(extra) (ref/timer.h:35-40),
  * then GPU-event time of Force::compute (sum ms over the TIMED calls) and the number of timed calls: the clock is read on
- * every call of a run on large systems, on every 3rd one on small systems (option "time_force_sample"); FORCE in out5 is their mean
- * times the number of calls */
+ * every 7th call of a run (option "time_force_sample": a dispatch that carries the event pair costs ~11 us of gaps around it); FORCE in
+ * out5 is their mean times the number of calls */
 int mmd_timers(mmd_handle* h, double out5[5], double* force_kernel_ms, int* force_kernel_launches);
 /* diagnostics of the last mmd_integrate_run on this rank: how often the host blocked on the GPU stream (count handshakes of
  * exchange / borders, list-size read-backs, thermo rows) and how many bytes it sent to OTHER ranks (halos, migrating atoms,
