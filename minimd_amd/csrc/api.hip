@@ -117,6 +117,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "eam_mlo")) h->opt_eam_mlo = value;
   else if(!strcmp(name, "ghost_resolve")) h->opt_ghost_resolve = value;
   else if(!strcmp(name, "time_force_sample")) h->opt_time_sample = value;
+  else if(!strcmp(name, "kernel_dummy")) h->opt_kernel_dummy = value;
   else if(!strcmp(name, "fold_reverse")) h->opt_fold_reverse = value;
   else if(!strcmp(name, "eam_half_rows")) h->opt_eam_half_rows = value;
   else if(!strcmp(name, "eam_fold_fp")) h->opt_eam_fold_fp = value;
@@ -342,7 +343,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // re-neighboring step the neighbor build may issue this launch itself, behind its own kernels (opt_spec, mmd_internal.hpp)
   auto launch_force = [&](int n, int evflag) -> int {
     fused_force = fuse_force && !evflag && n + 1 < ntimes && (h->style == 0 ? mmd_lj_can_fuse_integrate(h) : mmd_eam_can_fuse_integrate(h));
-    if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
+    if(fused_force) MMD_TRY(mmd_prepare_x_alt(h, h->opt_kernel_dummy != 0));
     h->fuse_now = fused_force;
     h->resolve_now = h->ghosts_stale;
     h->fold_reverse_now = folded = fold && h->ghost_chain_ok && mmd_lj_half_tiles_available(h);
@@ -383,7 +384,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
           ovf_timed_now = h->time_force_events && timed_step;
           if(ovf_timed_now) MMD_TRY(ovf_begin(h));
           fused_force = fuse_force && !ev_now && n + 1 < ntimes && mmd_lj_can_fuse_integrate(h);
-          if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
+          if(fused_force) MMD_TRY(mmd_prepare_x_alt(h, h->opt_kernel_dummy != 0));
           h->fuse_now = fused_force;
           const int rc0 = mmd_lj_compute_tiles_split(h, ev_now, 0);
           h->fuse_now = 0;

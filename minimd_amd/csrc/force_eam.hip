@@ -643,6 +643,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;     // persistent workgroups, see k_eam_density_tile
   const bool use_core = eam_use_core(C, lane);
   if(FUSE && C.words_zero != nullptr && blockIdx.x == 0 && tid < 64) C.words_zero[tid] = 0;       // the set the NEXT launch will write
+  if(FUSE && blockIdx.x == 0 && tid == 0) xnew[nall] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};      // (the dummy atom of the buffer this launch fills: no k_set_dummy launch after a re-neighboring)
   float d2max = 0;                                    // FUSE: largest squared displacement since the build over this workgroup's atoms
   for(int tq = blockIdx.x >> 3; tq < per_xcd; tq += wg_per_xcd) {
   const int witem = (blockIdx.x & 7) * per_xcd + tq;          // ntiles = length of the work list (all tiles, or one part of them)

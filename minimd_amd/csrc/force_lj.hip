@@ -202,8 +202,9 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   const int witem = SP.gate != nullptr ? xcd_work_item_of(ntiles) : xcd_work_item(ntiles);
   if(witem < 0) return;                          // (grid is padded to a multiple of 8)
   const int tile = tile_list ? tile_list[witem] : witem;
-  // (a fused launch behind a build: the dummy atom of the second position buffer sits behind the last ghost, whose number only the device knows)
-  if(FUSE && SP.gate != nullptr && witem == 0 && tid == 0) xnew[nall] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
+  // (the dummy atom of the position buffer this launch fills sits behind the last ghost — behind a build only the device knows where that is; every
+  //  fused launch writes it, so no k_set_dummy launch stands between two force kernels after a re-neighboring has moved it: 5 + 5 us)
+  if(FUSE && witem == 0 && tid == 0) xnew[nall] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
   // The tile's loads are issued as three round trips — header scalars; candidate indices + own atom index + first slots; positions —
   // not as the six a straight reading of the steps below would make (indices -> positions -> LDS, then atom index -> position, then slots).
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];     // a tile never straddles pencils

@@ -294,6 +294,7 @@ struct mmd_handle {
   int opt_lj_original = 0;             // --half_neigh -1: ForceLJ::compute_original (ref/force_lj.cpp:118-176) = the row kernel k_lj_half, not the tile kernel
   int opt_async_counts = 1;            // re-neighboring: list sizes from the previous build, the counts return with the build's flags
   int ntiles_hint = 0;
+  int opt_kernel_dummy = 1;            // the fused force kernels write the dummy atom of the position buffer they fill (0: a k_set_dummy launch whenever a re-neighboring has moved it)
   int opt_time_sample = 0;             // force-kernel clock on every n-th Force::compute of a run (0: every 7th)
   int force_calls = 0;
   bool resolve_now = false, ghosts_stale = false;
@@ -368,7 +369,7 @@ int mmd_lj_tiles_available(mmd_handle* h);
 int mmd_lj_half_tiles_available(mmd_handle* h);
 int mmd_lj_can_fuse_integrate(mmd_handle* h);
 int mmd_eam_can_fuse_integrate(mmd_handle* h);
-int mmd_prepare_x_alt(mmd_handle* h);        // second position buffer (capacity + dummy atom) for the fused force+integrate kernel
+int mmd_prepare_x_alt(mmd_handle* h, bool kernel_writes_dummy = false);        // second position buffer (capacity + dummy atom) for the fused force+integrate kernel
 int mmd_lj_compute_tiles_split(mmd_handle* h, int evflag, int part);   // part 0: interior tiles, 1: boundary tiles + energy sum
 int mmd_order_tiles(mmd_handle* h);
 int mmd_ensure_rows(mmd_handle* h);       // materialise `neigh` from the tile form when a kernel needs it

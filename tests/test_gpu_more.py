@@ -998,6 +998,24 @@ def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("args", [["-s", "12", "-n", "90", "--half_neigh", "0"], ["-i", "in.eam.miniMD", "-s", "8", "-n", "70", "--half_neigh", "0"]])
+def test_dummy_atom_written_by_the_fused_kernels(args):
+    """option kernel_dummy (default on): a fused force + integrate launch writes the dummy atom (the far-away partner of the padded list entries) of the
+    position buffer it fills; with 0 a k_set_dummy launch does, whenever a re-neighboring has moved the slot behind the last ghost. Same bits either way
+    over several re-neighborings (the ghost count changes at each of them), LJ and EAM."""
+    res = []
+    for kd in (0, 1):
+        s = mm().Sim(args)
+        s.handle.set_option("kernel_dummy", kd)
+        s.initial(); s.run()
+        d = s.handle.download()
+        res.append((s.rows(), d["x"][:d["nlocal"]].copy(), d["v"].copy()))
+        s.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_force_launch_behind_the_build_changes_nothing(prec):
     """option spec (default on): on a re-neighboring step of a one-rank LJ full-list run Force::compute goes onto the stream behind the
