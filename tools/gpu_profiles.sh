@@ -33,6 +33,9 @@ rm -rf gpurun_out/tl80 gpurun_out/tl32
 { echo "# tools/loopback_trace.py 80 1 under rocprofv3 --kernel-trace: one rank of in.lj.miniMD -s 80 whose self swaps go through RCCL (force_transport), overlap on"; echo "## two plain steps"; python tools/rocpd_steps.py $(find gpurun_out/tllb -name "*.db" | head -1) 1 | head -12; echo "## one re-neighboring"; python tools/rocpd_timeline.py $(find gpurun_out/tllb -name "*.db" | head -1); } > $O/timeline_rank_path_loopback_s80.txt 2>&1
 rm -rf gpurun_out/tllb
 timeout 300 python tools/loopback_probe.py 80 2>&1 | grep "^-s" > $O/rank_path_loopback.txt
+# what the driver runs, three times, and one such slice under the profiler
+for r in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null > $O/bench_driver_shape_$r.json; done
+bash tools/gpu_slice.sh > $O/slice_driver_shape.txt 2>&1
 # keep the merge small: drop the raw rocprof trees, keep logs + summaries
 find $O -name "*.db" -delete; find $O -type d -name "kt_*" -exec rm -rf {} + 2>/dev/null; find $O -mindepth 1 -maxdepth 1 -type d -name "pmc_*" -exec rm -rf {} + 2>/dev/null
 ls -la $O
