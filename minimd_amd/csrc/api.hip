@@ -302,6 +302,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   h->in_run = true;
   // (a previous run that failed mid-step may have left the ghosts one step behind their owners)
   if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }
+  if(first_step == 0) MMD_TRY(mmd_run_reserve(h));      // (no allocation inside the first re-neighborings)
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double t_start = mmd_wall();
   // host-side phase clocks need the device drained at phase boundaries only when a phase is to be

@@ -1858,6 +1858,40 @@ static int borders_fast_finish(mmd_handle* h)
 
 static int borders_general(mmd_handle* h);
 
+// Everything the re-neighborings of a run will ask for, allocated before the run's clock starts (mmd_integrate_run): the device-resident borders sizes
+// its arrays from the previous counts + 50 %, Atom::sort and the fused integrator want second copies of the per-atom arrays — left to their first use they
+// are (re)allocated inside the first two re-neighborings, and a DevArr that grows waits for the stream and frees (670 + 40 us of idle GPU in the
+// first 40 steps of `miniMD -s 80`: 3 % of the 100-step PERF_SUMMARY run). Sizes: what those paths would request, with room for the counts to
+// grow by a third (a melting lattice: +15 % boundary atoms between the first two re-neighborings). Growing later still works, it only costs.
+int mmd_run_reserve(mmd_handle* h)
+{
+  if(h->host_only || h->nlocal <= 0) return 0;
+  const int nlocal = h->nlocal, nghost = std::max(h->nghost, h->prev_nghost);
+  const size_t est_ghost = (size_t)2 * nghost + 8192;
+  MMD_TRY(h->ghost_image.ensure(est_ghost + 8, true, h->stream));
+  MMD_TRY(h->ghost_root.ensure(est_ghost + 8, true, h->stream));
+  MMD_TRY(h->bnd_list.ensure((size_t)nlocal + 8, false, h->stream));
+  for(auto& sw : h->swaps) MMD_TRY(sw.sendlist.ensure((size_t)2 * sw.sendnum + 8192, true, h->stream));
+  const int nt_own = div_up(nlocal, CP_TILE), nt_sw = div_up((long long)h->prev_nb * 2 + est_ghost + 8192, CP_TILE);
+  MMD_TRY(h->flag_tmp.ensure((size_t)std::max({nt_own, 2 * nt_sw, BRD_ROWS * std::max(nt_own, 1) + BRD_ROWS}) + 8, false, h->stream));
+  MMD_TRY(h->bstate.ensure(64, false, h->stream));
+  MMD_TRY(h->brd_bits.ensure((size_t)nlocal + 64, false, h->stream));
+  // second copies: Atom::sort (all four), the fused force + integrate kernels (positions)
+  const size_t need = (size_t)h->nmax + 1;
+  MMD_TRY(h->x_alt.ensure(need, false, h->stream));
+  if(h->sort_every > 0) {
+    MMD_TRY(h->v_alt.ensure(3 * need, false, h->stream));
+    MMD_TRY(h->type_alt.ensure(need, false, h->stream));
+    MMD_TRY(h->tag_alt.ensure(need, false, h->stream));
+  }
+  // the binning of a build behind a deferred borders covers owned atoms + the ghost CAPACITY (the count is still on the device)
+  MMD_TRY(h->atom_bin.ensure(need, false, h->stream));
+  MMD_TRY(h->atom_rank.ensure(need, false, h->stream));
+  MMD_TRY(h->binned.ensure(need, true, h->stream));        // (live: the tiles of the current lists name their atoms through it)
+  if(h->neigh_ready) MMD_TRY(h->pencil_lohi.ensure((size_t)2 * h->bg.nblk[1] * h->bg.nblk[2] + 2, false, h->stream));
+  return 0;
+}
+
 extern "C" int mmd_comm_borders(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }

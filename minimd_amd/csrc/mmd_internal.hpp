@@ -70,6 +70,9 @@ struct DevArr {
   {
     if(n <= cap) return 0;
     size_t ncap = n + n / 8 + 1024;
+#ifdef MMD_DEBUG_REALLOC          // (tools/realloc_probe.py: which arrays still grow inside a run)
+    fprintf(stderr, "ensure: %zu x %zu B -> %zu (had %zu) %s\n", n, sizeof(T), ncap, cap, __PRETTY_FUNCTION__);
+#endif
     T* q = nullptr;
     HIP_TRY(hipMalloc((void**)&q, ncap * sizeof(T)));
     if(preserve && p && cap) {
@@ -358,6 +361,7 @@ int mmd_set_dummy(mmd_handle* h);
 int mmd_box_dev(mmd_handle* h);
 int mmd_dh_exchange(mmd_handle* h, int what);      // direct halo of a step: 0 positions (x), 1 EAM fp; only when h->dh.ready
 int mmd_borders_deferred_finish(mmd_handle* h);
+int mmd_run_reserve(mmd_handle* h);            // buffers the re-neighborings of a run will ask for, before its clock starts (comm.hip)
 int mmd_borders_deferred_resolve(mmd_handle* h);
 int mmd_exclusive_scan(mmd_handle* h, int* data, int n, int* total_host);   // in-place, returns total
 int mmd_exclusive_scan_from(mmd_handle* h, const int* src, int* data, int n, int* total_host);   // src -> data (may alias)
