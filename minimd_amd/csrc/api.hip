@@ -67,7 +67,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   (void)hipDeviceSynchronize();
   h->x.release(); h->x_alt.release(); h->v.release(); h->v_alt.release(); h->f.release(); h->x_stage.release();
   h->type.release(); h->type_alt.release(); h->tag.release(); h->tag_alt.release();
-  h->bin_count.release(); h->bin_start.release(); h->binned.release(); h->scan_tmp.release(); h->atom_bin.release(); h->atom_rank.release();
+  h->bin_count.release(); h->bin_start.release(); h->bin_start_alt.release(); h->binned.release(); h->scan_tmp.release(); h->atom_bin.release(); h->atom_rank.release();
   h->neigh.release(); h->numneigh.release(); h->wave_max.release(); h->ghost_image.release(); h->ghost_root.release();
   h->tile_of_block.release(); h->pencil_range.release(); h->pencil_lohi.release(); h->tile_block.release(); h->tile_first.release(); h->tile_max.release();
   h->tile_cand.release(); h->tile_cand_src.release(); h->box_dev.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
@@ -118,6 +118,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "ghost_resolve")) h->opt_ghost_resolve = value;
   else if(!strcmp(name, "time_force_sample")) h->opt_time_sample = value;
   else if(!strcmp(name, "kernel_dummy")) h->opt_kernel_dummy = value;
+  else if(!strcmp(name, "bin_reuse")) h->opt_bin_reuse = value;
   else if(!strcmp(name, "fold_reverse")) h->opt_fold_reverse = value;
   else if(!strcmp(name, "eam_half_rows")) h->opt_eam_half_rows = value;
   else if(!strcmp(name, "eam_fold_fp")) h->opt_eam_fold_fp = value;
@@ -294,7 +295,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     ~TransientGuard() {
       h->fuse_now = 0; h->resolve_now = false; h->fold_reverse_now = false; h->core.mode_now = 0; h->zero_f_in_integrate = false;
       h->halo_pending = false; h->in_reneighbor = false; h->pbc_defer = false; h->launch_ev_a = h->launch_ev_b = nullptr;
-      h->in_run = false;
+      h->in_run = false; h->bin_owned_valid = false;
       h->spec_fn = nullptr; h->spec = SpecLaunch{nullptr, nullptr, nullptr}; h->spec_done = false;
       h->ovf_open = false;
     }
@@ -565,6 +566,7 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "eam_wg_force")) *value = h->eam_diag[3];
   else if(!strcmp(name, "tile_cmax")) *value = h->tile_cmax;
   else if(!strcmp(name, "rows_uploaded")) *value = h->rows_uploaded ? 1 : 0;
+  else if(!strcmp(name, "bin_reuses")) *value = h->bin_reuses;        // build binnings that placed the ghosts only (owned atoms taken from the binning of Atom::sort)
   else if(!strcmp(name, "spec_runs")) *value = h->spec_runs;          // Force::compute launches issued behind a neighbor build ...
   else if(!strcmp(name, "spec_fails")) *value = h->spec_fails;        // ... and how many of them the build's verdict turned into no-ops
   else { mmd_set_error("mmd_get_counter: unknown counter '%s'", name); return -1; }

@@ -1888,6 +1888,7 @@ int mmd_run_reserve(mmd_handle* h)
   MMD_TRY(h->atom_bin.ensure(need, false, h->stream));
   MMD_TRY(h->atom_rank.ensure(need, false, h->stream));
   MMD_TRY(h->binned.ensure(need, true, h->stream));        // (live: the tiles of the current lists name their atoms through it)
+  if(h->neigh_ready && h->opt_bin_reuse) MMD_TRY(h->bin_start_alt.ensure((size_t)h->bg.mbins + 8, false, h->stream));
   if(h->neigh_ready) MMD_TRY(h->pencil_lohi.ensure((size_t)2 * h->bg.nblk[1] * h->bg.nblk[2] + 2, false, h->stream));
   return 0;
 }

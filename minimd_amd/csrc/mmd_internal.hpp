@@ -167,7 +167,7 @@ struct mmd_handle {
   int halfneigh = 0, ghost_newton = 0, ntypes = 1;
   BinGeom bg;                // device bins (= the reference's unless those are too fine for the build kernels, mmd_neighbor_setup)
   BinGeom bg_ref;            // the reference's bins (Neighbor::setup)
-  DevArr<int> bin_count, bin_start, binned, scan_tmp, atom_bin;
+  DevArr<int> bin_count, bin_start, bin_start_alt, binned, scan_tmp, atom_bin;
   DevArr<int> atom_rank;       // arrival rank of each atom inside its bin (k_bin_count)
   int maxneighs = 100;       // row stride (multiple of MMD_UNROLL)
   DevArr<int> neigh, numneigh, wave_max;
@@ -290,6 +290,8 @@ struct mmd_handle {
   const int* nghost_dev = nullptr;     // != nullptr: one-rank borders enqueued, ghost count still on the device (nghost holds a bound)
   int bf_est_nb = 0;
   bool pbc_defer = false, pbc_pending = false;     // Atom::pbc folded into the binning pass of the Atom::sort that follows
+  // the binning Atom::sort did inside this re-neighboring left the owned atoms in bin order and their counts in the histogram: the build's binning places the ghosts only (mmd_bin_atoms)
+  bool bin_owned_valid = false; int bin_owned_n = 0, bin_owned_mbins = 0; int opt_bin_reuse = 1; long long bin_reuses = 0;
   int bin_count_clean = -1;            // mbins for which bin_count is known to be all zero (k_bin_sort leaves it so)
   int opt_core_pct = 30;               // EAM full lists on one rank: rows in two parts, the core part ends this many per cent into the skin (0: off)
   bool zero_f_in_integrate = false;    // Integrate::run, one-rank half lists: k_final_initial_integrate clears f behind itself

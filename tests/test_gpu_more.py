@@ -998,6 +998,37 @@ def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("args", [["-s", "14", "-n", "130", "--half_neigh", "0"], ["-s", "12", "-n", "90", "--half_neigh", "1"],
+                                  ["-i", "in.eam.miniMD", "-s", "8", "-n", "70", "--half_neigh", "0"], ["-s", "6", "-b", "1", "-n", "50", "--half_neigh", "0"]])
+def test_build_binning_that_places_the_ghosts_only(args):
+    """option bin_reuse (default on): inside a re-neighboring the owned atoms are in bin order once Atom::sort has run, and the histogram still holds their
+    counts; the build's Neighbor::binatoms (ref/neighbor.cpp:215-268) then counts and places the ghosts only and writes the owned part of every bin from
+    the sort's bin starts. The same `binned`, so the same lists and the same bits as binning everything again (bin_reuse 0): full and half lists, EAM,
+    and `-b 1` (every atom in one bin: the long-bin path, which never reuses)."""
+    res = []
+    for br in (0, 1):
+        s = mm().Sim(args)
+        s.handle.set_option("bin_reuse", br)
+        s.initial(); s.run()
+        d = s.handle.download()
+        res.append((s.rows(), d["x"][:d["nlocal"]].copy(), d["v"].copy(), d["tag"].copy(), s.handle.neighbor_info()["total"], s.handle.counter("bin_reuses")))
+        s.close()
+    assert res[0][5] == 0
+    if "-b" in args:
+        assert res[1][5] == 0
+    else:
+        assert res[1][5] >= 3
+    assert res[0][4] == res[1][4]
+    if args[-1] == "1" and "--half_neigh" in args:            # (half lists: the forces are sums of atomics, equal to their order)
+        rows_close(res[0][0], res[1][0], 1e-10)
+        assert np.array_equal(res[0][3], res[1][3]) and np.allclose(res[0][1], res[1][1], rtol=0, atol=1e-9)
+    else:
+        assert res[0][0] == res[1][0]
+        for a_, b_ in zip(res[0][1:4], res[1][1:4]):
+            assert np.array_equal(a_, b_)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("args", [["-s", "12", "-n", "90", "--half_neigh", "0"], ["-i", "in.eam.miniMD", "-s", "8", "-n", "70", "--half_neigh", "0"]])
 def test_dummy_atom_written_by_the_fused_kernels(args):
     """option kernel_dummy (default on): a fused force + integrate launch writes the dummy atom (the far-away partner of the padded list entries) of the
