@@ -286,6 +286,10 @@ def main():
     # the force kernel's clock: every 7th launch (library default; a launch that carries the event pair costs 11 us of gaps around it: 20 steps are timed by launches 0, 7, 14), every launch of a region shorter than 14 steps
     timed_every = 7 if args.steps >= 14 else 1
     sim.handle.set_option("time_force_sample", timed_every)
+    # torch's own HIP context comes up at the first torch.cuda call: have that happen HERE, not inside the first fence() in front of the timed region
+    # (the GPU would idle for the time it takes and start the first window with its clocks on the way down)
+    if torch.cuda.is_available() and not os.environ.get("MMD_BENCH_LATE_TORCH"):       # (the variable: A/B of this very line)
+        torch.cuda.synchronize()
     sim.initial()
     if args.equil > 0:
         sim.run_steps(args.equil)
