@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import random
 import socket
 import subprocess
 import sys
@@ -186,9 +187,21 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher — one rank per GPU through torch.distributed.run on a free
         # loop-back port; the ranks' stdout (rank 0's single JSON line) passes straight through
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
+        # (a port below the kernel's ephemeral range: one handed out by bind(0) can become the source port of somebody's outgoing connection before the rendezvous listens on it)
+        port = 0
+        for _try in range(64):
+            cand = random.randint(20000, 29999)
+            with socket.socket() as so:
+                try:
+                    so.bind(("127.0.0.1", cand))
+                    port = cand
+                    break
+                except OSError:
+                    pass
+        if not port:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))

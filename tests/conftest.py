@@ -18,7 +18,18 @@ def pytest_configure(config):
 def free_port():
     """a loop-back TCP port nobody listens on right now (multi-process tests rendezvous there: a fixed number is a
     spurious red on a shared box)"""
+    import random
     import socket
+    # below the kernel's ephemeral range (32768-60999): a port handed out by bind(0) can be taken as the SOURCE port of somebody's outgoing
+    # connection (the gloo meshes of 8-rank tests open dozens) between this probe and the rendezvous server's listen() — seen as EADDRINUSE
+    for _ in range(64):
+        p = random.randint(20000, 29999)
+        with socket.socket() as so:
+            try:
+                so.bind(("127.0.0.1", p))
+                return p
+            except OSError:
+                continue
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         return so.getsockname()[1]

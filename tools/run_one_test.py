@@ -17,6 +17,7 @@ import argparse
 import json
 import math
 import os
+import random
 import socket
 import subprocess
 import sys
@@ -85,9 +86,21 @@ def run_one(exe, nprocs, nt, size, nsteps, neighlist, ghostcomm, inp, quiet=Fals
     if nprocs == 1:
         outs = [subprocess.run(argv, cwd=cwd, capture_output=True, text=True)]
     else:
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
+        # (a port below the kernel's ephemeral range: one handed out by bind(0) can become the source port of somebody's outgoing connection before the rendezvous listens on it)
+        port = 0
+        for _try in range(64):
+            cand = random.randint(20000, 29999)
+            with socket.socket() as so:
+                try:
+                    so.bind(("127.0.0.1", cand))
+                    port = cand
+                    break
+                except OSError:
+                    pass
+        if not port:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
         procs = []
         for r in range(nprocs):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(nprocs), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
