@@ -118,6 +118,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "ghost_resolve")) h->opt_ghost_resolve = value;
   else if(!strcmp(name, "time_force_sample")) h->opt_time_sample = value;
   else if(!strcmp(name, "kernel_dummy")) h->opt_kernel_dummy = value;
+  else if(!strcmp(name, "fuse_final")) h->opt_fuse_final = value;
   else if(!strcmp(name, "bin_reuse")) h->opt_bin_reuse = value;
   else if(!strcmp(name, "fold_reverse")) h->opt_fold_reverse = value;
   else if(!strcmp(name, "eam_half_rows")) h->opt_eam_half_rows = value;
@@ -335,6 +336,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   const bool resolve_half = h->opt_ghost_resolve && !overlap && h->opt_fuse && !h->opt_force_transport && h->style == 0 && h->halfneigh && h->nprocs == 1 &&
                             !h->opt_lj_original && (!h->ghost_newton || fold);
   bool fused_force = false;          // this step's force launch carries finalIntegrate + the next initialIntegrate
+  bool final_fused = false;          // this (last) step's force launch carries finalIntegrate
   if(overlap && !h->ev_x_ready) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_x_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
@@ -345,8 +347,10 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // re-neighboring step the neighbor build may issue this launch itself, behind its own kernels (opt_spec, mmd_internal.hpp)
   auto launch_force = [&](int n, int evflag) -> int {
     fused_force = fuse_force && !evflag && n + 1 < ntimes && (h->style == 0 ? mmd_lj_can_fuse_integrate(h) : mmd_eam_can_fuse_integrate(h));
+    // the last step of a run (LJ tile kernel): finalIntegrate inside the force launch — no k_final_integrate pass over f and v behind it
+    final_fused = fuse_force && !evflag && n + 1 == ntimes && h->style == 0 && h->opt_fuse_final && mmd_lj_can_fuse_integrate(h);
     if(fused_force) MMD_TRY(mmd_prepare_x_alt(h, h->opt_kernel_dummy != 0));
-    h->fuse_now = fused_force;
+    h->fuse_now = fused_force ? 1 : (final_fused ? 2 : 0);
     h->resolve_now = h->ghosts_stale;
     h->fold_reverse_now = folded = fold && h->ghost_chain_ok && mmd_lj_half_tiles_available(h);
     h->core.mode_now = core_next;                // rows in two parts (CoreRows): which part this call may walk
@@ -509,7 +513,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       h->zero_f_in_integrate = false;
       MMD_TRY(rci);
       initial_done = true;
-    } else MMD_TRY(mmd_integrate_final(h));
+    } else if(final_fused) final_fused = false;      // (the launch did it)
+    else MMD_TRY(mmd_integrate_final(h));
     if(collect_pending) { MMD_TRY(ev_collect(h, false)); collect_pending = false; }      // host work under the force kernel
     if(evflag) {
       MMD_TRY(mmd_temperature_async(h, 2));

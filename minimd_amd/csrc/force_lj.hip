@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
   const int tile = tile_list ? tile_list[witem] : witem;
   // (the dummy atom of the position buffer this launch fills sits behind the last ghost — behind a build only the device knows where that is; every
   //  fused launch writes it, so no k_set_dummy launch stands between two force kernels after a re-neighboring has moved it: 5 + 5 us)
-  if(FUSE && witem == 0 && tid == 0) xnew[nall] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
+  if(FUSE == 1 && witem == 0 && tid == 0) xnew[nall] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
   // The tile's loads are issued as three round trips — header scalars; candidate indices + own atom index + first slots; positions —
   // not as the six a straight reading of the steps below would make (indices -> positions -> LDS, then atom index -> position, then slots).
   const int ncand = tile_ncand[tile], cnt = tile_cnt[tile], first = tile_first[tile];     // a tile never straddles pencils
@@ -346,13 +346,14 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     for(int q = 0; q < LJ_TILE_WAVES - 1; q++) { const real* d = s_f + 3 * 64 * q; fx += d[lane]; fy += d[64 + lane]; fz += d[128 + lane]; }
     fx *= c_out; fy *= c_out; fz *= c_out;
     // (a fused step consumes the force here; f[] is next read after the unfused thermo / last step, which stores it)
-    if(!FUSE) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
+    // (FUSE = 2, the LAST step of a run: finalIntegrate only — the state the caller gets back is that of a whole step, forces included)
+    if(FUSE != 1) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
     if(FUSE) {
       real vx = vx0, vy = vy0, vz = vz0;
       vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
-      vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
+      if(FUSE == 1) { vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz); }
       v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
-      xnew[i] = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
+      if(FUSE == 1) xnew[i] = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
     }
   }
   if(EV) {
@@ -766,7 +767,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   const int nlocal = h->nlocal;
   const int ev = evflag ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
   bool launched = false;
-  const int fz = h->fuse_now ? 1 : 0;
+  const int fz = h->fuse_now;                    // 0: force only, 1: + finalIntegrate + the next initialIntegrate, 2: + finalIntegrate (last step of a run)
   // the caller's event pair rides ON the dispatch (start/stop stamps of the kernel itself): timing a step's force kernel costs the
   // stream no marker packets (a bracketing hipEventRecord pair costs ~6 us per step, 15 % of a -s 32 step)
   hipEvent_t kev_a = h->launch_ev_a, kev_b = h->launch_ev_b;
@@ -774,7 +775,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   GhostResolve G{nullptr, nullptr, nullptr, {h->prd[0], h->prd[1], h->prd[2]}, nullptr};
   if(h->resolve_now) { G.root = h->ghost_root.p; G.image = h->ghost_image.p; G.tile_ghost = h->tile_ghost.p; G.cand_src = h->cand_src_ready ? h->tile_cand_src.p : nullptr; }
   const SpecLaunch SP = list == nullptr ? h->spec : SpecLaunch{nullptr, nullptr, nullptr};
-  if(SP.gate != nullptr) { h->spec_launches++; h->spec_fused = fz != 0; }
+  if(SP.gate != nullptr) { h->spec_launches++; h->spec_fused = fz == 1; }
 #define TK(EVv, Xv, Wv, Uv, Rv, Fv) if(!launched && ev == EVv && ex == Xv && tw == Wv && tu == Uv && rd == Rv && fz == Fv) { launched = true;  \
     hipExtLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv, Rv, Fv>), dim3(xcd_grid(count)), dim3(64 * Wv),                    \
                        pos_bytes + lj_tile_sf_bytes(Wv) + 16 * sizeof(double), h->stream, kev_a, kev_b, 0, h->x.p,                   \
@@ -782,8 +783,8 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
                        count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,              \
                        h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce, G, SP); }
   const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = ex ? (h->opt_tile_read == 1 ? 1 : 0) : h->opt_tile_read;   // (exact division: one divide per pair)
-  TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
-  TK(0, 0, 2, 8, 3, 1); TK(0, 0, 2, 8, 3, 0); TK(1, 0, 2, 8, 3, 0);                              // tile_read=3: the same with three separate 8-byte LDS reads per pair
+  TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 2); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
+  TK(0, 0, 2, 8, 3, 1); TK(0, 0, 2, 8, 3, 2); TK(0, 0, 2, 8, 3, 0); TK(1, 0, 2, 8, 3, 0);                              // tile_read=3: the same with three separate 8-byte LDS reads per pair
   TK(0, 0, 2, 8, 0, 1);                                                                          // production, integrator fused
   TK(0, 0, 2, 8, 0, 0); TK(1, 0, 2, 8, 0, 0); TK(0, 1, 2, 8, 0, 0); TK(1, 1, 2, 8, 0, 0);        // production shape (+ exact-division check)
   TK(0, 0, 2, 8, 1, 0); TK(1, 0, 2, 8, 1, 0);

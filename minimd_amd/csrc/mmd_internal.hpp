@@ -299,6 +299,7 @@ struct mmd_handle {
   int opt_lj_original = 0;             // --half_neigh -1: ForceLJ::compute_original (ref/force_lj.cpp:118-176) = the row kernel k_lj_half, not the tile kernel
   int opt_async_counts = 1;            // re-neighboring: list sizes from the previous build, the counts return with the build's flags
   int ntiles_hint = 0;
+  int opt_fuse_final = 1;              // the last step of a run: finalIntegrate inside the LJ tile force launch (0: k_final_integrate behind it)
   int opt_kernel_dummy = 1;            // the fused force kernels write the dummy atom of the position buffer they fill (0: a k_set_dummy launch whenever a re-neighboring has moved it)
   int opt_time_sample = 0;             // force-kernel clock on every n-th Force::compute of a run (0: every 7th)
   int force_calls = 0;

@@ -998,6 +998,28 @@ def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_final_integrate_inside_the_last_force_launch(prec):
+    """option fuse_final (default on): the last step of a run has no next step to fuse initialIntegrate with; its LJ tile force launch still carries
+    finalIntegrate (v += dtf f with the force in registers) and stores the forces — no k_final_integrate pass behind it. Same bits as the separate
+    kernel (ref/integrate.cpp:59-68), for a run cut into slices of 1, 7 and 20 steps (every slice ends with such a step; the re-neighboring at step 20
+    is the last step of a slice once, launched behind the build) and in one piece."""
+    res = []
+    for ff, cuts in ((0, [47]), (1, [47]), (1, [1, 6, 13, 20, 7])):
+        s = mm().Sim(["-s", "12", "-n", "47", "--half_neigh", "0"], precision=prec)
+        s.handle.set_option("fuse_final", ff)
+        s.initial()
+        for c in cuts:
+            s.run_steps(c)
+        d = s.handle.download()
+        res.append((d["x"][:d["nlocal"]].copy(), d["v"].copy(), d["f"][:3 * d["nlocal"]].copy() if d["f"].ndim == 1 else d["f"][:d["nlocal"]].copy(), d["tag"].copy()))
+        s.close()
+    for other in res[1:]:
+        for a_, b_ in zip(res[0], other):
+            assert np.array_equal(a_, b_)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("args", [["-s", "14", "-n", "130", "--half_neigh", "0"], ["-s", "12", "-n", "90", "--half_neigh", "1"],
                                   ["-i", "in.eam.miniMD", "-s", "8", "-n", "70", "--half_neigh", "0"], ["-s", "6", "-b", "1", "-n", "50", "--half_neigh", "0"]])
 def test_build_binning_that_places_the_ghosts_only(args):
