@@ -296,7 +296,7 @@ def main():
     for kv in filter(None, os.environ.get("MMD_BENCH_OPTIONS", "").split(",")):     # A/B knobs, e.g. "build_waves=1,fuse=1"
         k, v = kv.split("=")
         sim.handle.set_option(k, int(v))
-    # the force kernel's clock: every 7th launch (library default; a launch that carries the event pair costs 11 us of gaps around it: 20 steps are timed by launches 0, 7, 14), every launch of a region shorter than 14 steps
+    # the force kernel's clock: every 7th launch (library default; a launch that carries the event pair costs 11 us of gaps around it: 20 steps are timed by launches 3, 10, 17), every launch of a region shorter than 14 steps
     timed_every = 7 if args.steps >= 14 else 1
     sim.handle.set_option("time_force_sample", timed_every)
     # torch's own HIP context comes up at the first torch.cuda call: have that happen HERE, not inside the first fence() in front of the timed region

@@ -301,6 +301,7 @@ struct mmd_handle {
   int ntiles_hint = 0;
   int opt_fuse_final = 1;              // the last step of a run: finalIntegrate inside the LJ tile force launch (0: k_final_integrate behind it)
   int opt_kernel_dummy = 1;            // the fused force kernels write the dummy atom of the position buffer they fill (0: a k_set_dummy launch whenever a re-neighboring has moved it)
+  int time_phase = 0;                  // which call of every period of opt_time_sample carries the clock (set per run)
   int opt_time_sample = 0;             // force-kernel clock on every n-th Force::compute of a run (0: every 7th)
   int force_calls = 0;
   bool resolve_now = false, ghosts_stale = false;
