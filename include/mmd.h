@@ -182,12 +182,13 @@ int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* bytes_sent, l
 /* read-only diagnostic counters of a handle (since mmd_create): "exchange_fast" / "exchange_overflows" = Comm::exchange calls served by the
  * handshake-free path / finished by the count-handshake path after a fixed-size message overflowed; "borders_fast" / "borders_general" =
  * Comm::borders calls served by the device-resident path / the swap-by-swap path; "device_bins_coarser" = 1 when the device bins coarser than the
- * reference's `-b` grid (mmd_neighbor_setup); "tiles_ready" / "rows_uploaded" = state of the current neighbor list. No reference counterpart. */
+ * reference's `-b` grid (mmd_neighbor_setup); "tiles_ready" / "rows_uploaded" = state of the current neighbor list; "spec_runs" / "spec_fails" = force launches
+ * issued behind a neighbor build / of those the build's verdict turned into no-ops; "bin_reuses" = build binnings that placed the ghosts only. No reference counterpart. */
 int mmd_get_counter(mmd_handle* h, const char* name, long long* value);
 /* time `nrep` launches of one hot kernel with hipEvents on the handle's compute stream.
  * which: 0 = force (current style, evflag=0), 1 = neighbor build, 2 = initial integrate, 3 = final integrate */
 int mmd_profile_kernel(mmd_handle* h, int which, int nrep, double* avg_ms);
-int mmd_set_option(mmd_handle* h, const char* name, int value);       /* tuning knobs, see DESIGN.md */
+int mmd_set_option(mmd_handle* h, const char* name, int value);       /* tuning knobs: the table of DESIGN_HISTORY.md section 4.5 (defaults are the measured best) */
 int mmd_sync(mmd_handle* h);
 
 /* ---------------------------------------------------------------------------------------------
