@@ -241,9 +241,11 @@ static int force_compute_async(mmd_handle* h, int evflag, double* eng, double* v
     //  predecessor and 4.5 us in front of its successor, which otherwise follow each other without a gap — its completion signal and time
     //  stamps; tools/steps_probe.sh. On every call that is 5 % of a step at -s 80 and 40 % at -s 32, on every 7th 0.7 % and 6 %)
     const int every = h->opt_time_sample > 0 ? h->opt_time_sample : 7;
-    // (phase 3 of the period: in a 20-step slice calls 3, 10, 17 — with phase 0 the three samples were the launch behind k_initial_integrate, a plain one and
-    //  the launch behind the neighbor build, which runs 5-20 % longer than a plain step's: a third of the samples instead of a twentieth of the launches)
-    timed = every <= 1 || h->force_calls % every == (every > 3 ? h->time_phase : 0);
+    // (the sampling counter runs on ACROSS mmd_integrate_run calls: a run cut into 20-step slices has every position of the slice — the launch behind
+    //  k_initial_integrate, the plain ones, the launch behind the neighbor build, which runs 5-20 % longer — sampled in proportion over time, instead of
+    //  the same three positions in every slice)
+    timed = every <= 1 || h->force_sample_ctr % every == 0 || (h->force_calls == 0 && h->run_ntimes < every);      // (a run shorter than the period still has its first launch clocked)
+    h->force_sample_ctr++;
     h->force_calls++;
   }
   if(timed && h->time_force_events && h->style == 0 && !h->halfneigh && !h->halo_pending && mmd_lj_tiles_available(h)) {
@@ -289,7 +291,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   for(int i = 0; i < 5; i++) h->timer[i] = 0;
   h->force_ms = 0; h->comm_ms = 0; h->force_launches = 0; h->force_calls = 0; h->ev_used = 0;
   h->force_ms_all = 0; h->force_launches_all = 0; h->halo_ms = 0;
-  h->time_phase = ntimes > 3 ? 3 : 0;             // (a run of fewer than four steps still has its first launch clocked)
+  h->run_ntimes = ntimes;
   long long halo_calls = 0, halo_timed = 0, ovf_calls = 0;
   h->host_syncs = 0; h->halo_bytes = 0; h->transport_syncs = 0;
   // the step loop steers the kernels through transient flags of the handle; whatever way this function is left (an overflowing

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64 * EAM_FW) __attribute__((amdgpu_waves_per_eu(HAL
   int* s_idx = (int*)(s_red + 16);                                     // HALF: the candidates' atom indices, for the flush
   unsigned char* s_gh = (unsigned char*)(s_idx + ((cmax + 2 + 3) & ~3)); // HALF && EV: candidate is a ghost
   for(int t = tid; t < (nr + 1 - mlo) * 7; t += NT) {
-    const int q = (int)(((unsigned)t * 9363u) >> 16);       // t / 7 (exact below 13108)
+    const int q = (int)(((unsigned)t * 74899u) >> 19);      // t / 7 (exact below 57343 = EAM_MAX_STAGE; eam_*tiles_available keep the window shorter)
     const int m = q + mlo, c = t - 7 * q;
     s_tab[q * EAM_FSTRIDE + c] = c < 3 ? rhor_spline[m * 7 + c] : z2r_spline[m * 7 + c];
   }
@@ -968,14 +968,16 @@ static size_t eam_tile_lds_force(const mmd_handle* h)
 static size_t eam_tile_lds_density_half(const mmd_handle* h) { return eam_tile_lds_density(h) + eam_acc_bytes(h->tile_cmax, 1) + (size_t)4 * (h->tile_cmax + 8); }
 static size_t eam_tile_lds_force_half(const mmd_handle* h) { return eam_tile_lds_force(h) + eam_acc_bytes(h->tile_cmax, 3) + (size_t)5 * (h->tile_cmax + 8) + 16; }
 // half lists (without ghost newton) in tile form: third-law scatter through LDS accumulators
+#define EAM_MAX_STAGE 57343        // table words the force sweep may stage: its division by 7 is a multiply + shift that is exact below this
+static bool eam_stage_ok(const mmd_handle* h) { return (long long)(h->nr + 1 - eam_mlo(h)) * 7 < EAM_MAX_STAGE; }
 static bool eam_half_tiles_available(const mmd_handle* h)
 {
-  return h->style == 1 && h->halfneigh && !h->ghost_newton && h->tiles_ready && h->opt_tiles && h->eam_uniform &&
+  return h->style == 1 && eam_stage_ok(h) && h->halfneigh && !h->ghost_newton && h->tiles_ready && h->opt_tiles && h->eam_uniform &&
          eam_tile_lds_force_half(h) <= 144 * 1024 && h->neigh_nlocal == h->nlocal;
 }
 static bool eam_tiles_available(const mmd_handle* h)
 {
-  return h->style == 1 && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->eam_uniform && eam_tile_lds_force(h) <= 144 * 1024 &&
+  return h->style == 1 && eam_stage_ok(h) && !h->halfneigh && h->tiles_ready && h->opt_tiles && h->eam_uniform && eam_tile_lds_force(h) <= 144 * 1024 &&
          h->neigh_nlocal == h->nlocal;
 }
 // the force sweep of the tile path can carry finalIntegrate(n) + initialIntegrate(n+1) (no energy/virial on that step)

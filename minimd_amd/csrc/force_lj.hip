@@ -450,15 +450,16 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_half(const real4* __restrict__
 // ds_add_u32 all retire ~5 lanes per clock and CU, ds_add_f32 an eighth of that), so a pair's x and y shares travel in ONE 64-bit integer
 // atomic: fixed point with 20 fractional bits, x in the high and y in the low 32 bits of V = qx * 2^32 + qy (as a two's-complement sum the
 // fields add independently as long as neither leaves int32: |sum| < 2048). z keeps its double accumulator: 2 instead of 3 LDS atomics per
-// pair. A candidate collects from at most the 64 atoms of the tile, so shares below 2^5 can never overflow a field; a share beyond that
-// (a pair closer than ~0.76 sigma: 100 epsilon up the repulsive wall) goes to global memory directly. Resolution 2^-20 of force / c_out per
+// pair. A candidate collects from at most the 64 atoms of the tile, so shares below 2^4 (+ the own force, below 1000) can never overflow a field; a share beyond that
+// (a pair closer than ~0.8 sigma: far up the repulsive wall) goes to global memory directly. Resolution 2^-20 of force / c_out per
 // share, rounded to nearest (unbiased): ~1e-6 after a row of adds, against ~1e-7 for float sums — far inside the SP parity rule.
 #ifndef LJH_PACK
 #define LJH_PACK (MMD_PRECISION == 1)
 #endif
 #define LJH_FIX_SCALE 1048576.0f          // 2^20
-#define LJH_FIX_SHARE 32.0f               // largest |share| that takes the packed path
-#define LJH_FIX_SUM 1024.0f               // largest |own force / c_out| folded into a packed accumulator
+// a field holds |sum| < 2048: at most 64 shares below 16 (each rounded to 2^-20: <= 1024 together) + the own force below 1000 stay inside it
+#define LJH_FIX_SHARE 16.0f               // largest |share| that takes the packed path
+#define LJH_FIX_SUM 1000.0f               // largest |own force / c_out| folded into a packed accumulator
 __device__ __forceinline__ unsigned long long ljh_pack_xy(float px, float py)
 {
   const long long qx = (long long)__float2int_rn(px * LJH_FIX_SCALE), qy = (long long)__float2int_rn(py * LJH_FIX_SCALE);
@@ -785,7 +786,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = ex ? (h->opt_tile_read == 1 ? 1 : 0) : h->opt_tile_read;   // (exact division: one divide per pair)
   TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 2); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
   TK(0, 0, 2, 8, 3, 1); TK(0, 0, 2, 8, 3, 2); TK(0, 0, 2, 8, 3, 0); TK(1, 0, 2, 8, 3, 0);                              // tile_read=3: the same with three separate 8-byte LDS reads per pair
-  TK(0, 0, 2, 8, 0, 1);                                                                          // production, integrator fused
+  TK(0, 0, 2, 8, 0, 1); TK(0, 0, 2, 8, 0, 2);                                                    // tile_read=0 (one reciprocal per pair), integrator fused / finalIntegrate fused
   TK(0, 0, 2, 8, 0, 0); TK(1, 0, 2, 8, 0, 0); TK(0, 1, 2, 8, 0, 0); TK(1, 1, 2, 8, 0, 0);        // production shape (+ exact-division check)
   TK(0, 0, 2, 8, 1, 0); TK(1, 0, 2, 8, 1, 0);
   TK(0, 0, 4, 8, 0, 0); TK(1, 0, 4, 8, 0, 0);                                                    // tuning shapes

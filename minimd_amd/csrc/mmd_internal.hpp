@@ -301,9 +301,10 @@ struct mmd_handle {
   int ntiles_hint = 0;
   int opt_fuse_final = 1;              // the last step of a run: finalIntegrate inside the LJ tile force launch (0: k_final_integrate behind it)
   int opt_kernel_dummy = 1;            // the fused force kernels write the dummy atom of the position buffer they fill (0: a k_set_dummy launch whenever a re-neighboring has moved it)
-  int time_phase = 0;                  // which call of every period of opt_time_sample carries the clock (set per run)
   int opt_time_sample = 0;             // force-kernel clock on every n-th Force::compute of a run (0: every 7th)
-  int force_calls = 0;
+  int force_calls = 0;                 // Force::compute calls of the current run that went through the sampled clock
+  int run_ntimes = 0;                  // length of the current mmd_integrate_run
+  long long force_sample_ctr = 0;      // the same, never reset: call number modulo the sampling period decides which launches carry the clock
   bool resolve_now = false, ghosts_stale = false;
   hipEvent_t launch_ev_a = nullptr, launch_ev_b = nullptr;     // event pair the next tile-kernel launch attaches to its dispatch
   int opt_borders_fast = 2, opt_borders_est = 150;    // device-resident borders: 0 off, 1 swap by swap (count / scatter pair per dimension), 2 + the three-launch form where every swap is a self swap; its sizing estimate in per cent of the previous counts

@@ -1825,7 +1825,9 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
       // [0..3] results, [4..5] total, [6] tile count, [12] long-bin flag, [16..55] bst of a deferred one-rank borders
-      int spec_cmax_used = 0;
+      int spec_cmax_used = 0, spec_calls_before = 0;
+      size_t spec_ev_before = 0;
+      long long spec_ctr_before = 0;
       int verdict = 0;                    // 1: this step's Force::compute was launched behind the build and the build's verdict let it run
       bool spec_go = false;
       if(h->opt_build == 1 && h->opt_spin_readback && h->in_run) {
@@ -1854,6 +1856,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
           h->spec = SpecLaunch{h->d_flags + NB_GATE_WORD, nt_dev, h->nghost_dev};
           h->spec_fused = false;
           const long long before = h->spec_launches;
+          spec_calls_before = h->force_calls; spec_ctr_before = h->force_sample_ctr; spec_ev_before = h->ev_used;
           const int rc = fn();
           h->spec = SpecLaunch{nullptr, nullptr, nullptr};
           h->tile_cmax = save_cmax; h->tiles_ready = false; h->neigh_nlocal = 0;
@@ -1864,7 +1867,12 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
         }
         MMD_TRY(flags_wait(h));
         h->clk_written |= 4;
-        if(spec_go) { verdict = h->h_flags[NB_GATE_WORD]; if(!verdict) h->spec_fails++; }
+        if(spec_go) {
+          verdict = h->h_flags[NB_GATE_WORD];
+          // a "no": the gated launch did nothing and the step loop launches this step's Force::compute again — the call counter of the kernel clock and
+          // the event pair the no-op may have carried (a 0 ms sample) go back to where they were
+          if(!verdict) { h->spec_fails++; h->force_calls = spec_calls_before; h->force_sample_ctr = spec_ctr_before; h->ev_used = spec_ev_before; }
+        }
       } else {
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, (h->nghost_dev ? 56 : 16) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       if(h->opt_build != 1) HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
