@@ -37,10 +37,11 @@ typedef struct mmd_handle mmd_handle;
 /* ---------------------------------------------------------------------------------------------
  * lifecycle
  * ------------------------------------------------------------------------------------------- */
-/* device: HIP device ordinal, -1 = LOCAL_RANK env (default 0), -2 = host-only handle (geometry functions
+/* device: HIP device ordinal, -1 = the launcher's local rank modulo the visible devices (mmd_launch_env; default 0), -2 = host-only handle (geometry functions
  * only: mmd_atom_set_box, mmd_comm_setup/info, mmd_neighbor_setup/geometry — usable without a GPU). */
 int mmd_create(int device, mmd_handle** out);
 int mmd_destroy(mmd_handle* h);
+int mmd_device_count(void);               /* HIP devices this process sees (0 without a GPU) */
 const char* mmd_last_error(void);
 int mmd_float_size(void);                 /* sizeof(MMD_float): "# Size of float" (ref/ljs.cpp:442) */
 const char* mmd_variant_string(void);     /* counterpart of VARIANT_STRING (ref/variant.h:33) */
@@ -233,10 +234,33 @@ int mmd_eam_tables_from_file(const char* filename, int ntypes, int* nr, int* nrh
 /* ---------------------------------------------------------------------------------------------
  * Whole-program twin of ref/ljs.cpp main(): same CLI, same stdout grammar
  * ------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * Process-level contract of a multi-rank run. The reference asks MPI for rank and size (MPI_Comm_rank / MPI_Comm_size,
+ * ref/ljs.cpp:63-68) and its harness starts `${MPISTART} -np N ./miniMD ...` (ref/run_one_test:50). Without linking MPI the same
+ * launchers work through what they export to their children:
+ *   torchrun RANK / WORLD_SIZE / LOCAL_RANK — Open MPI OMPI_COMM_WORLD_{RANK,SIZE,LOCAL_RANK} — MPICH / Intel MPI (hydra) PMI_RANK /
+ *   PMI_SIZE / MPI_LOCALRANKID — PMIx PMIX_RANK — Slurm SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID   (first match in this order; none: 1 rank).
+ * mmd_launch_rendezvous: MASTER_ADDR / MASTER_PORT when exported, else 127.0.0.1 and a port derived from the launcher's job id (or the
+ * parent's pid), the same on every rank of the job. mmd_mesh_*: the TCP streams the ranks meet on (rank 0 listens on port + 17); the mesh
+ * carries the RCCL id and, when the ranks of a node outnumber its GPUs, is itself the (debug, host-staged) transport: mmd_mesh_sendrecv /
+ * mmd_mesh_allreduce are mmd_sendrecv_fn / mmd_allreduce_fn with the mesh as ctx (MPI_Sendrecv, ref/comm.cpp:291-297; MPI_Allreduce SUM,
+ * ref/thermo.cpp:131-133 — summed in rank order, the same bits on every rank). Host code only: usable without a GPU.
+ * ------------------------------------------------------------------------------------------- */
+int mmd_launch_env(int* rank, int* nranks, int* local_rank, int* local_size, char* launcher, int launcher_len);
+int mmd_launch_rendezvous(char* addr, int addr_len, int* port);
+typedef struct mmd_mesh mmd_mesh;
+int mmd_mesh_create(int rank, int nranks, const char* addr, int port, mmd_mesh** out);
+int mmd_mesh_destroy(mmd_mesh* m);
+int mmd_mesh_allgather(mmd_mesh* m, const void* mine, int nbytes, void* all);
+long long mmd_mesh_sendrecv(void* mesh, const void* sendbuf, long long nsend, int dest, void* recvbuf, long long nrecv_max, int src);
+int mmd_mesh_allreduce(void* mesh, double* vals, int n);
+int mmd_mesh_info(mmd_mesh* m, int* rank, int* nranks, long long* bytes_sent, long long* messages);
+
 typedef struct mmd_sim mmd_sim;
 /* parses argv (ref/ljs.cpp:87-261) + deck, builds the system and uploads it (ref/ljs.cpp:264-443).
- * Multi-GPU: one process per GPU, RANK/WORLD_SIZE/LOCAL_RANK from the environment; the RCCL id is
- * taken from mmd_sim_set_unique_id() if called before, else exchanged over MASTER_ADDR:MASTER_PORT. */
+ * Several ranks: one process per rank, rank / size from mmd_launch_env. Transport, first match: the host callbacks of
+ * mmd_sim_set_host_transport; RCCL with the id of mmd_sim_set_unique_id; otherwise the ranks meet on the mesh and use RCCL when every
+ * rank of every node has a GPU of its own, else (or with MMD_TRANSPORT=tcp) the mesh itself — named in the banner ("# Transport: ..."). */
 int mmd_sim_set_unique_id(const unsigned char id[128]);
 /* use a host-staged transport (see mmd_comm_set_host_transport) for the sims created afterwards */
 int mmd_sim_set_host_transport(mmd_sendrecv_fn sr, mmd_allreduce_fn ar, void* ctx);

@@ -86,6 +86,9 @@ def load_library(precision="dp"):
         "mmd_eam_tables_from_file": [C.c_char_p, I, ip, ip, ip, ip, rp, rp, rp, rp, rp, rp, rp],
         "mmd_sim_set_unique_id": [C.c_char_p], "mmd_sim_set_host_transport": [P, P, P], "mmd_sim_create": [I, C.POINTER(C.c_char_p), I, C.POINTER(P)],
         "mmd_sim_initial": [P], "mmd_sim_run": [P], "mmd_sim_run_steps": [P, I, dp], "mmd_sim_print_perf": [P],
+        "mmd_device_count": [], "mmd_launch_env": [ip, ip, ip, ip, C.c_char_p, I], "mmd_launch_rendezvous": [C.c_char_p, I, ip],
+        "mmd_mesh_create": [I, I, C.c_char_p, I, C.POINTER(P)], "mmd_mesh_destroy": [P], "mmd_mesh_allgather": [P, P, I, P],
+        "mmd_mesh_allreduce": [P, dp, I], "mmd_mesh_info": [P, ip, ip, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
         "mmd_sim_rows": [P, ip, ip, dp, dp, dp, I], "mmd_sim_output": [P, I], "mmd_sim_wants_yaml": [P, ip], "mmd_sim_natoms": [P], "mmd_sim_destroy": [P],
     }
     for name, args in sig.items():
@@ -94,10 +97,12 @@ def load_library(precision="dp"):
         fn.restype = I
     L.mmd_sim_handle.argtypes = [P]
     L.mmd_sim_handle.restype = P
+    L.mmd_mesh_sendrecv.argtypes = [P, P, C.c_longlong, I, P, C.c_longlong, I]
+    L.mmd_mesh_sendrecv.restype = C.c_longlong
     L._creal = creal
     L._real = np.float64 if precision == "dp" else np.float32
     L._Input = _input_struct(creal)
-    L._symbols = list(sig) + ["mmd_sim_handle", "mmd_last_error", "mmd_variant_string"]
+    L._symbols = list(sig) + ["mmd_sim_handle", "mmd_last_error", "mmd_variant_string", "mmd_mesh_sendrecv"]
     _LIBS[precision] = L
     return L
 
@@ -504,6 +509,65 @@ def eam_tables_from_file(path, ntypes=4, precision="dp"):
     return {"nr": nr.value, "nrho": nrho.value, "nr_tot": nrt.value, "nrho_tot": nrhot.value, "rdr": rdr.value, "rdrho": rdrho.value,
             "cutmax": cut.value, "mass": mass.value, "rhor_spline": a, "frho_spline": b, "z2r_spline": c,
             "cutforcesq": np.full(n2, L._real(cut.value) * L._real(cut.value), L._real)}
+
+
+def launch_env(precision="dp"):
+    """rank / size / local rank as the launcher's environment describes them (torchrun, Open MPI, MPICH hydra, PMIx, Slurm: include/mmd.h)"""
+    L = load_library(precision)
+    r, n, lr, ls = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    name = C.create_string_buffer(32)
+    if L.mmd_launch_env(C.byref(r), C.byref(n), C.byref(lr), C.byref(ls), name, 32) < 0:
+        raise MMDError(L.mmd_last_error().decode())
+    return {"rank": r.value, "nranks": n.value, "local_rank": lr.value, "local_size": ls.value, "launcher": name.value.decode()}
+
+
+def launch_rendezvous(precision="dp"):
+    L = load_library(precision)
+    addr = C.create_string_buffer(256)
+    port = C.c_int()
+    if L.mmd_launch_rendezvous(addr, 256, C.byref(port)) < 0:
+        raise MMDError(L.mmd_last_error().decode())
+    return addr.value.decode(), port.value
+
+
+class Mesh:
+    """the executable's built-in TCP mesh (csrc/launch.cpp): rendezvous of the ranks and host-staged debug transport"""
+
+    def __init__(self, rank, nranks, addr="127.0.0.1", port=29500, precision="dp"):
+        self.L = load_library(precision)
+        self.p = C.c_void_p()
+        if self.L.mmd_mesh_create(rank, nranks, addr.encode(), port, C.byref(self.p)) < 0:
+            raise MMDError(self.L.mmd_last_error().decode())
+        self.rank, self.nranks = rank, nranks
+
+    def sendrecv(self, data: bytes, dest: int, nrecv: int, src: int) -> bytes:
+        rbuf = C.create_string_buffer(max(nrecv, 1))
+        got = self.L.mmd_mesh_sendrecv(self.p, data, len(data), dest, rbuf, nrecv, src)
+        if got < 0:
+            raise MMDError(self.L.mmd_last_error().decode())
+        return rbuf.raw[:got]
+
+    def allreduce(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.L.mmd_mesh_allreduce(self.p, a.ctypes.data_as(C.POINTER(C.c_double)), a.size) < 0:
+            raise MMDError(self.L.mmd_last_error().decode())
+        arr[:] = a
+
+    def allgather(self, mine: bytes) -> list:
+        out = C.create_string_buffer(len(mine) * self.nranks)
+        if self.L.mmd_mesh_allgather(self.p, mine, len(mine), out) < 0:
+            raise MMDError(self.L.mmd_last_error().decode())
+        return [out.raw[i * len(mine):(i + 1) * len(mine)] for i in range(self.nranks)]
+
+    def info(self):
+        r, n, b, m = C.c_int(), C.c_int(), C.c_longlong(), C.c_longlong()
+        self.L.mmd_mesh_info(self.p, C.byref(r), C.byref(n), C.byref(b), C.byref(m))
+        return {"rank": r.value, "nranks": n.value, "bytes_sent": b.value, "messages": m.value}
+
+    def close(self):
+        if self.p:
+            self.L.mmd_mesh_destroy(self.p)
+            self.p = C.c_void_p()
 
 
 _SIM_TRANSPORT_KEEP = []

@@ -25,9 +25,10 @@ extern "C" int mmd_create(int device, mmd_handle** out)
     mmd_set_error("mmd_create: no HIP device is visible — this library has no CPU fallback");
     return -2;
   }
-  if(device < 0) {
-    const char* lr = getenv("LOCAL_RANK");
-    device = lr ? atoi(lr) % ndev : 0;
+  if(device < 0) {                // the rank's own device: local rank as the launcher names it (torchrun, mpirun, srun: launch.cpp)
+    int lr = 0;
+    if(mmd_launch_env(nullptr, nullptr, &lr, nullptr, nullptr, 0) < 0) lr = 0;
+    device = lr % ndev;
   }
   if(device >= ndev) { mmd_set_error("mmd_create: device %d out of range (%d visible)", device, ndev); return -1; }
   HIP_TRY(hipSetDevice(device));
@@ -57,6 +58,13 @@ extern "C" int mmd_create(int device, mmd_handle** out)
   memset(h->h_flags, 0, 64 * sizeof(int)); memset(h->h_flags_big, 0, 64 * sizeof(int)); memset(h->h_result, 0, 32 * sizeof(double));
   *out = h;
   return 0;
+}
+
+extern "C" int mmd_device_count(void)
+{
+  int ndev = 0;
+  if(hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return ndev;
 }
 
 extern "C" int mmd_destroy(mmd_handle* h)

@@ -1,6 +1,7 @@
 // minimd_amd/csrc/sim.cpp — whole-program twin of ref/ljs.cpp main(): same command line, same input deck,
 // same stdout grammar (banner, "# Timestep T U P Time" rows, PERF_SUMMARY), driving the device handle
-// through the C-ABI of include/mmd.h. One process per GPU; ranks come from RANK/WORLD_SIZE/LOCAL_RANK.
+// through the C-ABI of include/mmd.h. One process per GPU; rank and size come from the launcher's environment (torchrun, mpirun / mpiexec of
+// Open MPI or MPICH, srun: launch.cpp), the ranks meet over TCP and talk RCCL — or, when they have to share GPUs, the TCP mesh itself (debug transport).
 #include <arpa/inet.h>
 #include <netdb.h>
 #include <netinet/in.h>
@@ -28,6 +29,11 @@ struct mmd_sim {
   mmd_input in;
   std::string input_file = "in.lj.miniMD";
   int me = 0, nprocs = 1, quiet = 0;
+  int local_rank = 0, local_size = 1;
+  char launcher[16] = "single";
+  mmd_mesh* mesh = nullptr;      // rendezvous of the ranks; stays open as the transport when they share GPUs
+  int transport = 0;             // 0 none (one rank), 1 RCCL, 2 caller's host callbacks, 3 built-in TCP mesh (debug)
+  int ngpu_node = 0;
   int num_threads = 1, ntypes = 4, halfneigh = 1, ghost_newton = 1, sort = -1, yaml_output = 0, yaml_screen = 0, check_exchange = 0, safe_exchange = 0;
   int nbin[3] = {1, 1, 1};
   int natoms = 0;
@@ -62,50 +68,6 @@ extern "C" int mmd_sim_set_unique_id(const unsigned char id[128])
   memcpy(g_id, id, 128);
   g_have_id = true;
   return 0;
-}
-
-// minimal rendezvous for the stand-alone executable: rank 0 serves the 128-byte RCCL id on
-// MASTER_ADDR:(MASTER_PORT+17) to the other ranks (torchrun exports both variables)
-static int exchange_id_tcp(int rank, int nranks, unsigned char id[128])
-{
-  const char* addr = getenv("MASTER_ADDR");
-  const char* port_s = getenv("MASTER_PORT");
-  if(!addr) addr = "127.0.0.1";
-  const int port = (port_s ? atoi(port_s) : 29500) + 17;
-  if(rank == 0) {
-    MMD_TRY(mmd_comm_unique_id(id));
-    int ls = socket(AF_INET, SOCK_STREAM, 0);
-    int one = 1;
-    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-    sockaddr_in sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons(port);
-    if(bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || listen(ls, nranks) != 0) { mmd_set_error("rendezvous: cannot listen on port %d", port); close(ls); return -1; }
-    for(int k = 1; k < nranks; k++) {
-      int cs = accept(ls, nullptr, nullptr);
-      if(cs < 0 || write(cs, id, 128) != 128) { mmd_set_error("rendezvous: send failed"); close(ls); return -1; }
-      close(cs);
-    }
-    close(ls);
-    return 0;
-  }
-  for(int attempt = 0; attempt < 600; attempt++) {
-    int s = socket(AF_INET, SOCK_STREAM, 0);
-    sockaddr_in sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.sin_family = AF_INET; sa.sin_port = htons(port);
-    hostent* he = gethostbyname(addr);
-    if(he) memcpy(&sa.sin_addr, he->h_addr_list[0], he->h_length); else inet_pton(AF_INET, addr, &sa.sin_addr);
-    if(connect(s, (sockaddr*)&sa, sizeof(sa)) == 0) {
-      size_t got = 0;
-      while(got < 128) { ssize_t r = read(s, id + got, 128 - got); if(r <= 0) break; got += r; }
-      close(s);
-      if(got == 128) return 0;
-    } else close(s);
-    usleep(100000);
-  }
-  mmd_set_error("rendezvous: rank %d could not reach %s:%d", rank, addr, port);
-  return -1;
 }
 
 static bool is_flag(const char* a, const char* s1, const char* s2 = nullptr) { return !strcmp(a, s1) || (s2 && !strcmp(a, s2)); }
@@ -169,10 +131,12 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
   *out = nullptr;
   mmd_sim* s = new mmd_sim();
   s->quiet = quiet;
-  const char* e;
-  if((e = getenv("RANK"))) s->me = atoi(e);
-  if((e = getenv("WORLD_SIZE"))) s->nprocs = atoi(e);
-  if(s->nprocs < 1) s->nprocs = 1;
+  // rank / size as the launcher describes them (the reference asks MPI, ref/ljs.cpp:63-68)
+  if(mmd_launch_env(&s->me, &s->nprocs, &s->local_rank, &s->local_size, s->launcher, (int)sizeof(s->launcher)) < 0) {
+    printf("ERROR: %s\n", mmd_last_error());
+    delete s;
+    return -1;
+  }
   for(int i = 0; i < argc; i++)
     if(is_flag(argv[i], "-i", "--input_file") && i + 1 < argc) s->input_file = argv[++i];
   if(mmd_input_read(&s->in, s->input_file.c_str())) {
@@ -250,7 +214,11 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
   s->dt = s->in.dt;
 
   if(s->me == 0 && !quiet) printf("# Create System:\n");
-  if(mmd_create(-1, &s->h)) { if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
+  {
+    int ndev = mmd_device_count();
+    s->ngpu_node = ndev;
+    if(mmd_create(ndev > 0 ? s->local_rank % ndev : -1, &s->h)) { if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); delete s; return -1; }
+  }
   mmd_handle* h = s->h;
 #define SIM_TRY(expr) do { if((expr) < 0) { if(s->me == 0 && !quiet) printf("ERROR: %s\n", mmd_last_error()); mmd_sim_destroy(s); return -1; } } while(0)
   if(s->in.has_datafile) {                         // ref/ljs.cpp:387-388
@@ -262,10 +230,50 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
   SIM_TRY(mmd_comm_setup(h, s->in.neigh_cut, s->me, s->nprocs));
   if(s->nprocs > 1 && g_host_sr) {
     SIM_TRY(mmd_comm_set_host_transport(h, g_host_sr, g_host_ar, g_host_ctx));
+    s->transport = 2;
+  } else if(s->nprocs > 1 && g_have_id) {
+    SIM_TRY(mmd_comm_init_rccl(h, g_id, s->me, s->nprocs));
+    s->transport = 1;
   } else if(s->nprocs > 1) {
-    unsigned char id[128];
-    if(g_have_id) memcpy(id, g_id, 128); else SIM_TRY(exchange_id_tcp(s->me, s->nprocs, id));
-    SIM_TRY(mmd_comm_init_rccl(h, id, s->me, s->nprocs));
+    // the ranks meet (launch.cpp) and settle the transport TOGETHER: RCCL when every rank of every node has a device of its own, otherwise — or on
+    // request, MMD_TRANSPORT=tcp — the mesh itself carries the messages, staged through host memory (a debug transport: the reference's np = 3 / 8
+    // validation runs on a one-GPU box). MMD_TRANSPORT=rccl insists on RCCL and fails where it cannot be had.
+    char addr[256];
+    int port = 0;
+    SIM_TRY(mmd_launch_rendezvous(addr, (int)sizeof(addr), &port));
+    SIM_TRY(mmd_mesh_create(s->me, s->nprocs, addr, port, &s->mesh));
+    struct Card { int ndev, local_size, want; unsigned host; } mine, *all;
+    char hn[256] = {0};
+    gethostname(hn, sizeof(hn) - 1);
+    unsigned hh = 2166136261u;
+    for(const char* c = hn; *c; c++) { hh ^= (unsigned char)*c; hh *= 16777619u; }
+    const char* want = getenv("MMD_TRANSPORT");
+    mine = Card{s->ngpu_node, s->local_size, want && !strcmp(want, "tcp") ? 2 : (want && !strcmp(want, "rccl") ? 1 : 0), hh};
+    std::vector<Card> cards(s->nprocs);
+    all = cards.data();
+    SIM_TRY(mmd_mesh_allgather(s->mesh, &mine, (int)sizeof(Card), all));
+    bool gpu_each = true, any_tcp = false, any_rccl = false;
+    for(int r = 0; r < s->nprocs; r++) {
+      int on_host = 0;
+      for(int q = 0; q < s->nprocs; q++) on_host += all[q].host == all[r].host ? 1 : 0;
+      if(on_host > all[r].ndev) gpu_each = false;
+      any_tcp = any_tcp || all[r].want == 2;
+      any_rccl = any_rccl || all[r].want == 1;
+    }
+    if(any_rccl && !gpu_each) { mmd_set_error("MMD_TRANSPORT=rccl, but the ranks of a node outnumber its GPUs (%d ranks, %d visible here)", s->nprocs, s->ngpu_node); SIM_TRY(-1); }
+    if(gpu_each && !any_tcp) {
+      std::vector<unsigned char> ids((size_t)128 * s->nprocs, 0);
+      unsigned char id[128] = {0};
+      if(s->me == 0) SIM_TRY(mmd_comm_unique_id(id));
+      SIM_TRY(mmd_mesh_allgather(s->mesh, id, 128, ids.data()));
+      SIM_TRY(mmd_comm_init_rccl(h, ids.data(), s->me, s->nprocs));
+      mmd_mesh_destroy(s->mesh);
+      s->mesh = nullptr;
+      s->transport = 1;
+    } else {
+      SIM_TRY(mmd_comm_set_host_transport(h, mmd_mesh_sendrecv, mmd_mesh_allreduce, s->mesh));
+      s->transport = 3;
+    }
   }
   // Device list style: as requested. EAM with half lists is ForceEAM::compute_halfneigh (ref/force_eam.cpp:94-270, third-law
   // scatter with atomics). `--eam_half_full` (ours; the reference ignores unknown flags) serves such a request on the faster
@@ -348,6 +356,9 @@ extern "C" int mmd_sim_create(int argc, char** argv, int quiet, mmd_sim** out)
     fprintf(stdout, "# %s output ...\n", mmd_variant_string());
     fprintf(stdout, "# Run Settings: \n");
     fprintf(stdout, "\t# MPI processes: %i\n", s->nprocs);
+    if(s->nprocs > 1)
+      fprintf(stdout, "\t# Transport: %s (launcher: %s)\n", s->transport == 1 ? "RCCL point-to-point, one GPU per rank" :
+              (s->transport == 3 ? "TCP mesh staged through host memory — DEBUG transport, the ranks share GPUs" : "host callbacks of the caller"), s->launcher);
     fprintf(stdout, "\t# OpenMP threads: %i\n", s->num_threads);
     fprintf(stdout, "\t# Inputfile: %s\n", s->input_file.c_str());
     fprintf(stdout, "\t# Datafile: %s\n", s->in.has_datafile ? s->in.datafile : "None");
@@ -623,6 +634,7 @@ extern "C" int mmd_sim_destroy(mmd_sim* s)
 {
   if(!s) return 0;
   if(s->h) mmd_destroy(s->h);
+  if(s->mesh) mmd_mesh_destroy(s->mesh);
   delete s;
   return 0;
 }

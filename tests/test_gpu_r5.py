@@ -34,3 +34,73 @@ def test_every_tile_read_form_runs_to_the_last_step(prec):
         s.close()
     for other in rows[1:]:
         assert np.allclose(rows[0][1], other[1], rtol=0, atol=1e-9 if prec == "dp" else 2e-3)
+
+
+# ---- the launcher contract of the drop-in executable (ref/run_one_test:50, ref/ljs.cpp:63-68) ---------------------------------------------------
+LAUNCH_VARS = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "PMI_RANK", "PMI_SIZE",
+               "MMD_TRANSPORT")
+
+
+def _thermo(stdout):
+    rows, on = [], False
+    for line in stdout.splitlines():
+        if line.startswith("# Timestep T"):
+            on = True
+            continue
+        if line.startswith("# Performance Summary"):
+            break
+        f = line.split()
+        if on and len(f) >= 4 and f[0].lstrip("-").isdigit():
+            rows.append((int(f[0]), float(f[1]), float(f[2]), float(f[3])))
+    return rows
+
+
+def _mpiexec():
+    import shutil
+    for cand in (shutil.which("mpiexec"), "/opt/conda/bin/mpiexec"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+@pytest.mark.parametrize("how", ["openmpi_env", "mpiexec"])
+def test_executable_as_three_plain_processes_reproduces_4k_lj(how):
+    """`miniMD_dp -s 10 -n 1000 --half_neigh 0` as THREE ranks started the way the reference's harness starts them (ref/run_one_test:50, np = 3 of
+    ref/run_tests:116-151): plain processes that learn their rank from the launcher's environment, no MASTER_* anywhere. On a one-GPU box the ranks agree
+    on the built-in TCP mesh (banner: DEBUG transport); the thermo rows are those of the reference's published 4k.lj log (its own mode-independence
+    claim, tests/reference_output/README:3-5) and pass the reference's statistical rule."""
+    import json
+    from oracle_lib import ref_pass_rule
+    exe = os.path.join(REPO, "minimd_amd", "bin", "miniMD_dp")
+    argv = [exe, "-s", "10", "-n", "1000", "--half_neigh", "0", "--yaml_output", "0", "-dm", "-i", "in.lj.miniMD"]
+    env0 = {k: v for k, v in os.environ.items() if k not in LAUNCH_VARS}
+    cwd = os.path.join(REPO, "data")
+    if how == "mpiexec":
+        if _mpiexec() is None:
+            pytest.skip("no mpiexec in this image")
+        r = subprocess.run([_mpiexec(), "-np", "3"] + argv, cwd=cwd, env=env0, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        out = r.stdout
+    else:
+        procs = [subprocess.Popen(argv, cwd=cwd, env=dict(env0, OMPI_COMM_WORLD_RANK=str(k), OMPI_COMM_WORLD_SIZE="3", OMPI_COMM_WORLD_LOCAL_RANK=str(k)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(3)]
+        outs = [p.communicate(timeout=900) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+        out = outs[0][0]
+        assert all(_thermo(o[0]) == [] for o in outs[1:])          # (only rank 0 prints, ref/thermo.cpp:106-112)
+    assert "# MPI processes: 3" in out
+    ngpu = mm().load_library("dp").mmd_device_count()
+    assert ("TCP mesh" in out) == (ngpu < 3) and ("RCCL" in out) == (ngpu >= 3), out[:1500]
+    rows = _thermo(out)
+    ref = [r for r in json.load(open(os.path.join(GOLD, "reference_output.json")))["4k.lj"]["rows"] if r[0] <= 1000]
+    rows_close(rows, ref, 1.5e-5)
+    assert ref_pass_rule(ref, rows, 4000, 8)[0]
+
+
+def test_harness_scope_1_runs_np_3_and_8():
+    """ref/run_tests scope 1 = sizes 10 at np 1, 3 and 8, 1000 steps: tools/run_one_test.py starts the executable through the launcher like `make test`
+    does and applies the reference's PASS rule — all three on whatever this box has (one GPU: the np > 1 runs share it over the TCP mesh)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "run_one_test.py"), "--scope", "1", "--input", "lj", "--halfneigh", "0"],
+                       capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.count("PASSED") == 3 and "np=8" in r.stdout, r.stdout[-3000:]

@@ -10,15 +10,14 @@ line by line with the reference log of the same system size (tests/golden/refere
 tests/reference_output/*.lj|*.eam) and judged by the reference's own statistical rule (ref/run_one_test:121-138): a row's |dT|, |dU|, |dP|
 count as a miss when they exceed  stddev/sqrt(natoms) * sqrt(2)*(0.5 + atan2(step - d*floatsize, 50)/3.1415) + add;  the run PASSES while
 misses <= 3*0.38*rows. Output lines follow the reference's ("Testfile: ...", natoms, "   PASSED (T: ..; E: ..; P: ..; Expected <=0.38)").
-np > 1 starts one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK, RCCL id over MASTER_ADDR:MASTER_PORT) and needs that many GPUs.
-Exit status 0 = every run passed. --scope N runs the list of ref/run_tests:42-151 for that scope (multi-rank entries are skipped with a
-note when fewer GPUs than ranks are visible)."""
+np > 1 is started the way ref/run_one_test:50 starts it, `${MPISTART:-mpiexec} -np N ${MPIOPTIONS} <exe> ...` (plain processes with Open MPI's
+variables where no launcher exists); the executable takes its rank from the launcher's environment and says in its banner which transport the ranks
+agreed on (RCCL with a GPU each, the built-in TCP mesh when they share GPUs). Exit status 0 = every run passed. --scope N runs the list of
+ref/run_tests:42-151 for that scope."""
 import argparse
 import json
 import math
 import os
-import random
-import socket
 import subprocess
 import sys
 
@@ -57,12 +56,16 @@ def thermo_block(stdout):
     return rows
 
 
-def visible_gpus():
-    try:
-        r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showid", "--csv"], capture_output=True, text=True, timeout=60)
-        return max(1, sum(1 for l in r.stdout.splitlines() if l.startswith("card")))
-    except Exception:  # noqa: BLE001
-        return 1
+def mpistart():
+    """the launcher of ref/run_one_test:50 (${MPISTART}, default mpiexec / mpirun on PATH or the image's /opt/conda/bin/mpiexec); [] when there is none"""
+    import shutil
+    want = os.environ.get("MPISTART", "").split()
+    if want:
+        return want
+    for cand in (shutil.which("mpiexec"), shutil.which("mpirun"), "/opt/conda/bin/mpiexec"):
+        if cand and os.path.exists(cand):
+            return [cand]
+    return []
 
 
 def run_one(exe, nprocs, nt, size, nsteps, neighlist, ghostcomm, inp, quiet=False):
@@ -83,28 +86,21 @@ def run_one(exe, nprocs, nt, size, nsteps, neighlist, ghostcomm, inp, quiet=Fals
     argv = [exe, "-t", str(nt), "-s", str(size), "-n", str(nsteps), "--half_neigh", str(neighlist), "-gn", str(ghostcomm), "--yaml_output", "0", "-dm",
             "-i", "in.%s.miniMD" % inp]
     cwd = os.path.join(REPO, "data")
+    launch_vars = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "PMI_RANK", "PMI_SIZE")
+    base_env = {k: v for k, v in os.environ.items() if k not in launch_vars}
+    base_env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if nprocs == 1:
-        outs = [subprocess.run(argv, cwd=cwd, capture_output=True, text=True)]
+        outs = [subprocess.run(argv, cwd=cwd, env=base_env, capture_output=True, text=True)]
+    elif mpistart():
+        # exactly ref/run_one_test:50: ${MPISTART} -np $2 ${MPIOPTIONS} ./exe ... — the executable reads the launcher's environment (PMI_RANK / OMPI_COMM_WORLD_RANK
+        # ...), the ranks meet on a port derived from the job, and use RCCL with a GPU each or the built-in TCP mesh when they share GPUs (named in the banner)
+        cmd = mpistart() + ["-np", str(nprocs)] + os.environ.get("MPIOPTIONS", "").split() + argv
+        outs = [subprocess.run(cmd, cwd=cwd, env=base_env, capture_output=True, text=True)]
     else:
-        # (a port below the kernel's ephemeral range: one handed out by bind(0) can become the source port of somebody's outgoing connection before the rendezvous listens on it)
-        port = 0
-        for _try in range(64):
-            cand = random.randint(20000, 29999)
-            with socket.socket() as so:
-                try:
-                    so.bind(("127.0.0.1", cand))
-                    port = cand
-                    break
-                except OSError:
-                    pass
-        if not port:
-            with socket.socket() as so:
-                so.bind(("127.0.0.1", 0))
-                port = so.getsockname()[1]
+        # no MPI launcher on this box: N plain processes with the variables Open MPI's mpirun would export
         procs = []
         for r in range(nprocs):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(nprocs), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env = dict(base_env, OMPI_COMM_WORLD_RANK=str(r), OMPI_COMM_WORLD_SIZE=str(nprocs), OMPI_COMM_WORLD_LOCAL_RANK=str(r))
             procs.append(subprocess.Popen(argv, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         outs = []
         for pr in procs:
@@ -118,6 +114,9 @@ def run_one(exe, nprocs, nt, size, nsteps, neighlist, ghostcomm, inp, quiet=Fals
     if not rows:
         print("FAILED")
         return False
+    tr = [l.strip() for l in out.stdout.splitlines() if l.strip().startswith("# Transport:")]
+    if tr:
+        print("   " + tr[0])
     fs = [l.split()[4] for l in out.stdout.splitlines() if l.startswith("# Size of float")]
     floatsize = int(fs[0]) if fs else 8
     print(ref["natoms"])
@@ -159,12 +158,8 @@ def main():
     print(" ")
     print("running miniMD tests scope=%d input=%s halfneigh=%d" % (args.scope, args.input, args.halfneigh))
     nsteps, threads, runs = scope_runs(args.scope)
-    ngpu = visible_gpus()
     bad = 0
     for nprocs, size in runs:
-        if nprocs > ngpu:
-            print(" \nskipping np=%d size=%d: %d GPU(s) visible (one rank per GPU)" % (nprocs, size, ngpu))
-            continue
         bad += 0 if run_one(args.exe, nprocs, threads, size, nsteps, args.halfneigh, 0, args.input) else 1
     sys.exit(1 if bad else 0)
 
