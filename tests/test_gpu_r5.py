@@ -90,7 +90,7 @@ def test_executable_as_three_plain_processes_reproduces_4k_lj(how):
         assert all(_thermo(o[0]) == [] for o in outs[1:])          # (only rank 0 prints, ref/thermo.cpp:106-112)
     assert "# MPI processes: 3" in out
     ngpu = mm().load_library("dp").mmd_device_count()
-    assert ("TCP mesh" in out) == (ngpu < 3) and ("RCCL" in out) == (ngpu >= 3), out[:1500]
+    assert ("# Transport: TCP mesh" in out) == (ngpu < 3) and ("# Transport: RCCL" in out) == (ngpu >= 3), out[:1500]
     rows = _thermo(out)
     ref = [r for r in json.load(open(os.path.join(GOLD, "reference_output.json")))["4k.lj"]["rows"] if r[0] <= 1000]
     rows_close(rows, ref, 1.5e-5)
