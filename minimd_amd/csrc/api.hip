@@ -50,6 +50,7 @@ extern "C" int mmd_create(int device, mmd_handle** out)
   HIP_TRY(hipHostMalloc((void**)&h->h_flags_big, 64 * sizeof(int), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&h->dh.h_counts, 32 * 30 * sizeof(int), hipHostMallocDefault));
   memset(h->dh.h_counts, 0, 32 * 30 * sizeof(int));
+  HIP_TRY(hipHostGetDevicePointer((void**)&h->dh.h_counts_dev, h->dh.h_counts, 0));
   HIP_TRY(hipMalloc((void**)&h->d_flags, 64 * sizeof(int)));
   HIP_TRY(hipMemset(h->d_result, 0, 32 * sizeof(double)));
   HIP_TRY(hipMemset(h->d_flags, 0, 64 * sizeof(int)));
@@ -81,7 +82,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->tile_cand.release(); h->tile_cand_src.release(); h->box_dev.release(); h->tile_ncand.release(); h->tile_cnt.release(); h->nl16.release();
   h->lj_tables.release(); h->rhor_spline.release(); h->frho_spline.release(); h->z2r_spline.release(); h->fp.release(); h->rho.release();
   for(auto& s : h->swaps) s.sendlist.release();
-  h->buf_send.release(); h->buf_recv.release(); h->est.release(); h->ex_list.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->brd_bits.release(); h->partials.release();
+  h->buf_send.release(); h->buf_recv.release(); h->est.release(); h->ex_list.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->brd_bits.release(); h->ghost_bits.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if(h->ev_x_ready) { (void)hipEventDestroy(h->ev_x_ready); (void)hipEventDestroy(h->ev_halo_done); }
   h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release(); h->tile_words.release(); h->tile_kcore.release(); h->xbuild.release(); h->core_words.release();
@@ -140,6 +141,8 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "spec")) h->opt_spec = value;
   else if(!strcmp(name, "fold_pencil")) h->opt_fold_pencil = value;
   else if(!strcmp(name, "direct_halo")) h->dh.opt = value;
+  else if(!strcmp(name, "direct_borders")) h->dh.opt_borders = value;
+  else if(!strcmp(name, "halo_recv")) h->dh.opt_recv = value;
   else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) {
@@ -576,6 +579,7 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "exchange_fast")) *value = h->ex_fast;
   else if(!strcmp(name, "borders_fast")) *value = h->borders_fast_runs;
   else if(!strcmp(name, "borders_general")) *value = h->borders_general_runs;
+  else if(!strcmp(name, "borders_direct")) *value = h->borders_direct_runs;
   else if(!strcmp(name, "device_bins_coarser")) *value = h->neigh_ready && (h->bg.nbin[0] != h->bg_ref.nbin[0] || h->bg.nbin[1] != h->bg_ref.nbin[1] || h->bg.nbin[2] != h->bg_ref.nbin[2]) ? 1 : 0;
   else if(!strcmp(name, "tiles_ready")) *value = h->tiles_ready ? 1 : 0;
   else if(!strcmp(name, "eam_lds_density")) *value = h->eam_diag[0];

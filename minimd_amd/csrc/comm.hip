@@ -128,6 +128,7 @@ extern "C" int mmd_comm_swap_info(mmd_handle* h, int iswap, double slab[2], int 
 extern "C" int mmd_comm_download_lists(mmd_handle* h, int iswap, int* sendlist)
 {
   if(!h || iswap < 0 || iswap >= (int)h->swaps.size() || !sendlist) { mmd_set_error("mmd_comm_download_lists: bad arguments"); return -1; }
+  MMD_TRY(mmd_comm_sendlists_ensure(h));
   const Swap& s = h->swaps[iswap];
   if(s.sendnum) HIP_TRY(hipMemcpyAsync(sendlist, s.sendlist.p, (size_t)s.sendnum * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(mmd_stream_sync(h));
@@ -426,6 +427,7 @@ extern "C" int mmd_comm_communicate(mmd_handle* h)
     return 0;
   }
   if(h->dh.ready) return mmd_dh_exchange(h, 0);           // one exchange with the up to 26 neighbours (DirectHalo, mmd_internal.hpp)
+  MMD_TRY(mmd_comm_sendlists_ensure(h));
   // swap by swap (later dimensions forward ghosts received by earlier ones); the two swaps of one dimension are
   // independent of each other, so with RCCL they share one ncclGroup: 3 instead of 6 p2p rounds per step
   const size_t nsw = h->swaps.size();
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(256) void k_unpack_reverse(real* __restrict__ f, co
 extern "C" int mmd_comm_reverse_communicate(mmd_handle* h)
 {
   if(!h) { mmd_set_error("null handle"); return -1; }
+  MMD_TRY(mmd_comm_sendlists_ensure(h));
   for(int is = (int)h->swaps.size() - 1; is >= 0; is--) {
     Swap& s = h->swaps[is];
     const real* ghost_f = h->f.p + 3 * (size_t)s.firstrecv;     // Atom::pack_reverse is a contiguous slice
@@ -1496,6 +1499,57 @@ static bool dh_applies(const mmd_handle* h)
   return true;
 }
 
+static void dh_self_swaps(const mmd_handle* h, SelfSwaps& W)
+{
+  for(int q = 0; q < 6; q++) {
+    const Swap& sw = h->swaps[q];
+    W.lo[q] = sw.slablo; W.hi[q] = sw.slabhi;
+    W.sx[q] = sw.pbc[0] * h->prd[0]; W.sy[q] = sw.pbc[1] * h->prd[1]; W.sz[q] = sw.pbc[2] * h->prd[2];
+    W.pbc_any[q] = sw.pbc_any; W.px[q] = sw.pbc[0]; W.py[q] = sw.pbc[1]; W.pz[q] = sw.pbc[2];
+    W.cap_list[q] = 0; W.sendlist[q] = nullptr;
+  }
+}
+static int image_add_host(int code, int px, int py, int pz)
+{
+  const int sx = code % 5 + px, sy = (code / 5) % 5 + py, sz = code / 25 + pz;
+  return std::min(std::max(sx, 0), 4) + 5 * std::min(std::max(sy, 0), 4) + 25 * std::min(std::max(sz, 0), 4);
+}
+// where every list goes and comes from: a list travels one step along each of its swaps' send directions (swap 2d towards -1, 2d+1 towards +1); the
+// distinct partners in list order — sender and receiver enumerate them alike (target_l(A) = B <=> source_l(B) = A); shift and image code of its ghosts
+static void dh_topology(mmd_handle* h)
+{
+  DirectHalo& D = h->dh;
+  const bool forced = h->opt_force_transport != 0;
+  for(int l = 0; l < 26; l++) {
+    int off[3] = {0, 0, 0};
+    D.shift[l][0] = D.shift[l][1] = D.shift[l][2] = 0;
+    D.code[l] = IMAGE_NONE;
+    for(int q = 0; q < 6; q++) if(brd_mask_of(l) & (1 << q)) {
+      off[q / 2] += (q & 1) ? 1 : -1;
+      const Swap& sw = h->swaps[q];
+      if(sw.pbc_any) for(int d = 0; d < 3; d++) D.shift[l][d] += sw.pbc[d] * h->prd[d];
+      D.code[l] = image_add_host(D.code[l], sw.pbc[0], sw.pbc[1], sw.pbc[2]);
+    }
+    D.target[l] = cart_rank(h->procgrid, h->myloc[0] + off[0], h->myloc[1] + off[1], h->myloc[2] + off[2]);
+    D.source[l] = cart_rank(h->procgrid, h->myloc[0] - off[0], h->myloc[1] - off[1], h->myloc[2] - off[2]);
+  }
+  D.npeer_s = D.npeer_r = 0;
+  for(int l = 0; l < 26; l++) { D.lps[l] = -1; D.lpr[l] = -1; }
+  for(int l = 0; l < 26; l++) {
+    if(D.target[l] == h->me && !forced) continue;
+    if(D.lps[l] < 0) {
+      D.peer_s[D.npeer_s] = D.target[l];
+      for(int m = l; m < 26; m++) if(D.target[m] == D.target[l] && !(D.target[m] == h->me && !forced)) D.lps[m] = D.npeer_s;
+      D.npeer_s++;
+    }
+    if(D.lpr[l] < 0) {
+      D.peer_r[D.npeer_r] = D.source[l];
+      for(int m = l; m < 26; m++) if(D.source[m] == D.source[l] && !(D.target[m] == h->me && !forced)) D.lpr[m] = D.npeer_r;
+      D.npeer_r++;
+    }
+  }
+}
+
 // lists + lengths of this rank on the stream, the lengths of the lists it will receive exchanged with the neighbours, both copied to pinned memory
 // (no host synchronisation here with RCCL: the neighbor build's own read-back comes later on the same stream)
 static int dh_enqueue(mmd_handle* h)
@@ -1505,30 +1559,8 @@ static int dh_enqueue(mmd_handle* h)
   if(!dh_applies(h)) return 0;
   const int nlocal = h->nlocal;
   SelfSwaps W;
-  for(int q = 0; q < 6; q++) {
-    const Swap& sw = h->swaps[q];
-    W.lo[q] = sw.slablo; W.hi[q] = sw.slabhi;
-    W.sx[q] = sw.pbc[0] * h->prd[0]; W.sy[q] = sw.pbc[1] * h->prd[1]; W.sz[q] = sw.pbc[2] * h->prd[2];
-    W.pbc_any[q] = sw.pbc_any; W.px[q] = sw.pbc[0]; W.py[q] = sw.pbc[1]; W.pz[q] = sw.pbc[2];
-    W.cap_list[q] = 0; W.sendlist[q] = nullptr;
-  }
-  // where every list goes and comes from: a list travels one step along each of its swaps' send directions (swap 2d towards -1, 2d+1 towards +1)
-  {
-    int l = 0;
-    const int masks[26] = {0x01, 0x02, 0x04, 0x05, 0x06, 0x08, 0x09, 0x0a, 0x10, 0x11, 0x12, 0x14, 0x15, 0x16, 0x18, 0x19, 0x1a,
-                           0x20, 0x21, 0x22, 0x24, 0x25, 0x26, 0x28, 0x29, 0x2a};
-    for(l = 0; l < 26; l++) {
-      int off[3] = {0, 0, 0};
-      D.shift[l][0] = D.shift[l][1] = D.shift[l][2] = 0;
-      for(int q = 0; q < 6; q++) if(masks[l] & (1 << q)) {
-        off[q / 2] += (q & 1) ? 1 : -1;
-        const Swap& sw = h->swaps[q];
-        if(sw.pbc_any) for(int d = 0; d < 3; d++) D.shift[l][d] += sw.pbc[d] * h->prd[d];
-      }
-      D.target[l] = cart_rank(h->procgrid, h->myloc[0] + off[0], h->myloc[1] + off[1], h->myloc[2] + off[2]);
-      D.source[l] = cart_rank(h->procgrid, h->myloc[0] - off[0], h->myloc[1] - off[1], h->myloc[2] - off[2]);
-    }
-  }
+  dh_self_swaps(h, W);
+  dh_topology(h);
   const int nblk = std::max(1, div_up(nlocal, CP_TILE));
   MMD_TRY(h->flag_tmp.ensure((size_t)BRD_ROWS * nblk + BRD_ROWS + 8, false, h->stream));
   MMD_TRY(h->brd_bits.ensure((size_t)nlocal + 64, false, h->stream));
@@ -1602,32 +1634,24 @@ static int dh_finish(mmd_handle* h)
   }
   D.soff[26] = so; D.rbase[26] = rb;
   D.total_send = so;
-  // one message per distinct partner, its lists end to end in list order (sender and receiver agree: target_l(A) = B <=> source_l(B) = A)
-  D.npeer_s = D.npeer_r = 0;
+  // one message per distinct partner, its lists end to end in list order (dh_topology: sender and receiver enumerate partners and lists alike)
   int ps = 0, pr = 0;
   for(int l = 0; l < 26; l++) { D.sdst[l] = -1; D.rsrc[l] = -1; }
-  for(int l = 0; l < 26; l++) {
-    if(D.target[l] == h->me && !forced) continue;
-    bool seen = false;
-    for(int k = 0; k < D.npeer_s; k++) seen = seen || D.peer_s[k] == D.target[l];
-    if(!seen) {
-      D.peer_s[D.npeer_s] = D.target[l]; D.peer_soff[D.npeer_s] = ps;
-      for(int m = l; m < 26; m++) if(D.target[m] == D.target[l] && !(D.target[m] == h->me && !forced)) { D.sdst[m] = ps; ps += D.ns[m]; }
-      D.npeer_s++;
-    }
-    seen = false;
-    for(int k = 0; k < D.npeer_r; k++) seen = seen || D.peer_r[k] == D.source[l];
-    if(!seen) {
-      D.peer_r[D.npeer_r] = D.source[l]; D.peer_roff[D.npeer_r] = pr;
-      for(int m = l; m < 26; m++) if(D.source[m] == D.source[l] && !(D.target[m] == h->me && !forced)) { D.rsrc[m] = pr; pr += D.nr[m]; }
-      D.npeer_r++;
-    }
+  for(int k = 0; k < D.npeer_s; k++) {
+    D.peer_soff[k] = ps;
+    for(int m = 0; m < 26; m++) if(D.lps[m] == k) { D.sdst[m] = ps; ps += D.ns[m]; }
+  }
+  for(int k = 0; k < D.npeer_r; k++) {
+    D.peer_roff[k] = pr;
+    for(int m = 0; m < 26; m++) if(D.lpr[m] == k) { D.rsrc[m] = pr; pr += D.nr[m]; }
   }
   D.peer_soff[D.npeer_s] = ps; D.peer_roff[D.npeer_r] = pr;
   D.total_recv = pr;
   if(rb != h->nghost) { mmd_set_error("direct halo: the 26 lists hold %d ghosts, Comm::borders made %d", rb, h->nghost); return -1; }
   if((size_t)so > D.idx.cap) { mmd_set_error("direct halo: send lists longer than provided for (%d)", so); return -1; }
   D.ready = true;
+  D.prev_valid = true;                     // (sizes the fixed messages of the next direct borders)
+  for(int l = 0; l < 26; l++) { D.ns_prev[l] = D.ns[l]; D.nr_prev[l] = D.nr[l]; }
   return 0;
 }
 
@@ -1651,7 +1675,7 @@ int mmd_dh_exchange(mmd_handle* h, int what)
   const size_t per = what == 0 ? 4 : 1;
   const int nsend_remote = D.peer_soff[D.npeer_s];
   MMD_TRY(h->buf_send.ensure(per * (size_t)nsend_remote + 16, false, h->stream));
-  MMD_TRY(h->buf_recv.ensure(per * (size_t)D.total_recv + 16, false, h->stream));
+  if(!(D.opt_recv >= 2 && h->rccl)) MMD_TRY(h->buf_recv.ensure(per * (size_t)D.total_recv + 16, false, h->stream));
   if(D.total_send) {
     if(what == 0) hipLaunchKernelGGL(k_dh_pack_x, dim3(div_up(D.total_send, 256)), dim3(256), 0, h->stream, h->x.p, D.idx.p, D.total_send, M, (real4*)h->buf_send.p, h->nlocal);
     else hipLaunchKernelGGL(k_dh_pack_f, dim3(div_up(D.total_send, 256)), dim3(256), 0, h->stream, h->fp.p, D.idx.p, D.total_send, M, h->buf_send.p, h->nlocal);
@@ -1659,6 +1683,20 @@ int mmd_dh_exchange(mmd_handle* h, int what)
   }
   unsigned char* sbuf = (unsigned char*)h->buf_send.p;
   unsigned char* rbuf = (unsigned char*)h->buf_recv.p;
+  // halo_recv 2: every list is a message of its own, received straight into the slots of its ghosts (no receive buffer, no k_dh_unpack: one dependent launch
+  // less per step; SURVEY K12 "unpack can be elided") — up to 26 sends + 26 receives in the group instead of one pair per distinct partner. Messages
+  // between the same two ranks are matched in issue order: ascending list number on both sides (target_l(A) = B <=> source_l(B) = A, same lengths).
+  const bool recv_direct = D.opt_recv >= 2 && h->rccl != nullptr;
+  if(recv_direct) {
+    h->halo_bytes += (long long)((size_t)nsend_remote * esz);
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    unsigned char* gdst = what == 0 ? (unsigned char*)(h->x.p + h->nlocal) : (unsigned char*)(h->fp.p + h->nlocal);
+    NCCL_TRY(ncclGroupStart());
+    for(int l = 0; l < 26; l++) if(D.lps[l] >= 0 && D.ns[l]) NCCL_TRY(ncclSend(sbuf + (size_t)D.sdst[l] * esz, (size_t)D.ns[l] * esz, ncclChar, D.target[l], c, h->stream));
+    for(int l = 0; l < 26; l++) if(D.lpr[l] >= 0 && D.nr[l]) NCCL_TRY(ncclRecv(gdst + (size_t)D.rbase[l] * esz, (size_t)D.nr[l] * esz, ncclChar, D.source[l], c, h->stream));
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+  }
   if(h->rccl) {
     h->halo_bytes += (long long)((size_t)nsend_remote * esz);
     ncclComm_t c = (ncclComm_t)h->rccl;
@@ -1689,6 +1727,259 @@ int mmd_dh_exchange(mmd_handle* h, int what)
     HIP_TRY(hipGetLastError());
   }
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Direct borders (round 5): Comm::borders (ref/comm.cpp:700-883) on several ranks as ONE exchange.
+// The three dependent rounds of the reference exist because a later dimension forwards the ghosts an earlier one received. But whether a ghost is
+// forwarded by swap q is decided by the coordinate of its ROOT in q's dimension against slab bounds the forwarding rank shares with the root's owner
+// (they differ in earlier dimensions only) — the owner can decide it itself. So every rank compacts its 26 lists (k_brd_count / k_brd_scan /
+// k_dh_lists, exactly the lists of the per-step direct halo), packs {x + shift, type} + the atom's slab bits of every list entry into ONE fixed-size
+// message per distinct partner (header = the 26 list lengths; capacity from the previous plan's lengths, derived alike on both sides), all messages
+// travel in one ncclGroup, and k_db_unpack lays the received lists end to end in list order — which IS the swap-by-swap ghost order (BrdList) — with
+// positions, types, image codes; it also leaves every ghost's slab bits (the six send lists of the swaps are derived from them on demand,
+// mmd_comm_sendlists_ensure: nothing on the step path reads them) and the swaps' counts in bst. A count beyond its capacity raises the overflow flag
+// (max-reduced over the ranks): every rank then redoes the borders swap by swap. Six launches + one RCCL group instead of 14 launches + 3 groups, one
+// dependent transfer instead of three, and the direct-halo plan of the steps comes out of the same lists (no second pass, no separate length exchange).
+// ---------------------------------------------------------------------------------------------------
+static int borders_fast_finish(mmd_handle* h);
+#define DBMSG_HEADER 128
+static inline size_t db_msg_bytes(int cap) { return ((size_t)DBMSG_HEADER + (size_t)cap * (sizeof(real4) + sizeof(int)) + 63) & ~(size_t)63; }
+struct DbPack {
+  int lps[26];                  // outgoing message of list l (self lists: the extra message np_s)
+  int cap[27];                  // record capacity of message m
+  unsigned char* msg[27];
+  int nmsg;
+  real sx[26], sy[26], sz[26];
+  int code[26];
+  int idx_cap;
+};
+__global__ __launch_bounds__(256) void k_db_pack(const real4* __restrict__ x, const int* __restrict__ idx, const int* __restrict__ counts,
+                                                 const unsigned char* __restrict__ bits, DbPack P, int* __restrict__ bst)
+{
+  __shared__ int s_soff[27], s_poff[26], s_tot[27];
+  if(threadIdx.x == 0) {
+    int so = 0;
+    for(int m = 0; m < 27; m++) s_tot[m] = 0;
+    for(int l = 0; l < 26; l++) {
+      const int n = counts[l], m = P.lps[l];
+      s_soff[l] = so; so += n;
+      s_poff[l] = s_tot[m]; s_tot[m] += n;
+    }
+    s_soff[26] = so;
+  }
+  __syncthreads();
+  if(blockIdx.x == 0 && threadIdx.x < P.nmsg) {          // headers: my 26 list lengths (the receiver reads those of the lists it gets from me), records in this message
+    int* hd = (int*)P.msg[threadIdx.x];
+    for(int l = 0; l < 26; l++) hd[l] = counts[l];
+    hd[26] = s_tot[threadIdx.x];
+    hd[27] = 0x6d6d6462;
+    if(s_tot[threadIdx.x] > P.cap[threadIdx.x]) bst[BST_OVF] = 1;
+  }
+  if(blockIdx.x == 0 && threadIdx.x == 0 && s_soff[26] > P.idx_cap) bst[BST_OVF] = 1;       // (k_dh_lists dropped entries)
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if(e >= s_soff[26] || e >= P.idx_cap) return;
+  int l = 0;
+#pragma unroll
+  for(int q = 1; q < 26; q++) l += e >= s_soff[q] ? 1 : 0;
+  const int m = P.lps[l], o = s_poff[l] + (e - s_soff[l]);
+  if(o >= P.cap[m]) return;                               // (overflow: flagged above)
+  const int i = idx[e];
+  real4 p = x[i];
+  p.x += P.sx[l]; p.y += P.sy[l]; p.z += P.sz[l];       // (a list without periodic swaps carries zeros: x + 0 is x)
+  real4* rec = (real4*)(P.msg[m] + DBMSG_HEADER);
+  int* aux = (int*)(P.msg[m] + DBMSG_HEADER + (size_t)P.cap[m] * sizeof(real4));
+  rec[o] = p;
+  aux[o] = (int)bits[i] | (P.code[l] << 8);
+}
+struct DbUnpack {
+  int lpr[26];                  // incoming message of list l
+  int cap[27];
+  const unsigned char* msg[27];
+  int nmsg;
+};
+__global__ __launch_bounds__(256) void k_db_unpack(real4* __restrict__ x, int nlocal, DbUnpack U, const int* __restrict__ counts, const int* __restrict__ tot_any,
+                                                   int cap_atoms, int cap_ghost, int* __restrict__ ghost_image, unsigned char* __restrict__ ghost_bits,
+                                                   int* __restrict__ type, int* __restrict__ bst, int* __restrict__ host_counts)
+{
+  __shared__ int s_nr[26], s_rbase[27], s_roff[26];
+  if(threadIdx.x == 0) {
+    int ovf = 0, rb = 0, mt[27];
+    for(int m = 0; m < 27; m++) mt[m] = 0;
+    for(int m = 0; m < U.nmsg; m++) { const int* hd = (const int*)U.msg[m]; if(hd[27] != 0x6d6d6462 || hd[26] > U.cap[m] || hd[26] < 0) ovf = 1; }
+    for(int l = 0; l < 26; l++) {
+      const int m = U.lpr[l];
+      int n = ((const int*)U.msg[m])[l];
+      n = min(max(n, 0), max(U.cap[m] - mt[m], 0));       // (never read beyond a message, whatever its header says)
+      s_nr[l] = n; s_rbase[l] = rb; s_roff[l] = mt[m];
+      rb += n; mt[m] += n;
+    }
+    s_rbase[26] = rb;
+    if(rb > cap_ghost || nlocal + rb + 1 > cap_atoms) ovf = 1;
+    if(blockIdx.x == 0) {
+      if(ovf) bst[BST_OVF] = 1;
+      int first = 0;
+      int rq[6] = {0, 0, 0, 0, 0, 0};
+      for(int l = 0; l < 26; l++) { const int q = l < 1 ? 0 : l < 2 ? 1 : l < 5 ? 2 : l < 8 ? 3 : l < 17 ? 4 : 5; rq[q] += s_nr[l]; }
+      for(int q = 0; q < 6; q++) { bst[BST_RECV + q] = rq[q]; bst[BST_GHOSTS + q] = first; first += rq[q]; }
+      bst[BST_GHOSTS + 6] = rb;
+      bst[BST_NB] = tot_any[0];
+      // what this rank's swaps send: the owned atoms inside the swap's slab (its one-swap list) + the forwarded ghosts counted below
+      atomicAdd(&bst[BST_SEND + 0], counts[0]); atomicAdd(&bst[BST_SEND + 1], counts[1]); atomicAdd(&bst[BST_SEND + 2], counts[2]);
+      atomicAdd(&bst[BST_SEND + 3], counts[5]); atomicAdd(&bst[BST_SEND + 4], counts[8]); atomicAdd(&bst[BST_SEND + 5], counts[17]);
+      for(int l = 0; l < 26; l++) { host_counts[l] = counts[l]; host_counts[32 + l] = s_nr[l]; }
+    }
+  }
+  __syncthreads();
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nghost = min(s_rbase[26], min(cap_ghost, cap_atoms - nlocal - 1));
+  int F = 0, l = 0;
+  if(g < nghost) {
+#pragma unroll
+    for(int q = 1; q < 26; q++) l += g >= s_rbase[q] ? 1 : 0;
+    const int m = U.lpr[l], o = s_roff[l] + (g - s_rbase[l]);
+    const real4* rec = (const real4*)(U.msg[m] + DBMSG_HEADER);
+    const int* aux = (const int*)(U.msg[m] + DBMSG_HEADER + (size_t)U.cap[m] * sizeof(real4));
+    const real4 p = rec[o];
+    const int a = aux[o];
+    x[nlocal + g] = p;
+    type[nlocal + g] = (int)p.w;
+    ghost_image[g] = a >> 8;
+    ghost_bits[g] = (unsigned char)(a & 0xff);
+    // a swap of dimension d forwards the ghosts of the EARLIER dimensions that lie in its slab (lists 0-1: x, 2-7: up to y)
+    F = a & 0xff;
+    if(l >= 8) F = 0; else if(l >= 2) F &= 0x30; else F &= 0x3c;
+  }
+#pragma unroll
+  for(int q = 2; q < 6; q++) {
+    const int c = __popcll(__builtin_amdgcn_ballot_w64((F >> q) & 1));
+    if(c && (threadIdx.x & 63) == 0) atomicAdd(&bst[BST_SEND + q], c);
+  }
+}
+
+struct BitsPred {      // send list of swap q from the slab bits: owned atoms and ghosts of the earlier dimensions inside its slab, ascending (ref/comm.cpp:766-779)
+  const unsigned char* own; const unsigned char* ghost; int nlocal, q;
+  __device__ bool operator()(int i) const { return (((int)(i < nlocal ? own[i] : ghost[i - nlocal])) >> q) & 1; }
+  __device__ int index(int i) const { return i; }
+};
+int mmd_comm_sendlists_ensure(mmd_handle* h)
+{
+  if(!h->sendlists_stale) return 0;
+  for(int q = 0; q < 6; q++) {
+    Swap& s = h->swaps[q];
+    const int nlast = q < 2 ? h->nlocal : h->swaps[q & ~1].firstrecv;       // (both swaps of a dimension scan the atoms in front of the dimension's first ghost)
+    // (the length is known — k_db_unpack counted it into bst — so the compaction needs no read-back: count, scan, scatter on the stream)
+    if(nlast <= 0 || s.sendnum <= 0) continue;
+    const BitsPred pred{h->brd_bits.p, h->ghost_bits.p, h->nlocal, q};
+    const int ntiles = div_up(nlast, CP_TILE);
+    MMD_TRY(h->flag_tmp.ensure((size_t)ntiles + 8, false, h->stream));
+    MMD_TRY(s.sendlist.ensure((size_t)s.sendnum + 8, false, h->stream));
+    hipLaunchKernelGGL((k_compact_count<BitsPred>), dim3(ntiles), dim3(256), 0, h->stream, pred, 0, nlast, h->flag_tmp.p);
+    MMD_TRY(mmd_exclusive_scan(h, h->flag_tmp.p, ntiles, nullptr));
+    hipLaunchKernelGGL((k_compact_scatter<BitsPred>), dim3(ntiles), dim3(256), 0, h->stream, pred, 0, nlast, h->flag_tmp.p, s.sendlist.p);
+    HIP_TRY(hipGetLastError());
+  }
+  h->sendlists_stale = false;
+  return 0;
+}
+
+// 2 = enqueued (deferred: counts still on the device), 1 = done, 0 = not applicable / overflow (the caller runs the swap-by-swap path), < 0 error
+static int borders_direct(mmd_handle* h, bool defer)
+{
+  DirectHalo& D = h->dh;
+  if(!D.opt_borders || !D.prev_valid || !dh_applies(h) || !h->borders_general_done || !h->opt_async_counts) return 0;
+  const bool forced = h->opt_force_transport != 0;
+  const int nlocal = h->nlocal;
+  dh_topology(h);
+  SelfSwaps W;
+  dh_self_swaps(h, W);
+  // fixed-size messages: message k of a side holds the lists of partner k; both sides size it from the same previous lengths
+  DbPack P;
+  DbUnpack U;
+  int caps_s[27], caps_r[27];
+  size_t off_s[28], off_r[28];
+  const int np_s = D.npeer_s, np_r = D.npeer_r;
+  bool any_self = false;
+  for(int l = 0; l < 26; l++) any_self = any_self || D.lps[l] < 0;
+  for(int k = 0; k <= 26; k++) { caps_s[k] = caps_r[k] = 0; }
+  for(int l = 0; l < 26; l++) {
+    caps_s[D.lps[l] < 0 ? np_s : D.lps[l]] += D.ns_prev[l];
+    caps_r[D.lpr[l] < 0 ? np_r : D.lpr[l]] += D.nr_prev[l];
+  }
+  const int nmsg_s = np_s + (any_self ? 1 : 0), nmsg_r = np_r + (any_self ? 1 : 0);
+  size_t bs = 0, br = 0;
+  long long cap_send_total = 0, cap_recv_total = 0;
+  // (opt_borders_est < 100: tests shrink the capacities to force the overflow protocol)
+  auto border_msg_cap = [h](int prev) { return h->opt_borders_est >= 100 ? ::border_msg_cap(prev) : (int)((long long)prev * h->opt_borders_est / 100); };
+  for(int k = 0; k < nmsg_s; k++) { caps_s[k] = border_msg_cap(caps_s[k]); off_s[k] = bs; bs += db_msg_bytes(caps_s[k]); cap_send_total += caps_s[k]; }
+  for(int k = 0; k < np_r; k++) { caps_r[k] = border_msg_cap(caps_r[k]); off_r[k] = br; br += db_msg_bytes(caps_r[k]); cap_recv_total += caps_r[k]; }
+  if(any_self) { caps_r[np_r] = caps_s[np_s]; cap_recv_total += caps_r[np_r]; }      // (the lists that stay here are read where k_db_pack wrote them)
+  if(cap_send_total > 0x3fffffff || cap_recv_total > 0x3fffffff) return 0;
+  const int est_ghost = (int)cap_recv_total;
+  MMD_TRY(mmd_ensure_atoms(h, nlocal + est_ghost + 1, true));
+  MMD_TRY(h->ghost_image.ensure((size_t)est_ghost + 8, false, h->stream));
+  MMD_TRY(h->ghost_bits.ensure((size_t)est_ghost + 8, false, h->stream));
+  MMD_TRY(h->buf_send.ensure(bs / sizeof(real) + 16, false, h->stream));
+  MMD_TRY(h->buf_recv.ensure(br / sizeof(real) + 16, false, h->stream));
+  MMD_TRY(h->bstate.ensure(64, false, h->stream));
+  const int nblk = std::max(1, div_up(nlocal, CP_TILE));
+  MMD_TRY(h->flag_tmp.ensure((size_t)BRD_ROWS * nblk + BRD_ROWS + 8, false, h->stream));
+  MMD_TRY(h->brd_bits.ensure((size_t)nlocal + 64, false, h->stream));
+  MMD_TRY(D.counts.ensure(32 * 30, false, h->stream));
+  MMD_TRY(D.idx.ensure((size_t)cap_send_total + 64, false, h->stream));
+  unsigned char* sbuf = (unsigned char*)h->buf_send.p;
+  unsigned char* rbuf = (unsigned char*)h->buf_recv.p;
+  for(int l = 0; l < 26; l++) {
+    P.lps[l] = D.lps[l] < 0 ? np_s : D.lps[l];
+    U.lpr[l] = D.lpr[l] < 0 ? np_r : D.lpr[l];
+    P.sx[l] = D.shift[l][0]; P.sy[l] = D.shift[l][1]; P.sz[l] = D.shift[l][2];
+    P.code[l] = D.code[l];
+  }
+  for(int k = 0; k < 27; k++) { P.cap[k] = caps_s[k]; U.cap[k] = caps_r[k]; P.msg[k] = nullptr; U.msg[k] = nullptr; }
+  for(int k = 0; k < nmsg_s; k++) P.msg[k] = sbuf + off_s[k];
+  for(int k = 0; k < np_r; k++) U.msg[k] = rbuf + off_r[k];
+  if(any_self) U.msg[np_r] = sbuf + off_s[np_s];
+  P.nmsg = nmsg_s; U.nmsg = nmsg_r;
+  P.idx_cap = (int)std::min<size_t>(D.idx.cap, 0x7fffffff);
+  int* tot = h->flag_tmp.p + (size_t)BRD_ROWS * nblk;
+  hipLaunchKernelGGL(k_brd_count, dim3(nblk), dim3(256), 0, h->stream, h->x.p, nlocal, W, h->brd_bits.p, h->flag_tmp.p, nblk, h->bstate.p);
+  hipLaunchKernelGGL(k_brd_scan, dim3(BRD_ROWS), dim3(256), 0, h->stream, h->flag_tmp.p, nblk, tot);
+  hipLaunchKernelGGL(k_dh_lists, dim3(nblk), dim3(256), 0, h->stream, nlocal, h->brd_bits.p, h->flag_tmp.p, nblk, tot, D.idx.p, D.counts.p, P.idx_cap);
+  hipLaunchKernelGGL(k_db_pack, dim3(std::max(1, div_up(cap_send_total, 256))), dim3(256), 0, h->stream, h->x.p, D.idx.p, D.counts.p, h->brd_bits.p, P, h->bstate.p);
+  HIP_TRY(hipGetLastError());
+  if(h->rccl) {
+    ncclComm_t c = (ncclComm_t)h->rccl;
+    NCCL_TRY(ncclGroupStart());
+    for(int k = 0; k < np_s; k++) { const size_t n = db_msg_bytes(caps_s[k]); h->halo_bytes += (long long)n; NCCL_TRY(ncclSend(sbuf + off_s[k], n, ncclChar, D.peer_s[k], c, h->stream)); }
+    for(int k = 0; k < np_r; k++) NCCL_TRY(ncclRecv(rbuf + off_r[k], db_msg_bytes(caps_r[k]), ncclChar, D.peer_r[k], c, h->stream));
+    NCCL_TRY(ncclGroupEnd());
+  } else {
+    const int np = std::max(np_s, np_r);        // (send k paired with receive k: the shift pattern of mmd_dh_exchange's host path)
+    for(int k = 0; k < np; k++) {
+      const bool hs = k < np_s, hr = k < np_r;
+      MMD_TRY(mmd_transport_sendrecv(h, sbuf + (hs ? off_s[k] : 0), hs ? db_msg_bytes(caps_s[k]) : 0, hs ? D.peer_s[k] : h->me, rbuf + (hr ? off_r[k] : 0),
+                                     hr ? db_msg_bytes(caps_r[k]) : 0, hr ? D.peer_r[k] : h->me));
+    }
+  }
+  const int cap_atoms = h->nmax, cap_ghost = (int)std::min<size_t>(std::min(h->ghost_image.cap, h->ghost_bits.cap), 0x7fffffff);
+  hipLaunchKernelGGL(k_db_unpack, dim3(std::max(1, div_up(cap_recv_total, 256))), dim3(256), 0, h->stream, h->x.p, nlocal, U, (const int*)D.counts.p, (const int*)(tot + BRD_NL),
+                     cap_atoms, cap_ghost, h->ghost_image.p, h->ghost_bits.p, h->type.p, h->bstate.p, D.h_counts_dev);
+  HIP_TRY(hipGetLastError());
+  MMD_TRY(reduce_flag_max(h, h->bstate.p + BST_OVF));
+  h->bf_est_nb = 0x7fffffff;
+  D.nsrc = 0; D.pending = true; D.ready = false;
+  (void)forced;
+  h->borders_direct_pending = true;
+  if(defer) {
+    h->nghost = std::min(cap_ghost, cap_atoms - nlocal - 1);
+    h->nghost = std::min(h->nghost, est_ghost);
+    h->nghost_dev = h->bstate.p + BST_GHOSTS + 6;
+    for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x.p) h->xalt_dummy_slot[k] = -1;
+    return 2;
+  }
+  HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(mmd_stream_sync(h));
+  return borders_fast_finish(h);
 }
 
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
@@ -1836,7 +2127,9 @@ static int borders_fast_finish(mmd_handle* h)
 {
   const int nlocal = h->nlocal;
   const int* hf = h->h_flags_big;
-  if(hf[BST_OVF] || hf[BST_NB] > h->bf_est_nb) return 0;        // estimates too small: general path (it grows the arrays)
+  const bool direct = h->borders_direct_pending;
+  h->borders_direct_pending = false;
+  if(hf[BST_OVF] || hf[BST_NB] > h->bf_est_nb) { if(direct) { h->dh.pending = false; h->dh.prev_valid = false; } return 0; }        // estimates too small: general path (it grows the arrays)
   int nall = nlocal;
   bool all_self = true;
   for(int q = 0; q < 6; q++) {
@@ -1852,7 +2145,8 @@ static int borders_fast_finish(mmd_handle* h)
   h->prev_nb = hf[BST_NB];
   h->prev_nghost = h->nghost;
   h->ghost_chain_ok = all_self;
-  h->borders_fast_runs++;
+  h->sendlists_stale = direct;               // (direct borders: the swaps' lists are derived from the slab bits when somebody asks)
+  if(direct) h->borders_direct_runs++; else h->borders_fast_runs++;
   return 1;
 }
 
@@ -1903,12 +2197,17 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   h->dh.ready = false; h->dh.pending = false;
   {
     const bool defer = h->in_reneighbor && h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && h->neigh_ready;
-    const int rc = borders_device_resident(h, defer);
+    h->borders_direct_pending = false;
+    h->sendlists_stale = false;
+    int rc = borders_direct(h, defer);             // several ranks: the 26 lists in one exchange (they are the plan of the per-step halo too)
+    if(rc < 0) return rc;
+    const bool direct = rc >= 1;
+    if(!direct) rc = borders_device_resident(h, defer);
     if(rc < 0) return rc;
     if(rc == 1) MMD_TRY(mmd_set_dummy(h));
     if(rc >= 1) {
       // several ranks: the lists of the direct per-step halo; their lengths arrive with the next host synchronisation (deferred: the neighbor build's)
-      MMD_TRY(dh_enqueue(h));
+      if(!direct) MMD_TRY(dh_enqueue(h));
       if(rc == 1 && h->dh.pending) { HIP_TRY(mmd_stream_sync(h)); MMD_TRY(dh_finish(h)); }
       h->neigh_nlocal = 0;
       h->tiles_ready = false;
@@ -1947,6 +2246,7 @@ int mmd_borders_deferred_resolve(mmd_handle* h)
 static int borders_general(mmd_handle* h)
 {
   int iswap = 0;
+  h->sendlists_stale = false; h->borders_direct_pending = false;
   MMD_TRY(h->ghost_image.ensure(1024, false, h->stream));
   MMD_TRY(h->ghost_root.ensure(1024, false, h->stream));
   h->ghost_chain_ok = true;                // stays true while every swap is a self swap

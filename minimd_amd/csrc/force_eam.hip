@@ -896,6 +896,7 @@ static int eam_fp_halo(mmd_handle* h)
     return 0;
   }
   if(h->dh.ready) return mmd_dh_exchange(h, 1);           // several ranks: one exchange with the up to 26 neighbours (DirectHalo, mmd_internal.hpp)
+  MMD_TRY(mmd_comm_sendlists_ensure(h));
   for(auto& s : h->swaps) {
     if(s.sendproc == h->me && !h->opt_force_transport) {
       if(s.sendnum) hipLaunchKernelGGL(k_fp_self, dim3(div_up(s.sendnum, 256)), dim3(256), 0, h->stream, h->fp.p, s.sendlist.p, s.sendnum, s.firstrecv);

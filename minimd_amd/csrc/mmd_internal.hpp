@@ -136,6 +136,8 @@ struct DirectHalo {
   // one message per distinct partner: the lists that go to (come from) the same rank travel end to end, in list order
   int sdst[26], rsrc[26];     // offset of list l inside the send / receive buffer (entries); -1: the list stays on this rank
   int npeer_s = 0, npeer_r = 0, peer_s[26], peer_r[26], peer_soff[27], peer_roff[27];
+  int lps[26], lpr[26];       // list l travels in outgoing message lps[l] / arrives in incoming message lpr[l] (-1: it stays on this rank)
+  int code[26];               // periodic-image code the ghosts of list l carry (image_add over the list's swaps, as pack_border accumulates it)
   int total_recv = 0;         // entries that arrive in the receive buffer
   int nsrc = 0, src_rank[26]; // RCCL: the distinct ranks whose 26 list lengths arrived (block k of the pinned copy)
   real shift[26][3];
@@ -144,6 +146,12 @@ struct DirectHalo {
   DevArr<int> counts;         // device: [0..25] lengths of my send lists, [32..57] of the lists I receive
   DevArr<int> scratch;
   int* h_counts = nullptr;    // pinned copy of `counts` (32 x 30 ints)
+  int* h_counts_dev = nullptr; // device view of h_counts (direct borders: k_db_unpack writes the lengths there itself)
+  // Direct borders (comm.hip, borders_direct): the plan of the previous re-neighboring sizes this one's fixed messages
+  bool prev_valid = false;
+  int ns_prev[26], nr_prev[26];
+  int opt_borders = 1;        // 1: Comm::borders on several ranks as ONE exchange of the 26 lists where a previous plan exists; 0: swap by swap
+  int opt_recv = 1;           // per-step halo: 1 = one message per partner + k_dh_unpack, 2 = every list received straight into its ghost slots
 };
 
 struct mmd_handle {
@@ -262,6 +270,10 @@ struct mmd_handle {
   DevArr<int> flag_tmp, bnd_list, bstate;
   DirectHalo dh;
   DevArr<unsigned char> brd_bits;      // one-rank borders in three launches: per owned atom, which of the six send slabs hold it
+  DevArr<unsigned char> ghost_bits;    // direct borders: the same bits of every ghost, as its owner computed them (the send lists of the swaps are derived from them on demand)
+  bool sendlists_stale = false;        // the ghosts came from the direct borders: swaps[q].sendlist is built when somebody asks (mmd_comm_sendlists_ensure)
+  long long borders_direct_runs = 0;
+  bool borders_direct_pending = false; // the borders in flight are the direct form (borders_fast_finish)
   DevArr<int> est, ex_list;            // handshake-free Comm::exchange (comm.hip): device-resident counts / leaver list
   int ex_prev_send[3] = {0, 0, 0}, ex_prev_recv[3][2] = {{0, 0}, {0, 0}, {0, 0}};     // migration counts of the last exchange (size the fixed messages)
   bool ex_prev_valid = false;
@@ -364,6 +376,7 @@ struct mmd_handle {
 int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve);
 int mmd_set_dummy(mmd_handle* h);
 int mmd_box_dev(mmd_handle* h);
+int mmd_comm_sendlists_ensure(mmd_handle* h);      // the six send lists of ref/comm.cpp:700-883 where the direct borders left them to be derived
 int mmd_dh_exchange(mmd_handle* h, int what);      // direct halo of a step: 0 positions (x), 1 EAM fp; only when h->dh.ready
 int mmd_borders_deferred_finish(mmd_handle* h);
 int mmd_run_reserve(mmd_handle* h);            // buffers the re-neighborings of a run will ask for, before its clock starts (comm.hip)

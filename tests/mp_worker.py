@@ -91,7 +91,7 @@ def sim(out, args, precision, rccl=False):
     dist.all_gather_object(counts, (nl, ng, s.handle.neighbor_info()["total"]))
     stats = [None] * world
     st = s.handle.run_stats()                                    # of Integrate::run (the last mmd_integrate_run of Sim.run)
-    for c in ("exchange_fast", "exchange_overflows", "borders_fast", "borders_general"):
+    for c in ("exchange_fast", "exchange_overflows", "borders_fast", "borders_general", "borders_direct"):
         st[c] = s.handle.counter(c)
     dist.all_gather_object(stats, st)
     if rank == 0:

@@ -104,3 +104,92 @@ def test_harness_scope_1_runs_np_3_and_8():
                        capture_output=True, text=True, timeout=2400)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert r.stdout.count("PASSED") == 3 and "np=8" in r.stdout, r.stdout[-3000:]
+
+
+# ---- direct borders: Comm::borders on several ranks as one exchange (ref/comm.cpp:700-883) --------------------------------------------------------
+def _loopback(args, options, prec="dp"):
+    """one rank whose periodic self swaps are forced through RCCL (the code path of a rank inside a multi-GPU run)"""
+    s = mm().Sim(args, precision=prec)
+    h = s.handle
+    h.init_rccl(h.unique_id(), 0, 1)
+    h.set_option("force_transport", 1)
+    for k, v in options.items():
+        h.set_option(k, v)
+    s.initial(); s.run()
+    d = h.download()
+    stats = h.run_stats()
+    info = h.comm_info()
+    swaps = [h.swap_info(q) for q in range(info["nswap"])]
+    lists = [h.sendlist(q).copy() for q in range(info["nswap"])]
+    out = {"rows": s.rows(), "x": d["x"].copy(), "f": d["f"].copy(), "v": d["v"].copy(), "counts": h.counts(), "swaps": swaps, "lists": lists,
+           "direct": h.counter("borders_direct"), "general": h.counter("borders_general"), "fast": h.counter("borders_fast"), "stats": stats}
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("deck,half,gn", [("in.lj.miniMD", 0, 0), ("in.lj.miniMD", 1, 1), ("in.lj.miniMD", 1, 0), ("in.eam.miniMD", 0, 0)])
+@pytest.mark.parametrize("recv", [1, 2])
+def test_direct_borders_equal_the_swap_by_swap_borders(deck, half, gn, recv):
+    """option direct_borders (default on): from the second re-neighboring of a run on, the ghosts of a rank are made by ONE exchange of the 26 image lists
+    (every owner decides from its own coordinates which later swaps forward its atoms) instead of the three dependent forwarding rounds of
+    ref/comm.cpp:700-883; halo_recv 2 receives every list of the per-step halo straight into its ghost slots. Same ghosts in the same slots with the same
+    positions, the same swap counts and — derived on demand from the slab bits that travelled along — the same six send lists; so the same rows, positions
+    and forces, bit for bit (half lists: to the order of the atomics) after 70 steps with 3 re-neighborings."""
+    args = ["-i", deck, "-s", "12" if "lj" in deck else "8", "-n", "70", "--half_neigh", str(half), "-gn", str(gn)]
+    a = _loopback(args, {"direct_borders": 0, "halo_recv": 1})
+    b = _loopback(args, {"direct_borders": 1, "halo_recv": recv})
+    assert a["direct"] == 0 and b["direct"] >= 2, (a["direct"], b["direct"], b["general"], b["fast"])
+    assert a["counts"][:2] == b["counts"][:2]
+    assert [(s_["sendnum"], s_["recvnum"], s_["firstrecv"]) for s_ in a["swaps"]] == [(s_["sendnum"], s_["recvnum"], s_["firstrecv"]) for s_ in b["swaps"]]
+    for la, lb in zip(a["lists"], b["lists"]):
+        np.testing.assert_array_equal(la, lb)
+    if half:
+        rows_close(a["rows"], b["rows"], 1e-10)
+        assert np.abs(a["x"] - b["x"]).max() <= 1e-9
+    else:
+        assert a["rows"] == b["rows"]
+        np.testing.assert_array_equal(a["x"], b["x"])
+        np.testing.assert_array_equal(a["f"], b["f"])
+        np.testing.assert_array_equal(a["v"], b["v"])
+    # one dependent transfer per re-neighboring instead of three: fewer bytes are not expected (the same records travel), fewer synchronisations are not
+    # needed either way (both forms defer their counts to the build's read-back)
+    assert b["stats"]["host_syncs"] <= a["stats"]["host_syncs"]
+
+
+def test_direct_borders_with_undersized_messages_fall_back(tmp_path):
+    """message capacities of 60 % of the previous lengths (borders_est 60): k_db_pack notices, the flag is max-reduced, and the borders are redone swap by
+    swap — the run is the one with the normal capacities."""
+    args = ["-s", "12", "-n", "70", "--half_neigh", "0"]
+    a = _loopback(args, {"direct_borders": 1})
+    b = _loopback(args, {"direct_borders": 1, "borders_est": 60})
+    assert a["direct"] >= 2 and b["direct"] == 0 and b["general"] > a["general"]
+    assert a["rows"] == b["rows"]
+    np.testing.assert_array_equal(a["x"], b["x"])
+
+
+def _mp_run(args, port, tmp_path, options="", nprocs=2, prec="dp"):
+    import json
+    out = str(tmp_path / ("mp_%d.json" % port))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MMD_TEST_OPTIONS=options)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nprocs), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "mp_worker.py"), "sim", out, prec] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("nprocs,args", [(2, ["-s", "12", "-n", "100", "--half_neigh", "0"]), (8, ["-s", "14", "-n", "60", "--half_neigh", "0"]),
+                                         (3, ["-i", "in.eam.miniMD", "-s", "10", "-n", "60", "--half_neigh", "0"]), (4, ["-s", "12", "-n", "60", "--half_neigh", "1"]),
+                                         (4, ["-s", "12", "-n", "60", "--half_neigh", "1", "-gn", "0"])])
+def test_direct_borders_on_several_ranks(nprocs, args, port, tmp_path):
+    """2 / 8 / 3 / 4 ranks sharing the GPU (2x1x1, 2x2x2, 3x1x1, 2x2x1: partners that are the same rank twice, diagonal partners, dimensions that wrap onto
+    the rank itself and stay local): direct borders against the swap-by-swap form — the same atoms and ghosts per rank, the same rows (half lists: to the
+    order of the atomics; with ghost newton the reverse communication runs on the send lists derived from the slab bits)."""
+    a = _mp_run(args, port, tmp_path, options="direct_borders=1", nprocs=nprocs)
+    b = _mp_run(args, free_port(), tmp_path, options="direct_borders=0", nprocs=nprocs)
+    assert all(st["borders_direct"] >= 2 for st in a["stats"]) and all(st["borders_direct"] == 0 for st in b["stats"]), (a["stats"], b["stats"])
+    assert a["counts"] == b["counts"]
+    if "--half_neigh" in args and args[args.index("--half_neigh") + 1] == "1":
+        rows_close([tuple(r) for r in a["rows"]], [tuple(r) for r in b["rows"]], 1e-10)
+    else:
+        assert a["rows"] == b["rows"]
