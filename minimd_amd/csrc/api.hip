@@ -85,13 +85,14 @@ extern "C" int mmd_destroy(mmd_handle* h)
   h->buf_send.release(); h->buf_recv.release(); h->est.release(); h->ex_list.release(); h->flag_tmp.release(); h->bnd_list.release(); h->bstate.release(); h->brd_bits.release(); h->ghost_bits.release(); h->partials.release();
   for(auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if(h->ev_x_ready) { (void)hipEventDestroy(h->ev_x_ready); (void)hipEventDestroy(h->ev_halo_done); }
+  for(int e = 0; e < 3; e++) if(h->ev_trial[e]) (void)hipEventDestroy(h->ev_trial[e]);
   h->tile_ghost.release(); h->tile_order.release(); h->tile_self.release(); h->tile_rowmax.release(); h->tile_rowsum.release(); h->tile_words.release(); h->tile_kcore.release(); h->xbuild.release(); h->core_words.release();
   if(h->h_result) (void)hipHostFree(h->h_result);
   if(h->d_result) (void)hipFree(h->d_result);
   if(h->h_flags) (void)hipHostFree(h->h_flags);
   if(h->h_flags_big) (void)hipHostFree(h->h_flags_big);
   if(h->dh.h_counts) (void)hipHostFree(h->dh.h_counts);
-  h->dh.idx.release(); h->dh.counts.release(); h->dh.scratch.release();
+  h->dh.idx.release(); h->dh.counts.release(); h->dh.scratch.release(); h->dh.gmap.release();
   if(h->d_flags) (void)hipFree(h->d_flags);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   if(h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
@@ -285,7 +286,7 @@ extern "C" int mmd_force_compute(mmd_handle* h, int evflag, double* eng_vdwl, do
   if(!h) { mmd_set_error("null handle"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
   double e = 0, v = 0;
-  if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }
+  if(h->ghosts_stale) { MMD_TRY(mmd_ghosts_refresh(h)); h->ghosts_stale = false; }
   MMD_TRY(force_compute_async(h, evflag, &e, &v, false));
   HIP_TRY(mmd_stream_sync(h));
   if(evflag) { if(eng_vdwl) *eng_vdwl = e; if(virial) *virial = v; }
@@ -311,7 +312,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     mmd_handle* h;
     ~TransientGuard() {
       h->fuse_now = 0; h->resolve_now = false; h->fold_reverse_now = false; h->core.mode_now = 0; h->zero_f_in_integrate = false;
-      h->halo_pending = false; h->in_reneighbor = false; h->pbc_defer = false; h->launch_ev_a = h->launch_ev_b = nullptr;
+      h->halo_pending = false; h->in_reneighbor = false; h->pbc_defer = false; h->launch_ev_a = h->launch_ev_b = nullptr; h->halo_in_x_allow = false;
       h->in_run = false; h->bin_owned_valid = false;
       h->spec_fn = nullptr; h->spec = SpecLaunch{nullptr, nullptr, nullptr}; h->spec_done = false;
       h->ovf_open = false;
@@ -319,7 +320,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   } transient_guard{h};
   h->in_run = true;
   // (a previous run that failed mid-step may have left the ghosts one step behind their owners)
-  if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }
+  if(h->ghosts_stale) { MMD_TRY(mmd_ghosts_refresh(h)); h->ghosts_stale = false; }
   if(first_step == 0) MMD_TRY(mmd_run_reserve(h));      // (no allocation inside the first re-neighborings)
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double t_start = mmd_wall();
@@ -332,7 +333,13 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   const bool reverse = h->halfneigh && h->ghost_newton;
   bool initial_done = false;        // initialIntegrate of this step already ran fused with the previous finalIntegrate
   // multi-rank (or forced-transport) runs with the LJ tile path overlap the forward halo with the interior tiles
-  const bool overlap = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport || h->opt_overlap >= 2);     // (2: also on one rank — the ghost update under the interior tiles)
+  const bool multi = h->nprocs > 1 || h->opt_force_transport != 0;
+  const bool overlap_auto = h->opt_overlap < 0 && multi;          // (-1: the form is chosen by measurement, collectively: mmd_internal.hpp)
+  bool overlap = (h->opt_overlap > 0 && (multi || h->opt_overlap >= 2)) || (overlap_auto && h->overlap_choice == 1);     // (2: also on one rank — the ghost update under the interior tiles)
+  // the trial of the automatic choice: B steps with, B steps without overlap behind a re-neighboring, no thermo step and no re-neighboring among them
+  int trial_phase = 0, trial_left = 0;
+  bool trial_armed = false;
+  const int trial_B = std::min(8, (h->neigh_every - 2) / 2);
   bool halo_pending = false, collect_pending = false, ovf_timed_now = false;
   int core_next = 0;                 // CoreRows: what the next force call may assume about the displacement since the build
   // the per-step halos are timed (into TIME_COMM) only where they are more than one tiny kernel: an event pair costs the stream
@@ -353,7 +360,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
                             !h->opt_lj_original && (!h->ghost_newton || fold);
   bool fused_force = false;          // this step's force launch carries finalIntegrate + the next initialIntegrate
   bool final_fused = false;          // this (last) step's force launch carries finalIntegrate
-  if(overlap && !h->ev_x_ready) {
+  if((overlap || overlap_auto) && !h->ev_x_ready) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_x_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
   }
@@ -383,6 +390,22 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   const bool spec_static = h->opt_spec > 0 && h->style == 0 && !h->halfneigh && h->nprocs == 1 && !overlap && !h->opt_force_transport && h->opt_spin_readback &&
                            h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && !h->opt_check_exchange && h->lj_uniform;
   for(int n = 0; n < ntimes; n++) {
+    if(overlap_auto && h->overlap_choice < 0) {
+      if(trial_phase == 0 && trial_armed) {
+        trial_armed = false;
+        bool ok = trial_B >= 2 && n + 2 * trial_B <= ntimes && (h->style == 0 ? (mmd_lj_tiles_available(h) || mmd_lj_half_tiles_available(h)) : mmd_eam_can_fuse_integrate(h));
+        for(int k = 0; k < 2 * trial_B && ok; k++) {
+          const int sk = first_step + n + 1 + k;
+          if(sk % h->neigh_every == 0 || (thermo_nstat > 0 && sk % thermo_nstat == 0)) ok = false;
+        }
+        if(ok) {
+          for(int e = 0; e < 3; e++) if(!h->ev_trial[e]) HIP_TRY(hipEventCreate(&h->ev_trial[e]));
+          HIP_TRY(hipEventRecord(h->ev_trial[0], h->stream));
+          trial_phase = 1; trial_left = trial_B;
+        }
+      }
+      overlap = trial_phase == 1;
+    }
     if(!initial_done) MMD_TRY(mmd_integrate_initial(h));
     initial_done = false;
     if((first_step + n + 1) % h->neigh_every) {
@@ -434,11 +457,18 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         const bool timed_step = time_halo && (halo_calls % 7 == 0);
         halo_calls++;
         if(timed_step) { halo_timed++; MMD_TRY(ev_begin(h, 5)); }
-        MMD_TRY(mmd_comm_communicate(h));
+        // several ranks, LJ over full lists in tile form: the partners' messages may stay where they land — behind the ghost slots of the position buffer —
+        // and this step's force launch stages the ghosts from there (halo_recv 3: no k_dh_unpack between the transfer and the force kernel)
+        h->halo_in_x_allow = h->style == 0 && !h->halfneigh && h->opt_fuse && h->opt_ghost_resolve && mmd_lj_tiles_available(h);
+        const int rch = mmd_comm_communicate(h);
+        h->halo_in_x_allow = false;
+        MMD_TRY(rch);
+        if(h->dh.x_unpack_pending) h->ghosts_stale = true;
         if(timed_step) MMD_TRY(ev_end(h));
       }
     } else {
       h->ghosts_stale = false;                   // (borders rebuilds every ghost)
+      trial_armed = true;
       const bool had_tiles = h->tiles_ready && h->neigh_nlocal == h->nlocal && h->nlocal > 0;
       if(h->opt_check_exchange && h->xold_n == h->nlocal) {    // ref/integrate.cpp:112-151 (warning text as there)
         double d_max = 0;
@@ -532,6 +562,22 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     } else if(final_fused) final_fused = false;      // (the launch did it)
     else MMD_TRY(mmd_integrate_final(h));
     if(collect_pending) { MMD_TRY(ev_collect(h, false)); collect_pending = false; }      // host work under the force kernel
+    if(trial_phase == 1 && --trial_left == 0) { HIP_TRY(hipEventRecord(h->ev_trial[1], h->stream)); trial_phase = 2; trial_left = trial_B; }
+    else if(trial_phase == 2 && --trial_left == 0) {
+      // both forms have run: the sums over the ranks decide, the same way on every rank (one host synchronisation, once per handle)
+      HIP_TRY(hipEventRecord(h->ev_trial[2], h->stream));
+      HIP_TRY(hipEventSynchronize(h->ev_trial[2]));
+      h->host_syncs++;
+      float ms_on = 0, ms_off = 0;
+      HIP_TRY(hipEventElapsedTime(&ms_on, h->ev_trial[0], h->ev_trial[1]));
+      HIP_TRY(hipEventElapsedTime(&ms_off, h->ev_trial[1], h->ev_trial[2]));
+      double t[2] = {ms_off * 1e-3 / trial_B, ms_on * 1e-3 / trial_B};
+      MMD_TRY(mmd_transport_allreduce(h, t, 2));
+      h->overlap_trial_s[0] = t[0]; h->overlap_trial_s[1] = t[1];
+      h->overlap_choice = t[1] < t[0] ? 1 : 0;
+      overlap = h->overlap_choice == 1;
+      trial_phase = 3;
+    }
     if(evflag) {
       MMD_TRY(mmd_temperature_async(h, 2));
       HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -541,7 +587,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       if(cb) cb(ctx, step, vals[0], vals[1], vals[2]);
     }
   }
-  if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }     // leave x consistent for the caller
+  if(h->ghosts_stale) { MMD_TRY(mmd_ghosts_refresh(h)); h->ghosts_stale = false; }     // leave x consistent for the caller
   MMD_TRY(ev_collect(h));
   MMD_TRY(ovf_harvest(h));
   h->timer[0] = mmd_wall() - t_start;
@@ -580,6 +626,15 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "borders_fast")) *value = h->borders_fast_runs;
   else if(!strcmp(name, "borders_general")) *value = h->borders_general_runs;
   else if(!strcmp(name, "borders_direct")) *value = h->borders_direct_runs;
+  else if(!strcmp(name, "overlap_choice")) *value = h->overlap_choice;        // halo overlap chosen by measurement: -1 undecided, 0 without, 1 with (option overlap = -1)
+  else if(!strcmp(name, "overlap_trial_off_ns")) *value = (long long)(h->overlap_trial_s[0] * 1e9);      // per step, summed over the ranks
+  else if(!strcmp(name, "overlap_trial_on_ns")) *value = (long long)(h->overlap_trial_s[1] * 1e9);
+  else if(!strcmp(name, "dh_total_recv")) *value = h->dh.total_recv;
+  else if(!strcmp(name, "dh_R")) *value = h->dh.R;
+  else if(!strcmp(name, "dh_gmap_live")) *value = h->dh.gmap_live ? 1 : 0;
+  else if(!strcmp(name, "dh_ready")) *value = h->dh.ready ? 1 : 0;
+  else if(!strcmp(name, "cand_src_halo")) *value = (h->cand_src_ready ? 1 : 0) + (h->cand_src_halo ? 2 : 0);
+  else if(!strcmp(name, "halo_in_x_steps")) *value = h->halo_in_x_steps;      // steps whose position halo stayed behind the ghost slots (no k_dh_unpack)
   else if(!strcmp(name, "device_bins_coarser")) *value = h->neigh_ready && (h->bg.nbin[0] != h->bg_ref.nbin[0] || h->bg.nbin[1] != h->bg_ref.nbin[1] || h->bg.nbin[2] != h->bg_ref.nbin[2]) ? 1 : 0;
   else if(!strcmp(name, "tiles_ready")) *value = h->tiles_ready ? 1 : 0;
   else if(!strcmp(name, "eam_lds_density")) *value = h->eam_diag[0];

@@ -13,6 +13,7 @@
 
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"
+#include "tile_lds.hpp"
 
 #define NCCL_TRY(expr)                                                                          \
   do {                                                                                          \
@@ -69,6 +70,7 @@ extern "C" int mmd_comm_setup(mmd_handle* h, mmd_float cutneigh, int me, int npr
     h->hi[d] = (h->myloc[d] + 1) * prd[d] / pg[d];
     h->need[d] = static_cast<int>(cutneigh * pg[d] / prd[d] + 1);
   }
+  for(int d = 0; d < 3; d++) { h->bg.sublo[d] = h->bg_ref.sublo[d] = h->lo[d]; h->bg.subhi[d] = h->bg_ref.subhi[d] = h->hi[d]; }      // (a Neighbor::setup that ran before this)
   for(auto& s : h->swaps) s.sendlist.release();
   h->swaps.clear();
   for(int d = 0; d < 3; d++) {
@@ -1673,20 +1675,25 @@ int mmd_dh_exchange(mmd_handle* h, int what)
   M.soff[26] = D.soff[26]; U.rbase[26] = D.rbase[26];
   const size_t esz = what == 0 ? sizeof(real4) : sizeof(real);
   const size_t per = what == 0 ? 4 : 1;
+  // halo_recv 3: the step loop allows it, the build named the boundary tiles' ghosts by gmap: positions are received behind the ghost slots and stay there
+  const bool in_x = what == 0 && h->halo_in_x_allow && D.opt_recv == 3 && D.gmap_live && h->cand_src_ready && h->cand_src_halo && h->rccl != nullptr &&
+                    (size_t)D.R + (size_t)D.total_recv <= (size_t)h->nmax;
+  if(what == 0) D.x_unpack_pending = in_x;
+  if(in_x) h->halo_in_x_steps++;
   const int nsend_remote = D.peer_soff[D.npeer_s];
   MMD_TRY(h->buf_send.ensure(per * (size_t)nsend_remote + 16, false, h->stream));
-  if(!(D.opt_recv >= 2 && h->rccl)) MMD_TRY(h->buf_recv.ensure(per * (size_t)D.total_recv + 16, false, h->stream));
+  if(!(D.opt_recv == 2 && h->rccl) && !in_x) MMD_TRY(h->buf_recv.ensure(per * (size_t)D.total_recv + 16, false, h->stream));
   if(D.total_send) {
     if(what == 0) hipLaunchKernelGGL(k_dh_pack_x, dim3(div_up(D.total_send, 256)), dim3(256), 0, h->stream, h->x.p, D.idx.p, D.total_send, M, (real4*)h->buf_send.p, h->nlocal);
     else hipLaunchKernelGGL(k_dh_pack_f, dim3(div_up(D.total_send, 256)), dim3(256), 0, h->stream, h->fp.p, D.idx.p, D.total_send, M, h->buf_send.p, h->nlocal);
     HIP_TRY(hipGetLastError());
   }
   unsigned char* sbuf = (unsigned char*)h->buf_send.p;
-  unsigned char* rbuf = (unsigned char*)h->buf_recv.p;
+  unsigned char* rbuf = in_x ? (unsigned char*)(h->x.p + D.R) : (unsigned char*)h->buf_recv.p;
   // halo_recv 2: every list is a message of its own, received straight into the slots of its ghosts (no receive buffer, no k_dh_unpack: one dependent launch
   // less per step; SURVEY K12 "unpack can be elided") — up to 26 sends + 26 receives in the group instead of one pair per distinct partner. Messages
   // between the same two ranks are matched in issue order: ascending list number on both sides (target_l(A) = B <=> source_l(B) = A, same lengths).
-  const bool recv_direct = D.opt_recv >= 2 && h->rccl != nullptr;
+  const bool recv_direct = D.opt_recv == 2 && h->rccl != nullptr;
   if(recv_direct) {
     h->halo_bytes += (long long)((size_t)nsend_remote * esz);
     ncclComm_t c = (ncclComm_t)h->rccl;
@@ -1721,7 +1728,7 @@ int mmd_dh_exchange(mmd_handle* h, int what)
                                      hr ? D.peer_r[k] : h->me));
     }
   }
-  if(D.total_recv && h->nghost) {
+  if(D.total_recv && h->nghost && !in_x) {
     if(what == 0) hipLaunchKernelGGL((k_dh_unpack<real4>), dim3(div_up(h->nghost, 256)), dim3(256), 0, h->stream, h->x.p + h->nlocal, (const real4*)h->buf_recv.p, h->nghost, U);
     else hipLaunchKernelGGL((k_dh_unpack<real>), dim3(div_up(h->nghost, 256)), dim3(256), 0, h->stream, h->fp.p + h->nlocal, (const real*)h->buf_recv.p, h->nghost, U);
     HIP_TRY(hipGetLastError());
@@ -1797,12 +1804,14 @@ struct DbUnpack {
   int cap[27];
   const unsigned char* msg[27];
   int nmsg;
+  int lpr_step[26];             // per-step halo: partner message list l arrives in (-1: the list stays on this rank and is written into its ghost slots)
+  int R;                        // first entry of the position buffer behind the ghost slots (0: no gmap wanted)
 };
 __global__ __launch_bounds__(256) void k_db_unpack(real4* __restrict__ x, int nlocal, DbUnpack U, const int* __restrict__ counts, const int* __restrict__ tot_any,
                                                    int cap_atoms, int cap_ghost, int* __restrict__ ghost_image, unsigned char* __restrict__ ghost_bits,
-                                                   int* __restrict__ type, int* __restrict__ bst, int* __restrict__ host_counts)
+                                                   int* __restrict__ type, int* __restrict__ bst, int* __restrict__ host_counts, int* __restrict__ gmap)
 {
-  __shared__ int s_nr[26], s_rbase[27], s_roff[26];
+  __shared__ int s_nr[26], s_rbase[27], s_roff[26], s_goff[26];
   if(threadIdx.x == 0) {
     int ovf = 0, rb = 0, mt[27];
     for(int m = 0; m < 27; m++) mt[m] = 0;
@@ -1815,7 +1824,7 @@ __global__ __launch_bounds__(256) void k_db_unpack(real4* __restrict__ x, int nl
       rb += n; mt[m] += n;
     }
     s_rbase[26] = rb;
-    if(rb > cap_ghost || nlocal + rb + 1 > cap_atoms) ovf = 1;
+    if(rb > cap_ghost || nlocal + rb + 1 > cap_atoms || (U.R > 0 && (nlocal + rb + 1 > U.R || U.R + rb > cap_atoms))) ovf = 1;
     if(blockIdx.x == 0) {
       if(ovf) bst[BST_OVF] = 1;
       int first = 0;
@@ -1829,6 +1838,13 @@ __global__ __launch_bounds__(256) void k_db_unpack(real4* __restrict__ x, int nl
       atomicAdd(&bst[BST_SEND + 3], counts[5]); atomicAdd(&bst[BST_SEND + 4], counts[8]); atomicAdd(&bst[BST_SEND + 5], counts[17]);
       for(int l = 0; l < 26; l++) { host_counts[l] = counts[l]; host_counts[32 + l] = s_nr[l]; }
     }
+  }
+  __syncthreads();
+  if(threadIdx.x < 26) {         // where list l starts in the per-step receive layout: the partners' messages in partner order, a partner's lists end to end
+    const int l = threadIdx.x, k = U.lpr_step[l];
+    int o = 0;
+    for(int m = 0; m < 26; m++) { const int km = U.lpr_step[m]; if(km >= 0 && (km < k || (km == k && m < l))) o += s_nr[m]; }
+    s_goff[l] = k < 0 ? -1 : o;
   }
   __syncthreads();
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1846,6 +1862,7 @@ __global__ __launch_bounds__(256) void k_db_unpack(real4* __restrict__ x, int nl
     type[nlocal + g] = (int)p.w;
     ghost_image[g] = a >> 8;
     ghost_bits[g] = (unsigned char)(a & 0xff);
+    if(U.R > 0) gmap[g] = s_goff[l] < 0 ? nlocal + g : U.R + s_goff[l] + (g - s_rbase[l]);
     // a swap of dimension d forwards the ghosts of the EARLIER dimensions that lie in its slab (lists 0-1: x, 2-7: up to y)
     F = a & 0xff;
     if(l >= 8) F = 0; else if(l >= 2) F &= 0x30; else F &= 0x3c;
@@ -1916,7 +1933,12 @@ static int borders_direct(mmd_handle* h, bool defer)
   if(any_self) { caps_r[np_r] = caps_s[np_s]; cap_recv_total += caps_r[np_r]; }      // (the lists that stay here are read where k_db_pack wrote them)
   if(cap_send_total > 0x3fffffff || cap_recv_total > 0x3fffffff) return 0;
   const int est_ghost = (int)cap_recv_total;
-  MMD_TRY(mmd_ensure_atoms(h, nlocal + est_ghost + 1, true));
+  // halo_recv 3: the per-step halo of the partners lands behind the ghost slots of the position buffer (DirectHalo::gmap)
+  const bool want_gmap = D.opt_recv == 3 && h->style == 0 && !h->halfneigh && h->opt_tiles && h->opt_build == 1 && h->lj_uniform && h->opt_ghost_resolve &&
+                         (long long)nlocal + 2 * (long long)est_ghost + 16 < (1 << MMD_SRC_BITS);
+  const int R = want_gmap ? ((nlocal + est_ghost + 1 + 3) & ~3) : 0;
+  MMD_TRY(mmd_ensure_atoms(h, want_gmap ? R + est_ghost + 1 : nlocal + est_ghost + 1, true));
+  if(want_gmap) MMD_TRY(D.gmap.ensure((size_t)est_ghost + 8, false, h->stream));
   MMD_TRY(h->ghost_image.ensure((size_t)est_ghost + 8, false, h->stream));
   MMD_TRY(h->ghost_bits.ensure((size_t)est_ghost + 8, false, h->stream));
   MMD_TRY(h->buf_send.ensure(bs / sizeof(real) + 16, false, h->stream));
@@ -1932,6 +1954,7 @@ static int borders_direct(mmd_handle* h, bool defer)
   for(int l = 0; l < 26; l++) {
     P.lps[l] = D.lps[l] < 0 ? np_s : D.lps[l];
     U.lpr[l] = D.lpr[l] < 0 ? np_r : D.lpr[l];
+    U.lpr_step[l] = D.lpr[l];
     P.sx[l] = D.shift[l][0]; P.sy[l] = D.shift[l][1]; P.sz[l] = D.shift[l][2];
     P.code[l] = D.code[l];
   }
@@ -1940,6 +1963,8 @@ static int borders_direct(mmd_handle* h, bool defer)
   for(int k = 0; k < np_r; k++) U.msg[k] = rbuf + off_r[k];
   if(any_self) U.msg[np_r] = sbuf + off_s[np_s];
   P.nmsg = nmsg_s; U.nmsg = nmsg_r;
+  U.R = R;
+  D.R = R; D.gmap_live = want_gmap; D.x_unpack_pending = false;
   P.idx_cap = (int)std::min<size_t>(D.idx.cap, 0x7fffffff);
   int* tot = h->flag_tmp.p + (size_t)BRD_ROWS * nblk;
   hipLaunchKernelGGL(k_brd_count, dim3(nblk), dim3(256), 0, h->stream, h->x.p, nlocal, W, h->brd_bits.p, h->flag_tmp.p, nblk, h->bstate.p);
@@ -1963,7 +1988,7 @@ static int borders_direct(mmd_handle* h, bool defer)
   }
   const int cap_atoms = h->nmax, cap_ghost = (int)std::min<size_t>(std::min(h->ghost_image.cap, h->ghost_bits.cap), 0x7fffffff);
   hipLaunchKernelGGL(k_db_unpack, dim3(std::max(1, div_up(cap_recv_total, 256))), dim3(256), 0, h->stream, h->x.p, nlocal, U, (const int*)D.counts.p, (const int*)(tot + BRD_NL),
-                     cap_atoms, cap_ghost, h->ghost_image.p, h->ghost_bits.p, h->type.p, h->bstate.p, D.h_counts_dev);
+                     cap_atoms, cap_ghost, h->ghost_image.p, h->ghost_bits.p, h->type.p, h->bstate.p, D.h_counts_dev, D.gmap.p);
   HIP_TRY(hipGetLastError());
   MMD_TRY(reduce_flag_max(h, h->bstate.p + BST_OVF));
   h->bf_est_nb = 0x7fffffff;
@@ -1980,6 +2005,25 @@ static int borders_direct(mmd_handle* h, bool defer)
   HIP_TRY(hipMemcpyAsync(h->h_flags_big, h->bstate.p, 40 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(mmd_stream_sync(h));
   return borders_fast_finish(h);
+}
+
+// the ghost slots of x in step with their owners again: after steps whose force kernels staged the ghosts themselves (one rank: from the owners;
+// several ranks with halo_recv 3: from the received messages behind the ghost slots — those are copied into the slots, nothing travels again)
+int mmd_ghosts_refresh(mmd_handle* h)
+{
+  DirectHalo& D = h->dh;
+  if(D.x_unpack_pending && D.ready) {
+    D.x_unpack_pending = false;
+    if(D.total_recv && h->nghost) {
+      DhUnpack U;
+      for(int l = 0; l < 26; l++) { U.rbase[l] = D.rbase[l]; U.rsrc[l] = D.rsrc[l]; }
+      U.rbase[26] = D.rbase[26];
+      hipLaunchKernelGGL((k_dh_unpack<real4>), dim3(div_up(h->nghost, 256)), dim3(256), 0, h->stream, h->x.p + h->nlocal, (const real4*)(h->x.p + D.R), h->nghost, U);
+      HIP_TRY(hipGetLastError());
+    }
+    return 0;
+  }
+  return mmd_comm_communicate(h);
 }
 
 // returns 1 when the fast path produced the ghosts, 0 when the caller must run the general path
@@ -2129,7 +2173,7 @@ static int borders_fast_finish(mmd_handle* h)
   const int* hf = h->h_flags_big;
   const bool direct = h->borders_direct_pending;
   h->borders_direct_pending = false;
-  if(hf[BST_OVF] || hf[BST_NB] > h->bf_est_nb) { if(direct) { h->dh.pending = false; h->dh.prev_valid = false; } return 0; }        // estimates too small: general path (it grows the arrays)
+  if(hf[BST_OVF] || hf[BST_NB] > h->bf_est_nb) { if(direct) { h->dh.pending = false; h->dh.prev_valid = false; h->dh.gmap_live = false; } return 0; }        // estimates too small: general path (it grows the arrays)
   int nall = nlocal;
   bool all_self = true;
   for(int q = 0; q < 6; q++) {
@@ -2199,6 +2243,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
     const bool defer = h->in_reneighbor && h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && h->neigh_ready;
     h->borders_direct_pending = false;
     h->sendlists_stale = false;
+    h->dh.gmap_live = false; h->dh.x_unpack_pending = false;
     int rc = borders_direct(h, defer);             // several ranks: the 26 lists in one exchange (they are the plan of the per-step halo too)
     if(rc < 0) return rc;
     const bool direct = rc >= 1;

@@ -101,6 +101,7 @@ struct LJParams {            // uniform-table fast path (all type pairs identica
 
 struct BinGeom {             // Neighbor::setup result (ref/neighbor.cpp:318-452) + block-major numbering
   real prd[3], bininv[3], binsize[3];
+  real sublo[3], subhi[3];   // this rank's sub-box (the whole box on one rank)
   int nbin[3], mbinlo[3], mbin[3];
   int blkshift[3];           // parity shift so that the periodic box edge falls on a block boundary
   int nblk[3];               // 2x2x2-bin blocks per dimension
@@ -151,7 +152,16 @@ struct DirectHalo {
   bool prev_valid = false;
   int ns_prev[26], nr_prev[26];
   int opt_borders = 1;        // 1: Comm::borders on several ranks as ONE exchange of the 26 lists where a previous plan exists; 0: swap by swap
-  int opt_recv = 1;           // per-step halo: 1 = one message per partner + k_dh_unpack, 2 = every list received straight into its ghost slots
+  int opt_recv = 3;           // per-step halo: 1 = one message per partner + k_dh_unpack; 2 = every list a message of its own, received straight into its ghost slots;
+                              // 3 = 1, and where the tile kernels can follow (LJ full lists, no overlap) the partners' messages land in the position buffer itself,
+                              // behind the ghost slots, and the boundary tiles read them there: no k_dh_unpack on the step
+  // halo_recv 3: the position buffers are longer than owned + ghosts; entry R + o is record o of the per-step receive layout (one message per partner, in partner
+  // order). gmap[g] (written by k_db_unpack) = where ghost g's position arrives: R + o, or its own slot nlocal + g for a list that stays on this rank; the build
+  // writes the boundary tiles' candidate lists once more with every ghost named by gmap (tile_cand_src), and a step's force kernel stages from there.
+  DevArr<int> gmap;
+  int R = 0;
+  bool gmap_live = false;     // gmap describes the ghosts of the current borders (set when they were made by the direct borders)
+  bool x_unpack_pending = false;   // the last position halo was received behind the ghost slots and has not been copied into them (mmd_ghosts_refresh does)
 };
 
 struct mmd_handle {
@@ -200,6 +210,8 @@ struct mmd_handle {
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
   DevArr<int> tile_cand_src;              // one-rank runs: tile_cand with every ghost named by its owner + image code (GhostResolve, tile_lds.hpp)
   bool cand_src_ready = false;
+  bool cand_src_halo = false;            // tile_cand_src names the ghosts by where the per-step halo delivers them (DirectHalo::gmap), not by owner + image code
+  bool halo_in_x_allow = false;          // transient (Integrate::run): this step's position halo may stay behind the ghost slots (the force launch that follows reads it there)
   DevArr<real> box_dev;                   // the box lengths in device memory (ghost_shifted fetches them inside its rare branch)
   bool box_dev_valid = false;
   DevArr<unsigned short> tile_self;       // half lists: union slot of each tile atom itself (0xffff: not in the union)
@@ -226,7 +238,14 @@ struct mmd_handle {
   DevArr<int> tile_ghost, tile_order;     // per tile: references a ghost atom?; tiles ordered interior-first
   int ntiles_interior = 0;
   hipEvent_t ev_x_ready = nullptr, ev_halo_done = nullptr;
-  int opt_overlap = 1;   // per-tile union of referenced candidates (compact, global indices)
+  // several ranks: the forward halo of a step on the communication stream under the interior tiles, the boundary tiles behind it. 1 on, 0 off, 2 on (one
+  // rank too); -1 (default) = decided by measurement: after the first re-neighboring of a run a few steps are timed in each form, the times are summed
+  // over the ranks, and every rank keeps the faster form (overlap_choice; the split costs two launches per step + the tile order per build, and only a real
+  // transfer can pay for it — in RCCL loop-back on one GPU it does not)
+  int opt_overlap = -1;
+  int overlap_choice = -1;           // -1 not decided yet, 0 / 1
+  double overlap_trial_s[2] = {0, 0}; // per step, summed over the ranks: [0] without, [1] with overlap
+  hipEvent_t ev_trial[3] = {nullptr, nullptr, nullptr};
   int tile_cstride = 0, tile_cmax = 0;
   DevArr<unsigned short> nl16;
   int opt_tiles = 1;
@@ -272,7 +291,7 @@ struct mmd_handle {
   DevArr<unsigned char> brd_bits;      // one-rank borders in three launches: per owned atom, which of the six send slabs hold it
   DevArr<unsigned char> ghost_bits;    // direct borders: the same bits of every ghost, as its owner computed them (the send lists of the swaps are derived from them on demand)
   bool sendlists_stale = false;        // the ghosts came from the direct borders: swaps[q].sendlist is built when somebody asks (mmd_comm_sendlists_ensure)
-  long long borders_direct_runs = 0;
+  long long borders_direct_runs = 0, halo_in_x_steps = 0;
   bool borders_direct_pending = false; // the borders in flight are the direct form (borders_fast_finish)
   DevArr<int> est, ex_list;            // handshake-free Comm::exchange (comm.hip): device-resident counts / leaver list
   int ex_prev_send[3] = {0, 0, 0}, ex_prev_recv[3][2] = {{0, 0}, {0, 0}, {0, 0}};     // migration counts of the last exchange (size the fixed messages)
@@ -377,6 +396,7 @@ int mmd_ensure_atoms(mmd_handle* h, int n, bool preserve);
 int mmd_set_dummy(mmd_handle* h);
 int mmd_box_dev(mmd_handle* h);
 int mmd_comm_sendlists_ensure(mmd_handle* h);      // the six send lists of ref/comm.cpp:700-883 where the direct borders left them to be derived
+int mmd_ghosts_refresh(mmd_handle* h);             // ghost slots of x in step with their owners again (after steps whose force kernels read the ghosts elsewhere)
 int mmd_dh_exchange(mmd_handle* h, int what);      // direct halo of a step: 0 positions (x), 1 EAM fp; only when h->dh.ready
 int mmd_borders_deferred_finish(mmd_handle* h);
 int mmd_run_reserve(mmd_handle* h);            // buffers the re-neighborings of a run will ask for, before its clock starts (comm.hip)

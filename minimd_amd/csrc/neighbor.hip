@@ -47,6 +47,7 @@ extern "C" int mmd_neighbor_setup(mmd_handle* h, const int nbin[3], mmd_float cu
   auto geometry = [&](const int nb[3], BinGeom& g) {
     for(int d = 0; d < 3; d++) {
       g.prd[d] = h->prd[d];
+      g.sublo[d] = h->lo[d]; g.subhi[d] = h->hi[d];
       g.nbin[d] = nb[d];
       g.binsize[d] = h->prd[d] / nb[d];
       g.bininv[d] = 1.0 / g.binsize[d];
@@ -1066,7 +1067,9 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // whose atoms come within the cutoff of a face of the (one-rank) box — a superset of the tiles tile_ghost will flag; the tile kernels read it for those only
   if(cand_src != nullptr && !cand_src_all) {             // (EAM asks for every tile: its sweeps then need no per-tile choice, which costs them registers they do not have)
     const float m = 1.001f * (float)cutneigh + 1.0e-3f * (float)g.prd[0] * 1.0e-3f + 1.0e-4f;
-    const bool near_face = bx0 - m < 0.0f || bx1 + m > (float)g.prd[0] || by0 - m < 0.0f || by1 + m > (float)g.prd[1] || bz0 - m < 0.0f || bz1 + m > (float)g.prd[2];
+    // (faces of this rank's sub-box: the whole box on one rank)
+    const bool near_face = bx0 - m < (float)g.sublo[0] || bx1 + m > (float)g.subhi[0] || by0 - m < (float)g.sublo[1] || by1 + m > (float)g.subhi[1] ||
+                           bz0 - m < (float)g.sublo[2] || bz1 + m > (float)g.subhi[2];
     if(!near_face) cand_src = nullptr;
   }
   // PF: local origin = the box's lower corner (exact in `real`); |local coordinate| of my atom and of every candidate that
@@ -1299,7 +1302,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             const int cj = __float_as_int(s_buf[NB2_IDX + gq + lane]);
             tile_cand[cbase + slot] = cj;
             // (one rank: the same list with a ghost named by its owner and image code, for tile kernels that stage ghosts from their owners)
-            if(cand_src != nullptr) cand_src[cbase + slot] = cj >= nlocal && cj < nall ? (ghost_root[cj - nlocal] | ((ghost_image[cj - nlocal] + 1) << MMD_SRC_BITS)) : cj;
+            // (several ranks, ghost_image == nullptr: ghost_root is DirectHalo::gmap — the entry of the position buffer the per-step halo delivers the ghost to)
+            if(cand_src != nullptr) cand_src[cbase + slot] = cj >= nlocal && cj < nall ? (ghost_image != nullptr ? (ghost_root[cj - nlocal] | ((ghost_image[cj - nlocal] + 1) << MMD_SRC_BITS)) : ghost_root[cj - nlocal]) : cj;
           }
           if(MODE != 0) { const unsigned own = s_own[gq + lane]; if(own != 0xffu) s_self[own] = (unsigned short)slot; }
         }
@@ -1767,6 +1771,17 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       MMD_TRY(h->tile_cand_src.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
       cand_src_p = h->tile_cand_src.p;
     }
+    // several ranks, LJ over full lists: the same second list with every ghost named by the entry of the position buffer its per-step halo message delivers it to
+    // (DirectHalo::gmap, written by the direct borders): the step's force kernel needs no k_dh_unpack in front of it
+    const int* src_root = (const int*)h->ghost_root.p;
+    const int* src_image = (const int*)h->ghost_image.p;
+    h->cand_src_halo = false;
+    if(cand_src_p == nullptr && h->dh.gmap_live && h->dh.opt_recv == 3 && h->opt_build == 1 && h->opt_ghost_resolve && h->style == 0 && !h->halfneigh && !h->ghosts_uploaded) {
+      MMD_TRY(h->tile_cand_src.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
+      cand_src_p = h->tile_cand_src.p;
+      src_root = (const int*)h->dh.gmap.p; src_image = nullptr;
+      h->cand_src_halo = true;
+    }
     if(fill_scans)
       hipLaunchKernelGGL(k_pencil_fill_scan, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
                          h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev, lohi ? (const unsigned*)h->pencil_lohi.p : (const unsigned*)nullptr, (const int*)h->bin_start.p);
@@ -1796,17 +1811,17 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 #define LAUNCH_ROWS(M) LAUNCH_ROWS2(M, 0)
 #define LAUNCH_ROWS2(M, CR)                                                                                                             \
   hipLaunchKernelGGL((k_build_rows<M, CR>), dim3(xcd_grid(h->ntiles)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,     \
-                     h->ghost_image.p, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
+                     src_image, g, h->ntiles, nlocal, nlocal + h->nghost, h->cutneigh, h->cutneighsq, h->maxneighs, h->tile_cstride, \
                      h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
                      h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate, nt_dev, h->nghost_dev, \
-                     core_thr, h->xbuild.p, h->tile_kcore.p, cand_src_p, (const int*)h->ghost_root.p, h->style == 1 ? 1 : 0)
+                     core_thr, h->xbuild.p, h->tile_kcore.p, cand_src_p, src_root, h->style == 1 ? 1 : 0)
       if(h->opt_build == 1) {             // one owned atom per lane (production)
         if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
         reduce_in_publish = h->opt_spin_readback && h->in_run && h->ntiles <= 4096;
         if(!reduce_in_publish)
         hipLaunchKernelGGL(k_tile_reduce, dim3(std::min(32, std::max(1, div_up(h->ntiles, 1024)))), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
                            h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr);
-        order_here = h->opt_overlap && (h->nprocs > 1 || h->opt_force_transport || h->opt_overlap >= 2) && h->ntiles > 0;
+        order_here = (h->opt_overlap > 0 || (h->opt_overlap < 0 && h->overlap_choice != 0)) && (h->nprocs > 1 || h->opt_force_transport || h->opt_overlap >= 2) && h->ntiles > 0;
         if(order_here) {                  // several ranks: the interior-first order of the halo overlap, no extra host synchronisation
           const int nb_o = div_up(h->ntiles, 1024);
           MMD_TRY(h->tile_order.ensure((size_t)h->ntiles + 8, false, h->stream));
@@ -1918,7 +1933,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       h->ntiles_hint = h->ntiles;
       h->neigh_nlocal = nlocal;
       h->ntiles_interior = order_here ? h->h_flags[13] : -1;    // (-1: the interior/boundary order is derived on demand, mmd_order_tiles)
-      h->cand_src_ready = cand_src_p != nullptr && h->ghost_chain_ok;
+      h->cand_src_ready = cand_src_p != nullptr && (h->ghost_chain_ok || h->cand_src_halo);
       h->spec_done = verdict != 0;
       if(verdict && h->spec_fused)           // the gated kernel wrote the dummy atom of the second position buffer behind the last ghost
         for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x_alt.p) h->xalt_dummy_slot[k] = nlocal + h->nghost;
@@ -2092,7 +2107,7 @@ extern "C" int mmd_neighbor_download(mmd_handle* h, int* neighbors, int maxneigh
   if(h->halfneigh && h->ghost_newton && n && h->tiles_ready && !h->rows_uploaded) {
     // (valid directly after mmd_neighbor_build: the rows are re-derived from the CURRENT positions and the bins of the last build; ghosts that
     //  a run left one step behind their owners are brought up to date first)
-    if(h->ghosts_stale) { MMD_TRY(mmd_comm_communicate(h)); h->ghosts_stale = false; }
+    if(h->ghosts_stale) { MMD_TRY(mmd_ghosts_refresh(h)); h->ghosts_stale = false; }
     // half lists with ghost newton: the device list partitions the pairs by the (z,y,x) order of the two positions, the reference by
     // its half stencil of bins + the same-bin rules (ref/neighbor.cpp:143-182, :424-441). What crosses the boundary is the REFERENCE's
     // list: rebuilt here from the same binned atoms with the reference's rule (k_build<3>), rows equal the oracle's as sets.

@@ -122,23 +122,26 @@ def _loopback(args, options, prec="dp"):
     swaps = [h.swap_info(q) for q in range(info["nswap"])]
     lists = [h.sendlist(q).copy() for q in range(info["nswap"])]
     out = {"rows": s.rows(), "x": d["x"].copy(), "f": d["f"].copy(), "v": d["v"].copy(), "counts": h.counts(), "swaps": swaps, "lists": lists,
-           "direct": h.counter("borders_direct"), "general": h.counter("borders_general"), "fast": h.counter("borders_fast"), "stats": stats}
+           "direct": h.counter("borders_direct"), "general": h.counter("borders_general"), "fast": h.counter("borders_fast"), "stats": stats, "in_x": h.counter("halo_in_x_steps")}
     s.close()
     return out
 
 
 @pytest.mark.parametrize("deck,half,gn", [("in.lj.miniMD", 0, 0), ("in.lj.miniMD", 1, 1), ("in.lj.miniMD", 1, 0), ("in.eam.miniMD", 0, 0)])
-@pytest.mark.parametrize("recv", [1, 2])
+@pytest.mark.parametrize("recv", [1, 2, 3])
 def test_direct_borders_equal_the_swap_by_swap_borders(deck, half, gn, recv):
     """option direct_borders (default on): from the second re-neighboring of a run on, the ghosts of a rank are made by ONE exchange of the 26 image lists
     (every owner decides from its own coordinates which later swaps forward its atoms) instead of the three dependent forwarding rounds of
-    ref/comm.cpp:700-883; halo_recv 2 receives every list of the per-step halo straight into its ghost slots. Same ghosts in the same slots with the same
+    ref/comm.cpp:700-883; halo_recv 2 receives every list of the per-step halo straight into its ghost slots; halo_recv 3 (default) leaves the partners'
+    messages where they land, behind the ghost slots of the position buffer, and the LJ full-list force kernel stages the boundary tiles' ghosts from there
+    (no k_dh_unpack on the step; the ghost slots are brought up to date when the run ends). Same ghosts in the same slots with the same
     positions, the same swap counts and — derived on demand from the slab bits that travelled along — the same six send lists; so the same rows, positions
     and forces, bit for bit (half lists: to the order of the atomics) after 70 steps with 3 re-neighborings."""
     args = ["-i", deck, "-s", "12" if "lj" in deck else "8", "-n", "70", "--half_neigh", str(half), "-gn", str(gn)]
-    a = _loopback(args, {"direct_borders": 0, "halo_recv": 1})
-    b = _loopback(args, {"direct_borders": 1, "halo_recv": recv})
+    a = _loopback(args, {"direct_borders": 0, "halo_recv": 1, "overlap": 0})
+    b = _loopback(args, {"direct_borders": 1, "halo_recv": recv, "overlap": 0})
     assert a["direct"] == 0 and b["direct"] >= 2, (a["direct"], b["direct"], b["general"], b["fast"])
+    assert a["in_x"] == 0 and (b["in_x"] > 30) == (recv == 3 and half == 0 and "lj" in deck), (recv, b["in_x"])
     assert a["counts"][:2] == b["counts"][:2]
     assert [(s_["sendnum"], s_["recvnum"], s_["firstrecv"]) for s_ in a["swaps"]] == [(s_["sendnum"], s_["recvnum"], s_["firstrecv"]) for s_ in b["swaps"]]
     for la, lb in zip(a["lists"], b["lists"]):
@@ -193,3 +196,27 @@ def test_direct_borders_on_several_ranks(nprocs, args, port, tmp_path):
         rows_close([tuple(r) for r in a["rows"]], [tuple(r) for r in b["rows"]], 1e-10)
     else:
         assert a["rows"] == b["rows"]
+
+
+@pytest.mark.parametrize("deck,half", [("in.lj.miniMD", 0), ("in.lj.miniMD", 1), ("in.eam.miniMD", 0)])
+def test_overlap_chosen_by_measurement_changes_nothing(deck, half):
+    """option overlap -1 (default): behind the first re-neighboring of a run 2 x 8 steps are timed with and without the halo under the interior tiles, the
+    times are summed over the ranks and every rank keeps the faster form. Whatever the choice, and across the switch inside the run, the results are those of
+    a run that never overlapped (full lists: bit for bit)."""
+    args = ["-i", deck, "-s", "12" if "lj" in deck else "8", "-n", "70", "--half_neigh", str(half)]
+    a = _loopback(args, {"overlap": 0})
+    m = mm()
+    s = m.Sim(args)
+    h = s.handle
+    h.init_rccl(h.unique_id(), 0, 1)
+    h.set_option("force_transport", 1)
+    s.initial(); s.run()
+    d = h.download()
+    assert h.counter("overlap_choice") in (0, 1) and h.counter("overlap_trial_on_ns") > 0 and h.counter("overlap_trial_off_ns") > 0
+    if half:
+        rows_close(a["rows"], s.rows(), 1e-10)
+    else:
+        assert a["rows"] == s.rows()
+        np.testing.assert_array_equal(a["x"], d["x"])
+        np.testing.assert_array_equal(a["f"], d["f"])
+    s.close()
