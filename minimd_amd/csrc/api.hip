@@ -387,7 +387,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     return rc;
   };
   // the launch behind the build: LJ over full lists in tile form on one rank, no halo overlap, lists of the previous build to size it from
-  const bool spec_static = h->opt_spec > 0 && h->style == 0 && !h->halfneigh && h->nprocs == 1 && !overlap && !h->opt_force_transport && h->opt_spin_readback &&
+  // (several ranks: the same, when the step's halo is not overlapped — the ghosts Comm::borders has just made are what this launch reads, the verdict covers the
+  //  max-reduced overflow flag of the direct borders; the direct-halo plan is finished behind it, when the words have arrived)
+  const bool spec_static = h->opt_spec > 0 && h->style == 0 && !h->halfneigh && h->opt_spin_readback &&
                            h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && !h->opt_check_exchange && h->lj_uniform;
   for(int n = 0; n < ntimes; n++) {
     if(overlap_auto && h->overlap_choice < 0) {
@@ -508,13 +510,18 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       {
         const int ev_rb = thermo_nstat > 0 && ((first_step + n + 1) % thermo_nstat == 0);
         // (only with the device-side phase clocks: an event bracket around the build is open here, and the launch would attach its own pair inside it)
-        if(spec_static && had_tiles && !ev_rb && dev_clock) h->spec_fn = [&launch_force, n]() { return launch_force(n, 0); };
+        // (several ranks: the phase clocks are event pairs — the Neighbor::build bracket is closed in front of the launch, so that it does not take the force kernel in)
+        bool neigh_bracket_closed = false;
+        if(spec_static && !overlap && had_tiles && !ev_rb && dev_clock) h->spec_fn = [&launch_force, n]() { return launch_force(n, 0); };
+        else if(spec_static && !overlap && had_tiles && !ev_rb && multi && (h->opt_overlap >= 0 || h->overlap_choice == 0))
+          h->spec_fn = [&launch_force, &neigh_bracket_closed, h, n]() { if(!neigh_bracket_closed) { MMD_TRY(ev_end(h)); neigh_bracket_closed = true; } return launch_force(n, 0); };
         const int rcb = mmd_neighbor_build(h);
         h->spec_fn = nullptr;
         MMD_TRY(rcb);
+        if(!dev_clock && !neigh_bracket_closed) MMD_TRY(ev_end(h));
       }
       h->clk_slot = -1;
-      if(!dev_clock) MMD_TRY(ev_end(h));
+      if(!dev_clock) {}
       else if(h->clk_written == 7) {
         // (a build that went through a fall-back or ran twice leaves stamps that do not line up: that re-neighboring is not clocked)
         long long c[3];

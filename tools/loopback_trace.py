@@ -9,6 +9,8 @@ h = s.handle
 h.init_rccl(h.unique_id(), 0, 1)
 h.set_option("force_transport", 1)
 h.set_option("overlap", ov)
+for kv in filter(None, os.environ.get("MMD_TRACE_OPTIONS", "").split(",")):
+    k, v = kv.split("="); h.set_option(k, int(v))
 s.initial()
 s.run_steps(60)
 s.close()
