@@ -139,10 +139,21 @@ def rank_path_loopback_child(size, steps):
     best = min(s.run_steps(steps) for _ in range(2))
     st = h.run_stats()
     nat = s.natoms()
+    choice = h.counter("overlap_choice")
+    trial = {"without_overlap_ms_per_step": h.counter("overlap_trial_off_ns") * 1e-6, "with_overlap_ms_per_step": h.counter("overlap_trial_on_ns") * 1e-6}
+    in_x, direct = h.counter("halo_in_x_steps"), h.counter("borders_direct")
+    # the form the automatic choice did NOT take, on the same state (explicit option), for the record
+    other = 1 - choice if choice in (0, 1) else 1
+    h.set_option("overlap", other)
+    s.run_steps(40)
+    best_other = min(s.run_steps(steps) for _ in range(2))
     s.close()
+    vals = {choice if choice in (0, 1) else 0: nat * steps / best / 1e6, other: nat * steps / best_other / 1e6}
     print(json.dumps({"value": nat * steps / best / 1e6, "unit": "Matom-steps/s", "ms_per_step": best * 1e3 / steps, "steps": steps,
                       "halo_bytes_per_step": st["bytes_sent"] / steps,
-                      "note": "one rank, self swaps through RCCL loop-back on one GPU (no xGMI transfer)"}), flush=True)
+                      "overlap": {"chosen": choice, "trial": trial, "value_without_overlap": vals.get(0), "value_with_overlap": vals.get(1)},
+                      "direct_borders": direct, "steps_without_unpack_kernel": in_x,
+                      "note": "one rank, self swaps through RCCL loop-back on one GPU (no xGMI transfer); halo overlap chosen by the library's own timed trial (option overlap -1)"}), flush=True)
 
 
 def rank_path_loopback(size, steps):
@@ -152,8 +163,8 @@ def rank_path_loopback(size, steps):
     time excepted. A diagnostic next to `value` (which is the production one-rank path), never instead of it. Runs as a process of its own with a
     time limit: whatever happens in there, the bench line is printed."""
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--loopback-child", "--size", str(size), "--steps", str(steps)],
-                           capture_output=True, text=True, timeout=240)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--loopback-child", "--size", str(size), "--steps", str(max(steps, 60))],
+                           capture_output=True, text=True, timeout=300)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return {"value": None, "error": (r.stderr or r.stdout)[-300:]}
@@ -355,8 +366,15 @@ def main():
     ninfo = sim.handle.neighbor_info()
     kbar = ninfo["total"] / max(nlocal, 1)
     bpa = algorithmic_bytes_per_atom(kbar, nghost / max(nlocal, 1))
-    k_ms = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
+    # the force kernel's time: EVERY launch of the timed region stamps the device clock itself (first workgroup's start, last workgroups' end: no event
+    # packets on the stream) — `frac` is their average, the launch behind the neighbor build and the last one of the slice included; the event pairs on
+    # every 7th launch (rocprof's notion of a kernel's duration: dispatch to completion signal) are reported next to it as the sampled figure
+    k_ms_sampled = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
+    clk_n = sim.handle.counter("force_clock_launches")
+    k_ms_all = sim.handle.counter("force_clock_ns") * 1e-6 / clk_n if clk_n > 0 else None
+    k_ms = k_ms_all if k_ms_all else k_ms_sampled
     achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+    achieved_sampled = bpa * nlocal / (k_ms_sampled * 1e-3) / 1e9 if k_ms_sampled > 0 else None
     traffic, traffic_source = None, None
     for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
@@ -405,13 +423,17 @@ def main():
         # new x: +80 B/atom, and skips the f store: -24 B); `achieved` still counts only SURVEY §8d's force-kernel bytes
         "roofline": {"bound": "hbm", "kernel": "k_lj_full_tile (ForceLJ::compute_fullneigh + fused Integrate)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
-                     # `frac` is the in-run figure (events on the timed region's own launches — every 7th launch, every launch when --steps < 14; these launches also carry the
-                     # integrator); `frac_kernel_only` = SURVEY 8(d)'s force kernel alone on the same thermalised state, 20 launches
+                     # `frac` is the in-run figure over ALL launches of the timed region (these launches also carry the integrator); `frac_sampled` the event-pair figure of
+                     # every 7th launch (every launch when --steps < 14); `frac_kernel_only` = SURVEY 8(d)'s force kernel alone on the same thermalised state, 20 launches
                      "frac_in_run": (achieved / HBM_PEAK_GBS) if achieved else None, "launches_timed_every": timed_every,
+                     "frac_source": "device-clock stamps inside every force launch of the timed region (%d launches)" % clk_n if k_ms_all else "event pairs on the sampled launches",
+                     "kernel_ms_all_launches": k_ms_all, "launches_all": clk_n,
+                     "kernel_ms_sampled": k_ms_sampled, "launches_sampled": tm["force_launches"],
+                     "frac_sampled": (achieved_sampled / HBM_PEAK_GBS) if achieved_sampled else None,
                      "kernel_only_ms": k_only_ms,
                      "frac_kernel_only": (bpa * nlocal / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_only_ms else None,
                      "measured_copy_GBs": copy_gbs,
-                     "kernel_ms": k_ms, "launches": tm["force_launches"], "bytes_per_atom": bpa, "atoms_per_launch": nlocal,
+                     "kernel_ms": k_ms, "launches": clk_n if k_ms_all else tm["force_launches"], "bytes_per_atom": bpa, "atoms_per_launch": nlocal,
                      # informational: the same launches with the fused integrator's own compulsory bytes counted too
                      # (+ v read/write 48 B, + new x 32 B, - the f store it skips 24 B)
                      "achieved_incl_fused_integrator": ((bpa + 56.0) * nlocal / (k_ms * 1e-3) / 1e9) if k_ms > 0 else None,

@@ -92,7 +92,7 @@ extern "C" int mmd_destroy(mmd_handle* h)
   if(h->h_flags) (void)hipHostFree(h->h_flags);
   if(h->h_flags_big) (void)hipHostFree(h->h_flags_big);
   if(h->dh.h_counts) (void)hipHostFree(h->dh.h_counts);
-  h->dh.idx.release(); h->dh.counts.release(); h->dh.scratch.release(); h->dh.gmap.release();
+  h->dh.idx.release(); h->dh.counts.release(); h->dh.scratch.release(); h->dh.gmap.release(); h->fclk.release();
   if(h->d_flags) (void)hipFree(h->d_flags);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   if(h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
@@ -142,6 +142,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "spec")) h->opt_spec = value;
   else if(!strcmp(name, "fold_pencil")) h->opt_fold_pencil = value;
   else if(!strcmp(name, "direct_halo")) h->dh.opt = value;
+  else if(!strcmp(name, "force_clock")) h->opt_force_clock = value;
   else if(!strcmp(name, "direct_borders")) h->dh.opt_borders = value;
   else if(!strcmp(name, "halo_recv")) h->dh.opt_recv = value;
   else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
@@ -304,6 +305,11 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   h->force_ms = 0; h->comm_ms = 0; h->force_launches = 0; h->force_calls = 0; h->ev_used = 0;
   h->force_ms_all = 0; h->force_launches_all = 0; h->halo_ms = 0;
   h->run_ntimes = ntimes;
+  h->fclk_n = 0; h->fclk_ms = 0; h->fclk_launches = 0; h->fclk_harvested = true;
+  if(h->opt_force_clock && h->clk_rate_hz > 0 && h->style == 0 && !h->halfneigh) {
+    MMD_TRY(h->fclk.ensure((size_t)FCLK_STRIDE * FCLK_SLOTS, false, h->stream));
+    HIP_TRY(hipMemsetAsync(h->fclk.p, 0, (size_t)FCLK_STRIDE * std::min(FCLK_SLOTS, ntimes + 2) * sizeof(unsigned long long), h->stream));
+  }
   long long halo_calls = 0, halo_timed = 0, ovf_calls = 0;
   h->host_syncs = 0; h->halo_bytes = 0; h->transport_syncs = 0;
   // the step loop steers the kernels through transient flags of the handle; whatever way this function is left (an overflowing
@@ -314,7 +320,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       h->fuse_now = 0; h->resolve_now = false; h->fold_reverse_now = false; h->core.mode_now = 0; h->zero_f_in_integrate = false;
       h->halo_pending = false; h->in_reneighbor = false; h->pbc_defer = false; h->launch_ev_a = h->launch_ev_b = nullptr; h->halo_in_x_allow = false;
       h->in_run = false; h->bin_owned_valid = false;
-      h->spec_fn = nullptr; h->spec = SpecLaunch{nullptr, nullptr, nullptr}; h->spec_done = false;
+      h->spec_fn = nullptr; h->spec = SpecLaunch{nullptr, nullptr, nullptr, nullptr}; h->spec_done = false;
       h->ovf_open = false;
     }
   } transient_guard{h};
@@ -598,6 +604,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   MMD_TRY(ev_collect(h));
   MMD_TRY(ovf_harvest(h));
   h->timer[0] = mmd_wall() - t_start;
+  h->fclk_harvested = false;            // (the stamps stay on the device until somebody asks: mmd_get_counter)
   // TIME_FORCE: GPU time between the events around Force::compute (scaled from the sampled calls to all of them)
   // force_calls / force_launches count the SAMPLED path only (force_compute_async); calls that are bracketed every time add their time as it is
   h->timer[2] = h->force_ms * 1e-3 * (h->force_launches > 0 && h->force_calls > h->force_launches ? (double)h->force_calls / h->force_launches : 1.0) +
@@ -625,6 +632,28 @@ extern "C" int mmd_run_stats(mmd_handle* h, long long* host_syncs, long long* by
   return 0;
 }
 
+// device-clock stamps of the last run's LJ full-list tile launches -> fclk_ms / fclk_launches (on demand: not inside anybody's timed region)
+static int fclk_harvest(mmd_handle* h)
+{
+  if(h->fclk_harvested) return 0;
+  h->fclk_harvested = true;
+  h->fclk_ms = 0; h->fclk_launches = 0;
+  if(h->fclk_n > 0 && h->fclk.p) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    static thread_local std::vector<unsigned long long> hc;
+    const int nl = std::min(h->fclk_n, FCLK_SLOTS);
+    hc.resize((size_t)FCLK_STRIDE * nl);
+    HIP_TRY(hipMemcpy(hc.data(), h->fclk.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for(int k = 0; k < nl; k++) {
+      const unsigned long long* c = hc.data() + (size_t)FCLK_STRIDE * k;
+      unsigned long long e = 0;
+      for(int q = 0; q < FCLK_TAIL; q++) e = std::max(e, c[8 + q]);
+      if(c[0] != 0 && e > c[0]) { h->fclk_ms += (double)(e - c[0]) / h->clk_rate_hz * 1e3; h->fclk_launches++; }
+    }
+  }
+  return 0;
+}
+
 extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value)
 {
   if(!h || !name || !value) { mmd_set_error("mmd_get_counter: bad arguments"); return -1; }
@@ -633,6 +662,8 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "borders_fast")) *value = h->borders_fast_runs;
   else if(!strcmp(name, "borders_general")) *value = h->borders_general_runs;
   else if(!strcmp(name, "borders_direct")) *value = h->borders_direct_runs;
+  else if(!strcmp(name, "force_clock_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_ms * 1e6); }       // last run: device-clock time of ALL its LJ full-list tile launches ...
+  else if(!strcmp(name, "force_clock_launches")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_launches; }            // ... and how many there were
   else if(!strcmp(name, "overlap_choice")) *value = h->overlap_choice;        // halo overlap chosen by measurement: -1 undecided, 0 without, 1 with (option overlap = -1)
   else if(!strcmp(name, "overlap_trial_off_ns")) *value = (long long)(h->overlap_trial_s[0] * 1e9);      // per step, summed over the ranks
   else if(!strcmp(name, "overlap_trial_on_ns")) *value = (long long)(h->overlap_trial_s[1] * 1e9);

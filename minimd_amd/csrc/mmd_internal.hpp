@@ -36,6 +36,9 @@ typedef double4 real4;
 #define MMD_WAVE 64
 #define MMD_UNROLL 8            // neighbor rows are padded to a multiple of this (>= every kernel's unroll factor)
 #define MMD_BLOCK 256
+#define FCLK_SLOTS 256            // launches of a run whose device-clock stamps are kept (the rest of a longer run is not stamped)
+#define FCLK_TAIL 2048            // last-dispatched workgroups of a launch that store their end time (a slot of its own each: no same-address atomics)
+#define FCLK_STRIDE (FCLK_TAIL + 8)
 
 // profiling-only phase switches of the tile kernels / the tile build ("ablate": results invalid). The shipped library is built
 // WITHOUT -DMMD_PROFILE: every switch folds to 0 at compile time and mmd_set_option("ablate") is refused; tools/build_variant.sh
@@ -123,7 +126,9 @@ struct EventPair { hipEvent_t a, b; int kind = 0; };
 // A force launch enqueued behind a neighbor build whose result words the host has not read yet (Integrate::run, one rank): the kernel
 // takes the build's verdict (`gate`, written by k_publish_flags: 1 = every list fits what this launch was sized for), the tile count and
 // the ghost count from device memory. gate == nullptr: an ordinary launch.
-struct SpecLaunch { const int* gate; const int* ntiles_dev; const int* nghost_dev; };
+// clk != nullptr: the launch stamps the device's wall clock — clk[0] the start of its first workgroup, clk[8 + q] the end of its q-th last
+// workgroup (q < FCLK_TAIL; the host takes the latest) (force-kernel time of EVERY launch of a run, without an event packet on the stream: mmd_get_counter "force_clock_ns")
+struct SpecLaunch { const int* gate; const int* ntiles_dev; const int* nghost_dev; unsigned long long* clk; };
 
 // Direct halo (several ranks, need = 1 in every dimension): the forward communication of a step as ONE exchange with the up to 26 neighbours instead
 // of three dependent rounds (one per dimension, the later ones forwarding what the earlier ones received). The ghosts of a rank are 26 lists — one
@@ -335,6 +340,14 @@ struct mmd_handle {
   int opt_time_sample = 0;             // force-kernel clock on every n-th Force::compute of a run (0: every 7th)
   int force_calls = 0;                 // Force::compute calls of the current run that went through the sampled clock
   int run_ntimes = 0;                  // length of the current mmd_integrate_run
+  // device-clock stamps of the LJ full-list tile launches of the current run (FCLK_SLOTS records of FCLK_STRIDE words, harvested when the run ends)
+  DevArr<unsigned long long> fclk;
+  int fclk_n = 0;                      // launches stamped in this run
+  double fclk_ms = 0;                  // sum of their durations (harvested)
+  int fclk_launches = 0;
+  bool fclk_harvested = true;
+  int opt_force_clock = 1;
+  bool spec_clk_redo = false;          // the launch behind the build was cancelled: the launch that replaces it takes its clock slot
   long long force_sample_ctr = 0;      // the same, never reset: call number modulo the sampling period decides which launches carry the clock
   bool resolve_now = false, ghosts_stale = false;
   hipEvent_t launch_ev_a = nullptr, launch_ev_b = nullptr;     // event pair the next tile-kernel launch attaches to its dispatch
@@ -361,7 +374,7 @@ struct mmd_handle {
   // the words and polling for them; the kernel does nothing unless the build's verdict on the device says the lists fit (SpecLaunch)
   int opt_spec = 16;                   // 0: off; > 0: on, the launch provides LDS for the previous build's largest candidate union + this many atoms
   std::function<int()> spec_fn;        // transient: how to launch this step's Force::compute
-  SpecLaunch spec = {nullptr, nullptr, nullptr};   // transient: set around spec_fn
+  SpecLaunch spec = {nullptr, nullptr, nullptr, nullptr};   // transient: set around spec_fn
   bool spec_fused = false;             // the gated launch carried the integrator (it wrote the second position buffer's dummy atom itself)
   bool spec_done = false;              // the build launched this step's force kernel and its verdict was "go"
   int spec_cmax = 0;                   // largest candidate union the speculative launch provides LDS for

@@ -1868,12 +1868,12 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
         if(reduce_in_publish) R = TileReduceArgs{1, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles, nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr};
         MMD_TRY(flags_publish(h, 62, V, R));
         if(spec) {
-          h->spec = SpecLaunch{h->d_flags + NB_GATE_WORD, nt_dev, h->nghost_dev};
+          h->spec = SpecLaunch{h->d_flags + NB_GATE_WORD, nt_dev, h->nghost_dev, nullptr};
           h->spec_fused = false;
           const long long before = h->spec_launches;
           spec_calls_before = h->force_calls; spec_ctr_before = h->force_sample_ctr; spec_ev_before = h->ev_used;
           const int rc = fn();
-          h->spec = SpecLaunch{nullptr, nullptr, nullptr};
+          h->spec = SpecLaunch{nullptr, nullptr, nullptr, nullptr};
           h->tile_cmax = save_cmax; h->tiles_ready = false; h->neigh_nlocal = 0;
           if(rc < 0) return rc;
           if(h->spec_launches != before + 1) { mmd_set_error("neighbor build: the force launch behind the build did not take the gated tile path"); return -1; }
@@ -1886,7 +1886,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
           verdict = h->h_flags[NB_GATE_WORD];
           // a "no": the gated launch did nothing and the step loop launches this step's Force::compute again — the call counter of the kernel clock and
           // the event pair the no-op may have carried (a 0 ms sample) go back to where they were
-          if(!verdict) { h->spec_fails++; h->force_calls = spec_calls_before; h->force_sample_ctr = spec_ctr_before; h->ev_used = spec_ev_before; }
+          if(!verdict) { h->spec_fails++; h->spec_clk_redo = h->fclk_n > 0; h->force_calls = spec_calls_before; h->force_sample_ctr = spec_ctr_before; h->ev_used = spec_ev_before; }
         }
       } else {
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, (h->nghost_dev ? 56 : 16) * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -1555,7 +1555,7 @@ def test_first_exchange_of_a_run_at_s80_on_two_ranks_does_not_overflow(port, tmp
         for k in (1, 2, 3):
             assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (a, b)
     for st in res["stats"]:
-        assert st["exchange_overflows"] == 0 and st["exchange_fast"] == 1 and st["borders_fast"] >= 1, res["stats"]
+        assert st["exchange_overflows"] == 0 and st["exchange_fast"] == 1 and st["borders_fast"] + st["borders_direct"] >= 1, res["stats"]
 
 
 @pytest.mark.gpu
