@@ -637,7 +637,7 @@ static int fclk_harvest(mmd_handle* h)
 {
   if(h->fclk_harvested) return 0;
   h->fclk_harvested = true;
-  h->fclk_ms = 0; h->fclk_launches = 0;
+  h->fclk_ms = 0; h->fclk_launches = 0; h->fclk_ms_sampled = 0; h->fclk_launches_sampled = 0;
   if(h->fclk_n > 0 && h->fclk.p) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     static thread_local std::vector<unsigned long long> hc;
@@ -648,7 +648,11 @@ static int fclk_harvest(mmd_handle* h)
       const unsigned long long* c = hc.data() + (size_t)FCLK_STRIDE * k;
       unsigned long long e = 0;
       for(int q = 0; q < FCLK_TAIL; q++) e = std::max(e, c[8 + q]);
-      if(c[0] != 0 && e > c[0]) { h->fclk_ms += (double)(e - c[0]) / h->clk_rate_hz * 1e3; h->fclk_launches++; }
+      if(c[0] != 0 && e > c[0]) {
+        const double ms = (double)(e - c[0]) / h->clk_rate_hz * 1e3;
+        h->fclk_ms += ms; h->fclk_launches++;
+        if(h->fclk_sampled[k]) { h->fclk_ms_sampled += ms; h->fclk_launches_sampled++; }
+      }
     }
   }
   return 0;
@@ -663,6 +667,8 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "borders_general")) *value = h->borders_general_runs;
   else if(!strcmp(name, "borders_direct")) *value = h->borders_direct_runs;
   else if(!strcmp(name, "force_clock_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_ms * 1e6); }       // last run: device-clock time of ALL its LJ full-list tile launches ...
+  else if(!strcmp(name, "force_clock_sampled_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_ms_sampled * 1e6); }       // ... the same over the launches that also carried an event pair
+  else if(!strcmp(name, "force_clock_sampled_launches")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_launches_sampled; }
   else if(!strcmp(name, "force_clock_launches")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_launches; }            // ... and how many there were
   else if(!strcmp(name, "overlap_choice")) *value = h->overlap_choice;        // halo overlap chosen by measurement: -1 undecided, 0 without, 1 with (option overlap = -1)
   else if(!strcmp(name, "overlap_trial_off_ns")) *value = (long long)(h->overlap_trial_s[0] * 1e9);      // per step, summed over the ranks

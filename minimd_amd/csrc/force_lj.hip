@@ -786,6 +786,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   if(list == nullptr && h->in_run && h->opt_force_clock && h->fclk.p != nullptr && (h->fclk_n < FCLK_SLOTS || h->spec_clk_redo)) {
     if(h->spec_clk_redo) { h->fclk_n--; h->spec_clk_redo = false; HIP_TRY(hipMemsetAsync(h->fclk.p + (size_t)FCLK_STRIDE * h->fclk_n, 0, FCLK_STRIDE * sizeof(unsigned long long), h->stream)); }
     SP.clk = h->fclk.p + (size_t)FCLK_STRIDE * h->fclk_n;
+    h->fclk_sampled[h->fclk_n] = kev_a != nullptr;          // (this launch also carries the event pair of the sampled clock)
     h->fclk_n++;
   }
   if(SP.gate != nullptr) { h->spec_launches++; h->spec_fused = fz == 1; }

@@ -346,6 +346,8 @@ struct mmd_handle {
   double fclk_ms = 0;                  // sum of their durations (harvested)
   int fclk_launches = 0;
   bool fclk_harvested = true;
+  bool fclk_sampled[FCLK_SLOTS] = {false};   // which of the stamped launches also carried an event pair
+  double fclk_ms_sampled = 0; int fclk_launches_sampled = 0;
   int opt_force_clock = 1;
   bool spec_clk_redo = false;          // the launch behind the build was cancelled: the launch that replaces it takes its clock slot
   long long force_sample_ctr = 0;      // the same, never reset: call number modulo the sampling period decides which launches carry the clock

@@ -8,7 +8,7 @@ python - $O/bench_driver.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
 print("value", d["value"], d["value_windows"], "ms/step", d["ms_per_step"])
-print({k: r.get(k) for k in ("frac", "frac_sampled", "kernel_ms_all_launches", "launches_all", "kernel_ms_sampled", "launches_sampled", "frac_kernel_only", "kernel_only_ms")})
+print({k: r.get(k) for k in ("frac", "frac_sampled", "kernel_ms", "kernel_span_ms_all_launches", "dispatch_and_completion_overhead_ms", "frac_span_only", "launches_all", "kernel_ms_sampled", "launches_sampled", "frac_kernel_only", "kernel_only_ms")})
 print("loopback", d.get("rank_path_loopback"))
 print("cold", (d.get("perf_summary_cold") or {}).get("value"), "cpu", (d.get("cpu_baseline") or {}).get("value"), d["phases_s"], d["force_launched_behind_build"])
 PY
