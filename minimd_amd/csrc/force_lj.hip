@@ -348,13 +348,16 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     fx *= c_out; fy *= c_out; fz *= c_out;
     // (a fused step consumes the force here; f[] is next read after the unfused thermo / last step, which stores it)
     // (FUSE = 2, the LAST step of a run: finalIntegrate only — the state the caller gets back is that of a whole step, forces included)
-    if(FUSE != 1) { f[3 * (size_t)i + 0] = fx; f[3 * (size_t)i + 1] = fy; f[3 * (size_t)i + 2] = fz; }
+    if(FUSE != 1) { out_store(f + 3 * (size_t)i + 0, fx); out_store(f + 3 * (size_t)i + 1, fy); out_store(f + 3 * (size_t)i + 2, fz); }
     if(FUSE) {
       real vx = vx0, vy = vy0, vz = vz0;
       vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz);
       if(FUSE == 1) { vx = mul_add_unfused(dtforce, fx, vx); vy = mul_add_unfused(dtforce, fy, vy); vz = mul_add_unfused(dtforce, fz, vz); }
-      v[3 * (size_t)i + 0] = vx; v[3 * (size_t)i + 1] = vy; v[3 * (size_t)i + 2] = vz;
-      if(FUSE == 1) xnew[i] = real4{mul_add_unfused(dt, vx, xi.x), mul_add_unfused(dt, vy, xi.y), mul_add_unfused(dt, vz, xi.z), xi.w};
+      out_store(v + 3 * (size_t)i + 0, vx); out_store(v + 3 * (size_t)i + 1, vy); out_store(v + 3 * (size_t)i + 2, vz);
+      if(FUSE == 1) {
+        real* xo = (real*)(xnew + i);
+        out_store(xo + 0, mul_add_unfused(dt, vx, xi.x)); out_store(xo + 1, mul_add_unfused(dt, vy, xi.y)); out_store(xo + 2, mul_add_unfused(dt, vz, xi.z)); out_store(xo + 3, xi.w);
+      }
     }
   }
   if(EV) {

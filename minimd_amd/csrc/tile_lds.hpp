@@ -53,6 +53,21 @@ template <typename T> __device__ __forceinline__ T stream_load(const T* p) { ret
 template <typename T> __device__ __forceinline__ T stream_load(const T* p) { return *p; }
 #endif
 
+// A store of data the NEXT launch reads (the fused integrator's v and new positions, the forces): every XCD writes its dirty L2 lines back when the kernel
+// ends (the XCDs' L2s are not coherent with each other), and that write-back is serial time between two launches — ~10 us behind a launch that leaves
+// 100+ MB of output. -DMMD_NT_OUT=1 marks these stores non-temporal (streamed towards memory while the kernel still runs).
+#ifndef MMD_NT_OUT
+#define MMD_NT_OUT 0
+#endif
+template <typename T> __device__ __forceinline__ void out_store(T* p, T v)
+{
+#if MMD_NT_OUT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // One-rank runs: every ghost is a periodic image of an owned atom (Comm::borders recorded its root and image vector), so a tile
 // kernel can stage a ghost candidate straight from the owner's CURRENT position plus the box shift — the per-step
 // Comm::communicate (k_ghost_update, ref/comm.cpp:276-317 with self swaps) and its launch gap disappear from the step.

@@ -10,7 +10,7 @@ out=../../variants/$name
 mkdir -p $out
 P=${PREC:-dp}; PN=2; [ $P = sp ] && PN=1
 make -j8 $P > /dev/null
-units="util atom neighbor integrate comm api force_lj force_eam host sim"
+units="util atom neighbor integrate comm api force_lj force_eam host sim launch"
 objs=""
 for u in $units; do
   if [ $u = $unit ] || [ $unit = all ]; then
