@@ -372,17 +372,20 @@ def main():
     k_ms_sampled = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
     clk_n = sim.handle.counter("force_clock_launches")
     k_ms_all = sim.handle.counter("force_clock_ns") * 1e-6 / clk_n if clk_n > 0 else None
-    # a launch's device-clock span (first workgroup's start to last workgroup's end) is SHORTER than the duration rocprofv3 and an event pair report for it
-    # (dispatch to completion signal: + launch ramp and the end-of-kernel write-back, ~8-13 us on this kernel). The launches that carry both clocks give that
-    # difference; `frac` prices every launch of the timed region at (its device-clock span + that mean difference) — the all-launch figure in rocprofv3's terms
+    # a launch's device-clock span (first workgroup's start to last workgroup's end) is shorter than the duration rocprofv3 reports for it (dispatch to
+    # completion): by the completion of the launch + the dispatch of its successor, i.e. by the idle time between two launches that follow each other directly —
+    # which the same stamps give (mean over the back-to-back pairs of the timed region). `frac` prices every launch at span + that gap: the all-launch figure in
+    # the profiler's terms (cross-checked against a trace of the same process: profiles/r05_frac_crosscheck.txt). The event pairs of the sampled clock add
+    # ~9 us of marker packets to the launches that carry them: `frac_sampled` is the lower bound they give.
     clk_ns_s, clk_n_s = sim.handle.counter("force_clock_sampled_ns"), sim.handle.counter("force_clock_sampled_launches")
     k_ms_span_sampled = clk_ns_s * 1e-6 / clk_n_s if clk_n_s > 0 else None
-    overhead_ms = (k_ms_sampled - k_ms_span_sampled) if (k_ms_span_sampled and tm["force_launches"] == clk_n_s) else None
-    k_ms = (k_ms_all + overhead_ms) if (k_ms_all and overhead_ms is not None) else k_ms_sampled
+    gaps = sim.handle.counter("force_clock_gaps")
+    overhead_ms = sim.handle.counter("force_clock_gap_ns") * 1e-6 / gaps if gaps > 0 else None
+    k_ms = (k_ms_all + overhead_ms) if (k_ms_all and overhead_ms is not None) else (k_ms_all or k_ms_sampled)
     achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
     achieved_sampled = bpa * nlocal / (k_ms_sampled * 1e-3) / 1e9 if k_ms_sampled > 0 else None
     traffic, traffic_source = None, None
-    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if world == 1 and args.size == 80 and os.path.exists(tpath):
             # HBM bytes per launch of the same kernel on the same workload from the committed rocprofv3 --pmc passes
@@ -432,10 +435,10 @@ def main():
                      # `frac` is the in-run figure over ALL launches of the timed region (these launches also carry the integrator); `frac_sampled` the event-pair figure of
                      # every 7th launch (every launch when --steps < 14); `frac_kernel_only` = SURVEY 8(d)'s force kernel alone on the same thermalised state, 20 launches
                      "frac_in_run": (achieved / HBM_PEAK_GBS) if achieved else None, "launches_timed_every": timed_every,
-                     "frac_source": ("every force launch of the timed region (%d): device-clock span of the launch + the mean (event pair - span) difference of the %d launches that carry both" % (clk_n, clk_n_s))
+                     "frac_source": ("every force launch of the timed region (%d): device-clock span of the launch + the mean idle time between launches that follow each other directly (%d pairs)" % (clk_n, gaps))
                      if (k_ms_all and overhead_ms is not None) else "event pairs on the sampled launches",
                      "kernel_span_ms_all_launches": k_ms_all, "launches_all": clk_n, "kernel_span_ms_sampled_launches": k_ms_span_sampled,
-                     "dispatch_and_completion_overhead_ms": overhead_ms,
+                     "dispatch_and_completion_overhead_ms": overhead_ms, "event_pair_minus_span_ms": (k_ms_sampled - k_ms_span_sampled) if k_ms_span_sampled else None,
                      "frac_span_only": (bpa * nlocal / (k_ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms_all else None,
                      "kernel_ms_sampled": k_ms_sampled, "launches_sampled": tm["force_launches"],
                      "frac_sampled": (achieved_sampled / HBM_PEAK_GBS) if achieved_sampled else None,

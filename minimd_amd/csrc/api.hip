@@ -401,7 +401,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     if(overlap_auto && h->overlap_choice < 0) {
       if(trial_phase == 0 && trial_armed) {
         trial_armed = false;
-        bool ok = trial_B >= 2 && n + 2 * trial_B <= ntimes && (h->style == 0 ? (mmd_lj_tiles_available(h) || mmd_lj_half_tiles_available(h)) : mmd_eam_can_fuse_integrate(h));
+        // (nothing rank-local may enter this condition: the trial ends in a collective, every rank has to run it on the same steps — a rank whose lists are
+        //  not in tile form simply does not overlap during its trial steps)
+        bool ok = trial_B >= 2 && n + 2 * trial_B <= ntimes;
         for(int k = 0; k < 2 * trial_B && ok; k++) {
           const int sk = first_step + n + 1 + k;
           if(sk % h->neigh_every == 0 || (thermo_nstat > 0 && sk % thermo_nstat == 0)) ok = false;
@@ -637,17 +639,22 @@ static int fclk_harvest(mmd_handle* h)
 {
   if(h->fclk_harvested) return 0;
   h->fclk_harvested = true;
-  h->fclk_ms = 0; h->fclk_launches = 0; h->fclk_ms_sampled = 0; h->fclk_launches_sampled = 0;
+  h->fclk_ms = 0; h->fclk_launches = 0; h->fclk_ms_sampled = 0; h->fclk_launches_sampled = 0; h->fclk_gap_ms = 0; h->fclk_gaps = 0;
   if(h->fclk_n > 0 && h->fclk.p) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     static thread_local std::vector<unsigned long long> hc;
     const int nl = std::min(h->fclk_n, FCLK_SLOTS);
     hc.resize((size_t)FCLK_STRIDE * nl);
     HIP_TRY(hipMemcpy(hc.data(), h->fclk.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long prev_end = 0;
     for(int k = 0; k < nl; k++) {
       const unsigned long long* c = hc.data() + (size_t)FCLK_STRIDE * k;
       unsigned long long e = 0;
       for(int q = 0; q < FCLK_TAIL; q++) e = std::max(e, c[8 + q]);
+      // two launches that follow each other directly (plain steps on one rank): the time between the last workgroup of one and the first of the next is
+      // the completion of the first + the dispatch of the second — what a profiler's per-kernel duration contains beyond the span
+      if(prev_end != 0 && c[0] > prev_end && (double)(c[0] - prev_end) / h->clk_rate_hz < 30.0e-6) { h->fclk_gap_ms += (double)(c[0] - prev_end) / h->clk_rate_hz * 1e3; h->fclk_gaps++; }
+      prev_end = e;
       if(c[0] != 0 && e > c[0]) {
         const double ms = (double)(e - c[0]) / h->clk_rate_hz * 1e3;
         h->fclk_ms += ms; h->fclk_launches++;
@@ -667,6 +674,8 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "borders_general")) *value = h->borders_general_runs;
   else if(!strcmp(name, "borders_direct")) *value = h->borders_direct_runs;
   else if(!strcmp(name, "force_clock_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_ms * 1e6); }       // last run: device-clock time of ALL its LJ full-list tile launches ...
+  else if(!strcmp(name, "force_clock_gap_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_gap_ms * 1e6); }       // ... idle time between launches that follow each other directly
+  else if(!strcmp(name, "force_clock_gaps")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_gaps; }
   else if(!strcmp(name, "force_clock_sampled_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_ms_sampled * 1e6); }       // ... the same over the launches that also carried an event pair
   else if(!strcmp(name, "force_clock_sampled_launches")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_launches_sampled; }
   else if(!strcmp(name, "force_clock_launches")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_launches; }            // ... and how many there were

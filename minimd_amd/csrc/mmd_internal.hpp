@@ -348,6 +348,7 @@ struct mmd_handle {
   bool fclk_harvested = true;
   bool fclk_sampled[FCLK_SLOTS] = {false};   // which of the stamped launches also carried an event pair
   double fclk_ms_sampled = 0; int fclk_launches_sampled = 0;
+  double fclk_gap_ms = 0; int fclk_gaps = 0;     // idle time between stamped launches that follow each other directly
   int opt_force_clock = 1;
   bool spec_clk_redo = false;          // the launch behind the build was cancelled: the launch that replaces it takes its clock slot
   long long force_sample_ctr = 0;      // the same, never reset: call number modulo the sampling period decides which launches carry the clock

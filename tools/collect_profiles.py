@@ -10,7 +10,7 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 dst = os.path.join(REPO, "profiles")
 names = {"bench_n1.json": "bench_n1.json", "configs.txt": "configs.txt", "kernel_stats_bench.md": "kernel_stats_bench_s80_full_dp.md",
@@ -19,7 +19,7 @@ names = {"bench_n1.json": "bench_n1.json", "configs.txt": "configs.txt", "kernel
          "kernel_stats_E.md": "kernel_stats_E_s160_half_sp.md", "pmc_lj_full.txt": "pmc_k_lj_full_tile.txt", "pmc_lj_half.txt": "pmc_k_lj_half_tile.txt",
          "pmc_eam.txt": "pmc_k_eam_tile.txt", "pmc_build.txt": "pmc_k_build_rows.txt",
          "timeline_reneighboring_s80.txt": "timeline_reneighboring_s80.txt", "timeline_reneighboring_s32.txt": "timeline_reneighboring_s32.txt",
-         "timeline_rank_path_loopback_s80.txt": "timeline_rank_path_loopback_s80.txt", "rank_path_loopback.txt": "rank_path_loopback.txt",
+         "timeline_rank_path_loopback_s80.txt": "timeline_rank_path_loopback_s80.txt", "rank_path_loopback.txt": "rank_path_loopback.txt", "window_probe.txt": "window_probe.txt", "kernel_stats_bench_driver_shape.md": "kernel_stats_bench_driver_shape.md", "bench_driver_shape_profiled.json": "bench_driver_shape_profiled.json", "sorted_rows_probe.txt": "sorted_rows_probe.txt",
          # what the driver runs (bench.py --gpus 1 --steps 20 --warmup 5), three times, and one such slice under the profiler
          "bench_driver_shape_1.json": "bench_driver_shape_1.json", "bench_driver_shape_2.json": "bench_driver_shape_2.json",
          "bench_driver_shape_3.json": "bench_driver_shape_3.json", "slice_driver_shape.txt": "slice_driver_shape.txt"}

@@ -3,7 +3,7 @@
 #   bench line, kernel statistics of every BASELINE configuration, PMC passes of the hot kernels, configuration runs.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r05}
 O=gpurun_out/prof_$R
 mkdir -p $O
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
@@ -28,14 +28,20 @@ tail -30 $O/pmc_lj_full.txt
 bash tools/gpu_timeline.sh 80 > $O/timeline_reneighboring_s80.txt 2>&1
 bash tools/gpu_timeline.sh 32 > $O/timeline_reneighboring_s32.txt 2>&1
 rm -rf gpurun_out/tl80 gpurun_out/tl32
-# the multi-rank code path on this one GPU (periodic self swaps through RCCL loop-back): kernels of two plain steps and of one re-neighboring
-(cd /tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/tllb -o t -- python $GRAFT_REPO_ROOT/tools/loopback_trace.py 80 1 > /dev/null 2>&1)
-{ echo "# tools/loopback_trace.py 80 1 under rocprofv3 --kernel-trace: one rank of in.lj.miniMD -s 80 whose self swaps go through RCCL (force_transport), overlap on"; echo "## two plain steps"; python tools/rocpd_steps.py $(find gpurun_out/tllb -name "*.db" | head -1) 1 | head -12; echo "## one re-neighboring"; python tools/rocpd_timeline.py $(find gpurun_out/tllb -name "*.db" | head -1); } > $O/timeline_rank_path_loopback_s80.txt 2>&1
+# the multi-rank code path on this one GPU (periodic self swaps through RCCL loop-back): kernels of plain steps and of one re-neighboring, halo form chosen by the library (overlap -1)
+bash tools/gpu_loopback_timeline.sh 80 -1 tllb > /dev/null 2>&1
+cp gpurun_out/tllb/timeline.txt $O/timeline_rank_path_loopback_s80.txt
 rm -rf gpurun_out/tllb
-timeout 300 python tools/loopback_probe.py 80 2>&1 | grep "^-s" > $O/rank_path_loopback.txt
+timeout 400 python tools/loopback_probe.py 80 "overlap=-1" "overlap=0" "overlap=1" "overlap=0,halo_recv=1" "overlap=0,halo_recv=2" "overlap=0,direct_borders=0,halo_recv=1" 2>&1 | grep "^-s" > $O/rank_path_loopback.txt
+# host-side pricing of two proposals on real tile lists; Force::compute on rows re-ordered by distance
+{ timeout 300 python tools/window_probe.py in.lj.miniMD 80 1; timeout 300 python tools/window_probe.py in.eam.miniMD 64 0; } 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostn\|^Libr" > $O/window_probe.txt
+{ timeout 300 python tools/sorted_rows_probe.py in.eam.miniMD 64; timeout 300 python tools/sorted_rows_probe.py in.lj.miniMD 80; } 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostn\|^Libr" > $O/sorted_rows_probe.txt
 # what the driver runs, three times, and one such slice under the profiler
 for r in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null > $O/bench_driver_shape_$r.json; done
 bash tools/gpu_slice.sh > $O/slice_driver_shape.txt 2>&1
+# the driver's command UNDER the profiler: its own line (roofline.frac) next to rocprofv3's kernel averages of the same process
+bash tools/gpu_stats_bench.sh prof_$R/stats_driver > $O/stats_driver.txt 2>&1
+cp $O/stats_driver/kernel_stats_bench.md $O/kernel_stats_bench_driver_shape.md; cp $O/stats_driver/bench.json $O/bench_driver_shape_profiled.json
 # keep the merge small: drop the raw rocprof trees, keep logs + summaries
 find $O -name "*.db" -delete; find $O -type d -name "kt_*" -exec rm -rf {} + 2>/dev/null; find $O -mindepth 1 -maxdepth 1 -type d -name "pmc_*" -exec rm -rf {} + 2>/dev/null
 ls -la $O

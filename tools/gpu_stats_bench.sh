@@ -12,4 +12,5 @@ import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
 print("value", d["value"], {k: r.get(k) for k in ("frac", "frac_sampled", "kernel_ms", "kernel_span_ms_all_launches", "dispatch_and_completion_overhead_ms", "frac_span_only", "launches_all", "kernel_ms_sampled", "launches_sampled")})
 PY
+python tools/rocpd_timed_region.py $(find $O/kt -name "*.db" | head -1) $O/bench.json | tee $O/frac_crosscheck.txt
 find $O -name "*.db" -delete
