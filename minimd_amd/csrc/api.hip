@@ -143,6 +143,7 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   else if(!strcmp(name, "fold_pencil")) h->opt_fold_pencil = value;
   else if(!strcmp(name, "direct_halo")) h->dh.opt = value;
   else if(!strcmp(name, "force_clock")) h->opt_force_clock = value;
+  else if(!strcmp(name, "overlap_join")) h->opt_overlap_join = value;
   else if(!strcmp(name, "direct_borders")) h->dh.opt_borders = value;
   else if(!strcmp(name, "halo_recv")) h->dh.opt_recv = value;
   else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
@@ -346,7 +347,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   int trial_phase = 0, trial_left = 0;
   bool trial_armed = false;
   const int trial_B = std::min(8, (h->neigh_every - 2) / 2);
-  bool halo_pending = false, collect_pending = false, ovf_timed_now = false;
+  bool halo_pending = false, collect_pending = false, ovf_timed_now = false, joined = false;
   int core_next = 0;                 // CoreRows: what the next force call may assume about the displacement since the build
   // the per-step halos are timed (into TIME_COMM) only where they are more than one tiny kernel: an event pair costs the stream
   // two markers, ~5 us per step that a -s 32 run would notice
@@ -447,8 +448,22 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         }
         std::swap(h->stream, h->comm_stream);
         int rc = timed_step ? ev_begin(h, 5) : 0;
+        // (round 5) the boundary tiles go onto the communication stream, right behind the transfer: they start the moment the ghosts are there, under the tail of the
+        // interior tiles, and read the received records where they landed (halo_recv 3: no unpack kernel either); the compute stream joins at the end of the step.
+        // A thermo step keeps the round-4 form (its energy sum needs both launches finished).
+        joined = lj_full && h->opt_overlap_join && !ev_now;
+        if(joined) h->halo_in_x_allow = h->opt_fuse && h->opt_ghost_resolve;
         if(rc >= 0) rc = mmd_comm_communicate(h);
+        h->halo_in_x_allow = false;
         if(rc >= 0 && timed_step) rc = ev_end(h);
+        if(rc >= 0 && joined) {
+          h->fuse_now = fused_force;
+          h->resolve_now = h->dh.x_unpack_pending;
+          rc = mmd_lj_compute_tiles_split(h, 0, 1);
+          h->fuse_now = 0; h->resolve_now = false;
+          if(h->dh.x_unpack_pending) h->ghosts_stale = true;
+          h->overlap_join_steps++;
+        }
         std::swap(h->stream, h->comm_stream);
         MMD_TRY(rc);
         HIP_TRY(hipEventRecord(h->ev_halo_done, h->comm_stream));
@@ -548,10 +563,13 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
     if(halo_pending) {
       // overlapped step: interior tiles ran under the halo; now wait for the ghosts and finish the boundary tiles
       HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
-      h->fuse_now = fused_force;
-      const int rc1 = mmd_lj_compute_tiles_split(h, evflag_pending, 1);
-      h->fuse_now = 0;
-      MMD_TRY(rc1);
+      if(!joined) {
+        h->fuse_now = fused_force;
+        const int rc1 = mmd_lj_compute_tiles_split(h, evflag_pending, 1);
+        h->fuse_now = 0;
+        MMD_TRY(rc1);
+      }
+      joined = false;
       if(ovf_timed_now) MMD_TRY(ovf_end(h));
       ovf_timed_now = false;
       halo_pending = false;
@@ -687,6 +705,7 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "dh_gmap_live")) *value = h->dh.gmap_live ? 1 : 0;
   else if(!strcmp(name, "dh_ready")) *value = h->dh.ready ? 1 : 0;
   else if(!strcmp(name, "cand_src_halo")) *value = (h->cand_src_ready ? 1 : 0) + (h->cand_src_halo ? 2 : 0);
+  else if(!strcmp(name, "overlap_join_steps")) *value = h->overlap_join_steps;      // overlapped steps whose boundary tiles ran on the communication stream behind the transfer
   else if(!strcmp(name, "halo_in_x_steps")) *value = h->halo_in_x_steps;      // steps whose position halo stayed behind the ghost slots (no k_dh_unpack)
   else if(!strcmp(name, "device_bins_coarser")) *value = h->neigh_ready && (h->bg.nbin[0] != h->bg_ref.nbin[0] || h->bg.nbin[1] != h->bg_ref.nbin[1] || h->bg.nbin[2] != h->bg_ref.nbin[2]) ? 1 : 0;
   else if(!strcmp(name, "tiles_ready")) *value = h->tiles_ready ? 1 : 0;

@@ -249,6 +249,10 @@ struct mmd_handle {
   // transfer can pay for it — in RCCL loop-back on one GPU it does not)
   int opt_overlap = -1;
   int overlap_choice = -1;           // -1 not decided yet, 0 / 1
+  // LJ full lists, overlapped step: 1 = the boundary tiles are launched on the COMMUNICATION stream right behind the transfer (they run under the tail of the
+  // interior tiles, the compute stream only joins at the end of the step); 0 = on the compute stream behind a wait for the halo (round 4)
+  int opt_overlap_join = 1;
+  long long overlap_join_steps = 0;
   double overlap_trial_s[2] = {0, 0}; // per step, summed over the ranks: [0] without, [1] with overlap
   hipEvent_t ev_trial[3] = {nullptr, nullptr, nullptr};
   int tile_cstride = 0, tile_cmax = 0;

@@ -220,3 +220,29 @@ def test_overlap_chosen_by_measurement_changes_nothing(deck, half):
         np.testing.assert_array_equal(a["x"], d["x"])
         np.testing.assert_array_equal(a["f"], d["f"])
     s.close()
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_boundary_tiles_on_the_communication_stream_change_nothing(prec):
+    """overlap 1 on several ranks, LJ over full lists (here: RCCL loop-back): the boundary tiles are launched on the communication stream right behind the transfer
+    (overlap_join 1, default: they run under the tail of the interior tiles and read the received records where they landed; the compute stream joins at the end of the
+    step) instead of on the compute stream behind a wait (overlap_join 0, round 4). Same bits as the run without overlap, thermo step included."""
+    args = ["-s", "14", "-n", "130", "--half_neigh", "0"]
+    res = {}
+    for name, opts in (("none", {"overlap": 0}), ("join", {"overlap": 1}), ("split", {"overlap": 1, "overlap_join": 0})):
+        s = mm().Sim(args, precision=prec)
+        h = s.handle
+        h.init_rccl(h.unique_id(), 0, 1)
+        h.set_option("force_transport", 1)
+        for k, v in opts.items():
+            h.set_option(k, v)
+        s.initial(); s.run()
+        d = h.download()
+        res[name] = (s.rows(), d["x"].copy(), d["v"].copy(), d["f"].copy(), h.counter("overlap_join_steps"), h.counter("halo_in_x_steps"))
+        s.close()
+    assert res["none"][4] == 0 and res["split"][4] == 0 and res["join"][4] > 100, [r[4:] for r in res.values()]
+    assert res["join"][5] > 80             # (from the second re-neighboring on the joined steps need no unpack kernel)
+    for other in ("join", "split"):
+        assert res["none"][0] == res[other][0]
+        for a_, b_ in zip(res["none"][1:4], res[other][1:4]):
+            np.testing.assert_array_equal(a_, b_)
