@@ -980,6 +980,48 @@ __device__ __forceinline__ float nb2_min3_abs(float acc, float a, float b)
   return acc;
 }
 
+// Round 5: the pre-test on the MATRIX cores (full lists). |a|^2 + |b|^2 - 2 a.b - cutneighsq of 32 candidates x 32 tile atoms is ONE
+// v_mfma_f32_32x32x16_f16: every fp32 quantity of the packed-VALU form travels as a pair of halves (hi = RN(v), lo = RN(v - hi): 22 bits; a product of
+// two halves is exact in the fp32 accumulator) and the 16 k-slots hold
+//   k 0..7  (lanes 0..31)  A = m_hi.x m_hi.y m_hi.z bb_hi m_lo.x m_lo.y m_lo.z bb_lo     B = a_hi.x a_hi.y a_hi.z 1 a_hi.x a_hi.y a_hi.z 1
+//   k 8..15 (lanes 32..63) A = m_hi.x m_hi.y m_hi.z 1     1      .      .      .         B = a_lo.x a_lo.y a_lo.z -thr_hi -thr_lo 0 0 0
+// (m = -2 b, bb = |b|^2 of the candidate, a / thr = cutneighsq - |a|^2 of the tile atom; a_lo . m_lo is dropped into the error bound). The candidate
+// buffer holds ONE 16-byte record {m_hi.xy | m_hi.z bb_hi | m_lo.xy | m_lo.z bb_lo} per candidate = the k 0..7 operand as it stands; the upper half of
+// the wavefront reads the same record and patches two halves to 1.0 (two v_bfi_b32). Two MFMAs (tile atoms 0..31, 32..63) test 32 candidates against
+// the whole tile; a lane finds in its 16 + 16 accumulators the values of atom (lane % 32) / (32 + lane % 32) for half of the candidates — candidate row
+// 8 (i / 4) + 4 (lane / 32) + i % 4 in register i (layout checked by tools/probes/mfma_f16_probe.hip) —, shifts their SIGNS into two 16-bit words
+// (v_alignbit_b32) and one v_permlane32_swap hands every lane the two words of ITS atom: bit 31 - i = the lower-half row of register i, bit 15 - i the
+// upper-half one (mf_bit). 1 LDS read + 2 MFMA + 54 VALU per group of 32 candidates instead of 32 LDS reads + 112 VALU.
+// Error band, per ATOM: the hardware's accumulation order is unknown — taken as 12 additions (13 non-zero terms) that each lose up to 2^-23 of the
+// sum of the |terms| (measured on gfx950: <= 5.3 x 2^-24 of it over 16 terms, f16 denormals honoured: mfma_f16_probe) = 24 units of 2^-24 — plus, per
+// quantity, the splits (4 units each for bb, thr, m, a), the dropped a_lo . m_lo (4), the fp32 |b|^2 chain (3), thr through float (1) and the float
+// rounding of the local coordinates (<= 4 B_i): <= 36 x 2^-24 x T_i, T_i = sum of the |terms| for a candidate within the cutoff (+ margin) of atom i:
+// B_i + |thr_i| + P_i, s_c = |a_c| + cut', B_i = sum s_c^2, P_i = 2 sum s_c |a_c|. E_i = 40 x 2^-24 x (T_i + cutneighsq). A pair whose exact d = rsq - cutneighsq exceeds the TILE-wide bound (the same with La, Lb) has the right sign whatever its magnitudes; one
+// below it lies within cut' of atom i, so E_i holds for it: the sign of an accumulator is trusted iff |value| >= E_i. A group in which some lane sees a
+// smaller |value| is decided again for ALL its pairs from the global positions, exactly (`rsq <= cutneighsq`, ref/neighbor.cpp:165,179) — 0.3 groups
+// per tile at LJ density. Tiles whose extent would take |b|^2 near the f16 range leave the build to the row kernel (flags[3]).
+#ifndef NB2_MFMA
+#define NB2_MFMA 1
+#endif
+#ifndef NB2_MF_PIPE
+#define NB2_MF_PIPE 0            // (issuing a group's MFMAs one group ahead of the reads of their accumulators: measured 1.5 % slower, 119 instead of 108 VGPRs)
+#endif
+typedef _Float16 nb2_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 nb2_h8 __attribute__((ext_vector_type(8)));
+typedef float nb2_f16v __attribute__((ext_vector_type(16)));
+// bit of the lane's hit word that candidate c (0..31) of a group lands in
+__device__ __forceinline__ int nb2_mf_bit(int c) { return ((c & 4) ? 15 : 31) - (((c >> 3) << 2) | (c & 3)); }
+__device__ __forceinline__ unsigned nb2_pack_h2(float lo, float hi)      // {RN f16(lo), RN f16(hi)}: one v_cvt_pk_f16_f32
+{
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(nb2_f2{lo, hi}, nb2_h2));
+}
+__device__ __forceinline__ nb2_f2 nb2_unpack_h2(unsigned v) { return __builtin_convertvector(__builtin_bit_cast(nb2_h2, v), nb2_f2); }
+__device__ __forceinline__ double nb2_readlane(double v, int l)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float nb2_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 template <int MODE, int CORE>
 __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, const int* __restrict__ binned,
                                                    const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
@@ -1001,6 +1043,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
   constexpr bool DOTK = NB2_DOTF(MODE);
+  constexpr bool MFK = NB2_MFMA && DOTK && MODE == 0 && CORE == 0;      // the pre-test on the matrix cores (see above)
   constexpr int NB2_NARR = DOTK ? 5 : 4;             // arrays of the candidate buffer: DOT -2x | -2y | -2z | |b|^2 | index, otherwise x | y | z | index
   constexpr int NB2_IDX = (NB2_NARR - 1) * NB2_BUF;  // the atom index (bit pattern) of a buffered candidate
   __shared__ __align__(16) float s_buf[NB2_NARR * NB2_BUF];
@@ -1108,6 +1151,39 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float thr_i = owned ? (float)((double)cutneighsq - aa_d) : -1.0e30f;              // d = (|b|^2 - 2 a.b) - thr_i = rsq - cutneighsq
   const float thrc_i = owned ? (float)((double)core_thr - aa_d) : -1.0e30f;               // CORE: the same against the core radius
   const float twofz = 2.0f * fzi;
+  // MFK: the atoms' operands of the two MFMAs, the per-atom error bounds that go with them, the masks that patch the upper half's candidate operand
+  nb2_h8 mfB1 = {}, mfB2 = {};
+  float mfEA = 0.0f, mfEB = 0.0f;
+  const unsigned mf_my = lane < 32 ? 0xffffffffu : 0x0000ffffu, mf_mz = lane < 32 ? 0xffffffffu : 0xffff0000u;
+  bool mf_range_bad = false;
+  if constexpr(MFK) {
+    mf_range_bad = 3.0f * Lb * Lb > 30000.0f;                   // |b|^2 must stay a finite half
+    const unsigned h0 = nb2_pack_h2(fxi, fyi), h1 = nb2_pack_h2(fzi, 1.0f);
+    const nb2_f2 b0 = nb2_unpack_h2(h0), b1 = nb2_unpack_h2(h1);
+    const float thf = owned ? (float)((double)cutneighsq - aa_d) : -60000.0f;
+    const float th = (float)(_Float16)thf;
+    const unsigned l0 = nb2_pack_h2(fxi - b0.x, fyi - b0.y), l1 = nb2_pack_h2(fzi - b1.x, -th), l2 = nb2_pack_h2(-(thf - th), 0.0f);
+    const unsigned hi4[4] = {h0, h1, h0, h1}, lo4[4] = {l0, l1, l2, 0u};
+    unsigned o1[4], o2[4];
+#pragma unroll
+    for(int j = 0; j < 4; j++) { const auto r = __builtin_amdgcn_permlane32_swap(hi4[j], lo4[j], false, false); o1[j] = r[0]; o2[j] = r[1]; }
+    mfB1 = __builtin_bit_cast(nb2_h8, uint4{o1[0], o1[1], o1[2], o1[3]});
+    mfB2 = __builtin_bit_cast(nb2_h8, uint4{o2[0], o2[1], o2[2], o2[3]});
+    const float cutp = 1.001f * (float)cutneigh + 0.01f;
+    const float sx = fabsf(fxi) + cutp, sy = fabsf(fyi) + cutp, sz = fabsf(fzi) + cutp;
+    const float Ti = sx * sx + sy * sy + sz * sz + fabsf(thf) + 2.0f * (sx * fabsf(fxi) + sy * fabsf(fyi) + sz * fabsf(fzi)) + (float)cutneighsq;
+#ifdef NB2_MF_NOWALK        // (timing probe only: no group is ever decided exactly)
+    const float Ei = 0.0f * Ti;
+#else
+    const float Ei = owned ? 40.0f * 5.96046448e-08f * Ti : 0.0f;
+#endif
+    const auto re = __builtin_amdgcn_permlane32_swap(__float_as_uint(Ei), __float_as_uint(Ei), false, false);
+    mfEA = __uint_as_float(re[0]); mfEB = __uint_as_float(re[1]);
+  }
+  if(MFK && mf_range_bad) {                // (a tile stretched over a near-empty pencil: the row kernel builds this list)
+    if(lane == 0) { tile_max[tile] = 0; tile_ncand[tile] = 0; tile_cand[cbase] = nall; if(cand_src != nullptr) cand_src[cbase] = nall; tile_ghost[tile] = 0; tile_rowmax[tile] = 0; tile_rowsum[tile] = 0; atomicMax(&flags[3], 1); }
+    return;
+  }
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
@@ -1125,8 +1201,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
 
   // ---- phase 2 + expansion over the buffered candidates
   auto flush = [&]() {
-    const int fill8 = (fill + 7) & ~7;
+    const int fill8 = MFK ? (fill + 31) & ~31 : (fill + 7) & ~7;      // (MFK: whole groups of 32)
     if(lane < fill8 - fill) {
+      if(MFK) {                       // m = 0, |b|^2 = 60000: d > 0 against every atom
+        ((uint4*)s_buf)[fill + lane] = uint4{0u, (unsigned)__builtin_bit_cast(unsigned short, (_Float16)60000.0f) << 16, 0u, 0u};
+      } else
       if(DOTK) {                      // -2 b and |b|^2 of a candidate at (1e15, 1e15, 1e15)
         s_buf[fill + lane] = -2.0e15f; s_buf[NB2_BUF + fill + lane] = -2.0e15f; s_buf[2 * NB2_BUF + fill + lane] = -2.0e15f;
         s_buf[3 * NB2_BUF + fill + lane] = 3.0e30f;
@@ -1136,9 +1215,59 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     }
     __syncthreads();
     const int selfpos = (MODE == 0 || DOTK) ? (int)s_selfpos[lane] : -1;
+    // MFK: the two MFMAs of a group are issued one group ahead of the instructions that read their accumulators (NB2_MF_PIPE)
+    nb2_f16v mf_n1 = {}, mf_n2 = {};
+    auto mf_issue = [&](int gq) {
+      const uint4 rec = ((const uint4*)s_buf)[gq + (lane & 31)];
+      uint4 av = rec;
+      av.y = (rec.y & mf_my) | (0x3c003c00u & ~mf_my);             // upper half: {m_hi.z, 1.0}
+      av.z = (rec.z & mf_mz) | (0x3c003c00u & ~mf_mz);             //             {1.0, .}
+      const nb2_h8 A = __builtin_bit_cast(nb2_h8, av);
+      const nb2_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      mf_n1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, mfB1, zero, 0, 0, 0);
+      mf_n2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, mfB2, zero, 0, 0, 0);
+    };
+    if(MFK && NB2_MF_PIPE && fill8 > 0 && !(ablate & 2)) mf_issue(0);
     for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0, bits_c = 0;
+      if constexpr(MFK) {
+        if(!NB2_MF_PIPE) mf_issue(gq);
+        const nb2_f16v d1 = mf_n1, d2 = mf_n2;
+        if(NB2_MF_PIPE && gq + 32 < fill8) mf_issue(gq + 32);
+        unsigned w1 = 0, w2 = 0;
+        float m1 = 3.0e38f, m2 = 3.0e38f;
+#pragma unroll
+        for(int i = 0; i < 16; i++) w1 = nb2_shift_sign(w1, d1[i]);
+#pragma unroll
+        for(int i = 0; i < 16; i += 2) m1 = __builtin_fminf(__builtin_fminf(m1, __builtin_fabsf(d1[i])), __builtin_fabsf(d1[i + 1]));      // (v_min3_f32 with |.| modifiers; NOT the inline-asm form: the compiler must see these reads of the MFMA's registers to keep the wait states in front of them)
+#pragma unroll
+        for(int i = 0; i < 16; i++) w2 = nb2_shift_sign(w2, d2[i]);
+#pragma unroll
+        for(int i = 0; i < 16; i += 2) m2 = __builtin_fminf(__builtin_fminf(m2, __builtin_fabsf(d2[i])), __builtin_fabsf(d2[i + 1]));
+        const bool amb = (int)(m1 < mfEA) | (int)(m2 < mfEB);
+        const auto rw = __builtin_amdgcn_permlane32_swap(w1, w2, false, false);       // -> the two words of MY atom
+        bits = (rw[0] << 16) | rw[1];
+        const unsigned long long ambm = __builtin_amdgcn_ballot_w64(amb);
+        if(ambm != 0ull) {
+          // some accumulator of the group is inside its atom's band: the pairs of that HALF of the group's candidates (the lower 32 lanes hold rows
+          // 0-3, 8-11, ... = the upper 16 bits of a word, the upper 32 lanes the rest) with all 64 atoms are decided exactly from the global positions
+          const int jq = __float_as_int(s_buf[NB2_IDX + gq + (lane & 31)]);           // (padding: negative)
+          const real4 pq = x[jq >= 0 ? jq : 0];
+          const bool walk0 = (unsigned)ambm != 0u, walk1 = (unsigned)(ambm >> 32) != 0u;
+          const unsigned wmask = (walk0 ? 0xffff0000u : 0u) | (walk1 ? 0x0000ffffu : 0u);
+          unsigned ex = 0;
+          for(int c = 0; c < 32; c++) {
+            if(!((c & 4) ? walk1 : walk0)) continue;
+            const real qx = nb2_readlane(pq.x, c), qy = nb2_readlane(pq.y, c), qz = nb2_readlane(pq.z, c);
+            const int sj = __builtin_amdgcn_readlane(jq, c);
+            const real dx = pme.x - qx, dy = pme.y - qy, dz = pme.z - qz;
+            const real rsq = dx * dx + dy * dy + dz * dz;
+            if(sj >= 0 && rsq <= cutneighsq) ex |= 1u << nb2_mf_bit(c);
+          }
+          bits = (bits & ~wmask) | (owned ? ex : 0u);
+        }
+      } else
       if constexpr(DOTK) {
         float acc = 3.0e38f;                         // smallest |d| of this lane in the group
         unsigned bits_zs = 0, bits_zp = 0;           // half lists: partner surely / possibly above me in z
@@ -1291,11 +1420,12 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       }
       }       // (difference form)
       // full lists: the atom itself (rsq = 0) is a hit of its own lane: dropped here
-      if(MODE == 0) { const unsigned sp = (unsigned)(selfpos - gq); if(sp < (unsigned)G) bits &= ~(1u << (G - 1 - sp)); }
+      if(MODE == 0) { const unsigned sp = (unsigned)(selfpos - gq); if(sp < (unsigned)G) bits &= ~(1u << (MFK ? nb2_mf_bit((int)sp) : G - 1 - (int)sp)); }
       // ---- the candidates some lane keeps form the tile's union: they get the next slots, in candidate order
       const unsigned used = wave_or_u(bits);
+      const int bq_mine = MFK ? nb2_mf_bit(lane & 31) : G - 1 - lane;      // the bit candidate `lane` of the group sits at
       if(lane < G) {
-        const int bq = G - 1 - lane;
+        const int bq = bq_mine;
         if((used >> bq) & 1u) {
           const int slot = S + __popc(used >> 1 >> bq);           // used candidates before mine
           if(slot < cstride - 1) {
@@ -1308,7 +1438,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           if(MODE != 0) { const unsigned own = s_own[gq + lane]; if(own != 0xffu) s_self[own] = (unsigned short)slot; }
         }
       }
-      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (G - 1 - lane)) & 1u) && __float_as_int(s_buf[NB2_IDX + gq + lane]) >= nlocal) != 0ull;
+      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (bq_mine & 31)) & 1u) && __float_as_int(s_buf[NB2_IDX + gq + lane]) >= nlocal) != 0ull;
       // ---- a lane's NON-EMPTY hit words wait, with their group numbers, in a scratch list (lane-interleaved, read back by
       // the same lane) for the lock-step expansion at the end of the tile
       if(gcount < NB2_NG) {
@@ -1373,6 +1503,12 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if(keep) {
           const float lx = (float)(pp[u].x - ox), ly = (float)(pp[u].y - oy), lz = (float)(pp[u].z - oz);
+          if(MFK) {
+            const float mx = -2.0f * lx, my = -2.0f * ly, mz = -2.0f * lz, bb = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+            const unsigned h0 = nb2_pack_h2(mx, my), h1 = nb2_pack_h2(mz, bb);
+            const nb2_f2 b0 = nb2_unpack_h2(h0), b1 = nb2_unpack_h2(h1);
+            ((uint4*)s_buf)[pos] = uint4{h0, h1, nb2_pack_h2(mx - b0.x, my - b0.y), nb2_pack_h2(mz - b1.x, bb - b1.y)};
+          } else
           if(DOTK) {
             s_buf[pos] = -2.0f * lx; s_buf[NB2_BUF + pos] = -2.0f * ly; s_buf[2 * NB2_BUF + pos] = -2.0f * lz;
             s_buf[3 * NB2_BUF + pos] = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));

@@ -16,7 +16,7 @@ for u in $units; do
   if [ $u = $unit ] || [ $unit = all ]; then
     fl="-ffp-contract=off"; case $u in force_lj|force_eam) fl="-ffp-contract=fast";; esac
     src=$u.hip; lang=""; [ -f $u.cpp ] && { src=$u.cpp; lang="-x hip"; }
-    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-result -I/opt/rocm/include $fl -DMMD_PRECISION=$PN "$@" $lang -c $src -o $out/$u.o &
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-result -I/opt/rocm/include -mllvm -amdgpu-mfma-vgpr-form=1 $fl -DMMD_PRECISION=$PN "$@" $lang -c $src -o $out/$u.o &
     objs="$objs $out/$u.o"
   else objs="$objs ../build/$P/$u.o"; fi
 done
