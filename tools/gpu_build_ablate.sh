@@ -1,6 +1,6 @@
 # phase split of k_build_rows by ablation (profiling libraries variants/profile, variants/profile_nomfma): tools/gpu_build_ablate.sh
 cd $GRAFT_REPO_ROOT
-for v in profile profile_nomfma; do
+for v in ${@:-profile profile_nomfma}; do
 MMD_LIB_DIR=variants/$v python - <<PY
 import sys; sys.path.insert(0, '.')
 import minimd_amd
