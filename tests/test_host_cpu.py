@@ -220,3 +220,25 @@ def test_harness_pass_rule_and_a_run_of_the_cpu_oracle():
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "run_one_test.py"), exe, "1", "1", "10", "100", "0", "0", "lj"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PASSED" in r.stdout and "Testfile: tests/reference_output/4k.lj" in r.stdout, r.stdout + r.stderr
+
+
+def test_register_budgets_of_the_hot_kernels():
+    """Occupancy on gfx950 goes in steps of 8 VGPRs (512 // VGPRs wavefronts per SIMD): the production instantiations must stay inside the budget they were tuned
+    for — the fused LJ tile kernel at 96 (5 wavefronts; 100 cost 2.4 % in round 5), the neighbor build at <= 128 (its 9.9 KB of LDS allow 4 per SIMD anyway).
+    Read from the built objects' AMDGPU metadata (tools/kernel_regs.py); no GPU needed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_regs", os.path.join(REPO, "tools", "kernel_regs.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = kr.kernels("dp")
+    assert len(ks) > 100, "kernel metadata not found in minimd_amd/build/dp (run __graft_entry__.build())"
+
+    def one(prefix):
+        m = [k for k in ks if k.startswith(prefix)]
+        assert len(m) == 1, (prefix, m)
+        return ks[m[0]]
+    for fuse in (0, 1, 2):        # k_lj_full_tile<0, false, 2, 8, 3, FUSE>: force only / fused integrator / fused finalIntegrate
+        k = one("_Z14k_lj_full_tileILi0ELb0ELi2ELi8ELi3ELi%dEE" % fuse)
+        assert k["vgpr"] <= 96 and k["agpr"] == 0, k
+    b = one("_Z12k_build_rowsILi0ELi0EE")
+    assert b["vgpr"] <= 128 and b["agpr"] == 0 and b["lds"] <= 10240, b      # (agpr == 0: the MFMA accumulators are read by VALU instructions, -amdgpu-mfma-vgpr-form)
