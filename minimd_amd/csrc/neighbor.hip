@@ -1003,8 +1003,8 @@ __device__ __forceinline__ float nb2_min3_abs(float acc, float a, float b)
 #ifndef NB2_MFMA
 #define NB2_MFMA 1
 #endif
-#ifndef NB2_MF_PIPE
-#define NB2_MF_PIPE 0            // (issuing a group's MFMAs one group ahead of the reads of their accumulators: measured 1.5 % slower, 119 instead of 108 VGPRs)
+#ifndef NB2_MFMA_CORE
+#define NB2_MFMA_CORE 1
 #endif
 typedef _Float16 nb2_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 nb2_h8 __attribute__((ext_vector_type(8)));
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
   constexpr bool DOTK = NB2_DOTF(MODE);
-  constexpr bool MFK = NB2_MFMA && DOTK && MODE == 0 && CORE == 0;      // the pre-test on the matrix cores (see above)
+  constexpr bool MFK = NB2_MFMA && DOTK && MODE == 0 && (CORE == 0 || NB2_MFMA_CORE);      // the pre-test on the matrix cores (see above); CORE: two more MFMAs against the core radius (a classification: no band)
   constexpr int NB2_NARR = DOTK ? 5 : 4;             // arrays of the candidate buffer: DOT -2x | -2y | -2z | |b|^2 | index, otherwise x | y | z | index
   constexpr int NB2_IDX = (NB2_NARR - 1) * NB2_BUF;  // the atom index (bit pattern) of a buffered candidate
   __shared__ __align__(16) float s_buf[NB2_NARR * NB2_BUF];
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const float thrc_i = owned ? (float)((double)core_thr - aa_d) : -1.0e30f;               // CORE: the same against the core radius
   const float twofz = 2.0f * fzi;
   // MFK: the atoms' operands of the two MFMAs, the per-atom error bounds that go with them, the masks that patch the upper half's candidate operand
-  nb2_h8 mfB1 = {}, mfB2 = {};
+  nb2_h8 mfB1 = {}, mfB2 = {}, mfB1c = {}, mfB2c = {};
   float mfEA = 0.0f, mfEB = 0.0f;
   const unsigned mf_my = lane < 32 ? 0xffffffffu : 0x0000ffffu, mf_mz = lane < 32 ? 0xffffffffu : 0xffff0000u;
   bool mf_range_bad = false;
@@ -1169,6 +1169,15 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     for(int j = 0; j < 4; j++) { const auto r = __builtin_amdgcn_permlane32_swap(hi4[j], lo4[j], false, false); o1[j] = r[0]; o2[j] = r[1]; }
     mfB1 = __builtin_bit_cast(nb2_h8, uint4{o1[0], o1[1], o1[2], o1[3]});
     mfB2 = __builtin_bit_cast(nb2_h8, uint4{o2[0], o2[1], o2[2], o2[3]});
+    if constexpr(CORE) {                  // the same operands with the core radius' threshold in k 11, 12
+      const float tcf = owned ? (float)((double)core_thr - aa_d) : -60000.0f;
+      const float tch = (float)(_Float16)tcf;
+      const unsigned c1 = nb2_pack_h2(fzi - b1.x, -tch), c2 = nb2_pack_h2(-(tcf - tch), 0.0f);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(h1, c1, false, false);
+      const auto r2 = __builtin_amdgcn_permlane32_swap(h0, c2, false, false);
+      mfB1c = __builtin_bit_cast(nb2_h8, uint4{o1[0], r1[0], r2[0], o1[3]});
+      mfB2c = __builtin_bit_cast(nb2_h8, uint4{o2[0], r1[1], r2[1], o2[3]});
+    }
     const float cutp = 1.001f * (float)cutneigh + 0.01f;
     const float sx = fabsf(fxi) + cutp, sy = fabsf(fyi) + cutp, sz = fabsf(fzi) + cutp;
     const float Ti = sx * sx + sy * sy + sz * sz + fabsf(thf) + 2.0f * (sx * fabsf(fxi) + sy * fabsf(fyi) + sz * fabsf(fzi)) + (float)cutneighsq;
@@ -1215,26 +1224,19 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     }
     __syncthreads();
     const int selfpos = (MODE == 0 || DOTK) ? (int)s_selfpos[lane] : -1;
-    // MFK: the two MFMAs of a group are issued one group ahead of the instructions that read their accumulators (NB2_MF_PIPE)
-    nb2_f16v mf_n1 = {}, mf_n2 = {};
-    auto mf_issue = [&](int gq) {
-      const uint4 rec = ((const uint4*)s_buf)[gq + (lane & 31)];
-      uint4 av = rec;
-      av.y = (rec.y & mf_my) | (0x3c003c00u & ~mf_my);             // upper half: {m_hi.z, 1.0}
-      av.z = (rec.z & mf_mz) | (0x3c003c00u & ~mf_mz);             //             {1.0, .}
-      const nb2_h8 A = __builtin_bit_cast(nb2_h8, av);
-      const nb2_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      mf_n1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, mfB1, zero, 0, 0, 0);
-      mf_n2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, mfB2, zero, 0, 0, 0);
-    };
-    if(MFK && NB2_MF_PIPE && fill8 > 0 && !(ablate & 2)) mf_issue(0);
     for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0, bits_c = 0;
       if constexpr(MFK) {
-        if(!NB2_MF_PIPE) mf_issue(gq);
-        const nb2_f16v d1 = mf_n1, d2 = mf_n2;
-        if(NB2_MF_PIPE && gq + 32 < fill8) mf_issue(gq + 32);
+        // (issuing a group's MFMAs one group ahead of the reads of their accumulators was built and measured 1.5 % slower: 119 instead of 108 VGPRs)
+        const uint4 rec = ((const uint4*)s_buf)[gq + (lane & 31)];
+        uint4 av = rec;
+        av.y = (rec.y & mf_my) | (0x3c003c00u & ~mf_my);             // upper half: {m_hi.z, 1.0}
+        av.z = (rec.z & mf_mz) | (0x3c003c00u & ~mf_mz);             //             {1.0, .}
+        const nb2_h8 A = __builtin_bit_cast(nb2_h8, av);
+        const nb2_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const nb2_f16v d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, mfB1, zero, 0, 0, 0);
+        const nb2_f16v d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, mfB2, zero, 0, 0, 0);
         unsigned w1 = 0, w2 = 0;
         float m1 = 3.0e38f, m2 = 3.0e38f;
 #pragma unroll
@@ -1248,6 +1250,17 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
         const bool amb = (int)(m1 < mfEA) | (int)(m2 < mfEB);
         const auto rw = __builtin_amdgcn_permlane32_swap(w1, w2, false, false);       // -> the two words of MY atom
         bits = (rw[0] << 16) | rw[1];
+        if constexpr(CORE) {
+          const nb2_f16v c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, mfB1c, zero, 0, 0, 0);
+          const nb2_f16v c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, mfB2c, zero, 0, 0, 0);
+          unsigned v1 = 0, v2 = 0;
+#pragma unroll
+          for(int i = 0; i < 16; i++) v1 = nb2_shift_sign(v1, c1[i]);
+#pragma unroll
+          for(int i = 0; i < 16; i++) v2 = nb2_shift_sign(v2, c2[i]);
+          const auto rc = __builtin_amdgcn_permlane32_swap(v1, v2, false, false);
+          bits_c = (rc[0] << 16) | rc[1];
+        }
         const unsigned long long ambm = __builtin_amdgcn_ballot_w64(amb);
         if(ambm != 0ull) {
           // some accumulator of the group is inside its atom's band: the pairs of that HALF of the group's candidates (the lower 32 lanes hold rows
@@ -1256,7 +1269,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           const real4 pq = x[jq >= 0 ? jq : 0];
           const bool walk0 = (unsigned)ambm != 0u, walk1 = (unsigned)(ambm >> 32) != 0u;
           const unsigned wmask = (walk0 ? 0xffff0000u : 0u) | (walk1 ? 0x0000ffffu : 0u);
-          unsigned ex = 0;
+          unsigned ex = 0, exc = 0;
           for(int c = 0; c < 32; c++) {
             if(!((c & 4) ? walk1 : walk0)) continue;
             const real qx = nb2_readlane(pq.x, c), qy = nb2_readlane(pq.y, c), qz = nb2_readlane(pq.z, c);
@@ -1264,8 +1277,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             const real dx = pme.x - qx, dy = pme.y - qy, dz = pme.z - qz;
             const real rsq = dx * dx + dy * dy + dz * dz;
             if(sj >= 0 && rsq <= cutneighsq) ex |= 1u << nb2_mf_bit(c);
+            if(CORE && sj >= 0 && (float)rsq <= core_thr) exc |= 1u << nb2_mf_bit(c);
           }
           bits = (bits & ~wmask) | (owned ? ex : 0u);
+          if(CORE) bits_c = (bits_c & ~wmask) | (owned ? exc : 0u);
         }
       } else
       if constexpr(DOTK) {
