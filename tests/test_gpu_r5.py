@@ -246,3 +246,76 @@ def test_boundary_tiles_on_the_communication_stream_change_nothing(prec):
         assert res["none"][0] == res[other][0]
         for a_, b_ in zip(res["none"][1:4], res[other][1:4]):
             np.testing.assert_array_equal(a_, b_)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Neighbor::build with the pre-test on the matrix cores (round 5): rows stay those of an all-double build
+# ---------------------------------------------------------------------------------------------------
+def _brute_force_rows(x, cutneighsq):
+    """full neighbor rows of owned atoms without ghosts, the reference's arithmetic (ref/neighbor.cpp:160-166: delx*delx + dely*dely + delz*delz <= cutneighsq)"""
+    d = x[:, None, :] - x[None, :, :]
+    rsq = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+    hit = rsq <= cutneighsq
+    np.fill_diagonal(hit, False)
+    return [np.nonzero(hit[i])[0] for i in range(len(x))]
+
+
+@pytest.mark.parametrize("prec", ["dp", "sp"])
+def test_neighbor_build_with_pairs_on_the_cutoff_sphere(prec):
+    """pairs placed ON the cutoff (rsq within a few ulps of cutneighsq, both sides) are exactly what the half-precision MFMA pre-test cannot decide: its band must
+    send them to the exact re-test. Rows against a brute-force list in the reference's arithmetic, as sets."""
+    rng = np.random.default_rng(11)
+    real = np.float64 if prec == "dp" else np.float32
+    cutneigh = real(2.8)
+    cutsq = real(cutneigh * cutneigh)
+    L = 33.6
+    pts = []
+    for c in rng.uniform(4.0, L - 4.0, (150, 3)):
+        pts.append(c)
+        for _ in range(6):                       # partners at distance cutneigh * (1 +- a few eps) in random directions
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            pts.append(c + u * float(cutneigh) * (1.0 + rng.integers(-6, 7) * (2.0e-16 if prec == "dp" else 1.0e-7)))
+    x = np.ascontiguousarray(np.array(pts), real)
+    h = mm().Handle(prec)
+    h.set_box([L, L, L])
+    h.set_mass(1.0)
+    n = len(x)
+    h.upload(x, np.zeros_like(x), np.zeros(n, np.int32), np.arange(1, n + 1, dtype=np.int32), nlocal=n)
+    h.neighbor_setup([20, 20, 20], float(cutneigh), 0, 1, 1)
+    h.neighbor_build()
+    assert h.neighbor_tile_stats()["tiles"] > 0
+    nb, nn = h.neighbor_download()
+    rows = _brute_force_rows(x, cutsq)
+    close = sum(int(np.sum(np.abs(((x[i] - x[rows[i]]) ** 2).sum(axis=1) / float(cutsq) - 1.0) < 1.0e-5)) for i in range(n) if len(rows[i]))
+    assert close > 300, close                    # (the construction did put pairs on the sphere)
+    for i in range(n):
+        assert nn[i] == len(rows[i]), (i, nn[i], len(rows[i]))
+        np.testing.assert_array_equal(np.sort(nb[i, :nn[i]]), rows[i])
+    h.close()
+
+
+def test_neighbor_build_of_stretched_tiles_falls_back_to_the_row_kernel():
+    """clusters strung along x in a long box: a tile of 64 atoms of one pencil spans hundreds of length units, |b|^2 of its candidates would leave the half range of
+    the MFMA pre-test — such a build is handed to the row kernel (no tile lists), with the same rows."""
+    rng = np.random.default_rng(5)
+    L = (640.0, 8.4, 8.4)
+    pts = []
+    for cx in np.arange(20.0, 620.0, 60.0):
+        for cy, cz in ((1.4, 1.4), (7.0, 4.2)):
+            pts.append(np.array([cx, cy, cz]) + rng.uniform(-1.0, 1.0, (12, 3)))
+    x = np.ascontiguousarray(np.concatenate(pts))
+    n = len(x)
+    h = mm().Handle("dp")
+    h.set_box(list(L))
+    h.set_mass(1.0)
+    h.upload(x, np.zeros_like(x), np.zeros(n, np.int32), np.arange(1, n + 1, dtype=np.int32), nlocal=n)
+    h.neighbor_setup([456, 6, 6], 2.8, 0, 1, 1)
+    h.neighbor_build()
+    assert h.neighbor_tile_stats()["tiles"] == 0
+    nb, nn = h.neighbor_download()
+    rows = _brute_force_rows(x, 2.8 * 2.8)
+    assert sum(len(r) for r in rows) > 1000
+    for i in range(n):
+        assert nn[i] == len(rows[i])
+        np.testing.assert_array_equal(np.sort(nb[i, :nn[i]]), rows[i])
+    h.close()
