@@ -1207,6 +1207,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   unsigned* __restrict__ ent2_w = ent_w + NB2_NG * 64;
   int cnt2 = 0, n2 = 0;
   bool any_ghost = false;
+  bool ghost_seen = false;                 // MFK: this lane gave a ghost a slot (any_ghost = one ballot at the end instead of one per group)
 
   // ---- phase 2 + expansion over the buffered candidates
   auto flush = [&]() {
@@ -1224,6 +1225,9 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     }
     __syncthreads();
     const int selfpos = (MODE == 0 || DOTK) ? (int)s_selfpos[lane] : -1;
+    // MFK: group and bit of the lane's own candidate record, once per buffer (the atom itself is a hit of its own lane: dropped in its group)
+    const int self_g = selfpos >> 5;                                   // (0xffff: group 2047, never reached)
+    const unsigned self_keep = ~(1u << nb2_mf_bit(selfpos & 31));
     for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0, bits_c = 0;
@@ -1435,7 +1439,8 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       }
       }       // (difference form)
       // full lists: the atom itself (rsq = 0) is a hit of its own lane: dropped here
-      if(MODE == 0) { const unsigned sp = (unsigned)(selfpos - gq); if(sp < (unsigned)G) bits &= ~(1u << (MFK ? nb2_mf_bit((int)sp) : G - 1 - (int)sp)); }
+      if(MFK) bits &= (gq >> 5) == self_g ? self_keep : ~0u;
+      else if(MODE == 0) { const unsigned sp = (unsigned)(selfpos - gq); if(sp < (unsigned)G) bits &= ~(1u << (G - 1 - (int)sp)); }
       // ---- the candidates some lane keeps form the tile's union: they get the next slots, in candidate order
       const unsigned used = wave_or_u(bits);
       const int bq_mine = MFK ? nb2_mf_bit(lane & 31) : G - 1 - lane;      // the bit candidate `lane` of the group sits at
@@ -1446,6 +1451,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           if(slot < cstride - 1) {
             const int cj = __float_as_int(s_buf[NB2_IDX + gq + lane]);
             tile_cand[cbase + slot] = cj;
+            if(MFK) ghost_seen = ghost_seen || cj >= nlocal;
             // (one rank: the same list with a ghost named by its owner and image code, for tile kernels that stage ghosts from their owners)
             // (several ranks, ghost_image == nullptr: ghost_root is DirectHalo::gmap — the entry of the position buffer the per-step halo delivers the ghost to)
             if(cand_src != nullptr) cand_src[cbase + slot] = cj >= nlocal && cj < nall ? (ghost_image != nullptr ? (ghost_root[cj - nlocal] | ((ghost_image[cj - nlocal] + 1) << MMD_SRC_BITS)) : ghost_root[cj - nlocal]) : cj;
@@ -1453,7 +1459,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           if(MODE != 0) { const unsigned own = s_own[gq + lane]; if(own != 0xffu) s_self[own] = (unsigned short)slot; }
         }
       }
-      any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (bq_mine & 31)) & 1u) && __float_as_int(s_buf[NB2_IDX + gq + lane]) >= nlocal) != 0ull;
+      if(!MFK) any_ghost = any_ghost || __builtin_amdgcn_ballot_w64(lane < G && ((used >> (bq_mine & 31)) & 1u) && __float_as_int(s_buf[NB2_IDX + gq + lane]) >= nlocal) != 0ull;
       // ---- a lane's NON-EMPTY hit words wait, with their group numbers, in a scratch list (lane-interleaved, read back by
       // the same lane) for the lock-step expansion at the end of the tile
       if(gcount < NB2_NG) {
@@ -1545,6 +1551,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // 128-byte line of nl16 and the padding comes for free. A lane's words are walked in group order; s_gS / s_gU give the slot
   // base and the union mask of a group.
   // (CORE: n = core entries, n2 = the rest; otherwise n = the row)
+  if(MFK) any_ghost = __builtin_amdgcn_ballot_w64(ghost_seen) != 0ull;
   const int maxn = (int)wave_max_u((unsigned)(n + n2));
   const int kc = min(((int)wave_max_u((unsigned)n) + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD, maxneighs);
   const int kr = CORE ? min(((int)wave_max_u((unsigned)n2) + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD, maxneighs - kc) : 0;
