@@ -1003,6 +1003,12 @@ __device__ __forceinline__ float nb2_min3_abs(float acc, float a, float b)
 #ifndef NB2_MFMA
 #define NB2_MFMA 1
 #endif
+// Round 5: a lane's hit words wait for the expansion in REGISTERS (one per group, written through a switch on the wave-uniform group number) instead of a
+// global scratch list — 125 MB per build at -s 80 that were written and read back, and a memory round trip at the start of every tile's expansion. The
+// non-empty ones are compacted into the LDS list the expansion walks when the last group is done. Not for the two-list core/rest rows (56 registers).
+#ifndef NB2_REGPARK
+#define NB2_REGPARK 1
+#endif
 #ifndef NB2_MFMA_CORE
 #define NB2_MFMA_CORE 1
 #endif
@@ -1196,6 +1202,10 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   int S = 0, fill = 0;                     // size of the union so far / culled candidates waiting in the buffer (wave-uniform)
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
+  constexpr bool REGP = NB2_REGPARK && !CORE;
+  unsigned pw[NB2_NE];                     // REGP: my hit word of every group
+#pragma unroll
+  for(int i = 0; i < NB2_NE; i++) pw[i] = 0u;
   // scratch of this tile: NB2_NG x 64 words; CORE: a second list of the same shape
   constexpr int WSTRIDE = NB2_NG * 64 * (CORE ? 2 : 1);
   unsigned* __restrict__ ent_w = tile_words + (size_t)tile * WSTRIDE + lane;
@@ -1471,6 +1481,16 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           n2 += __popc(rest);
           bits = bits_c;                                         // (n counts the core part below)
         } else
+        if(REGP) {
+#define NB2_PW(i) case i: pw[i] = bits; break;
+          switch(gcount) {
+            NB2_PW(0) NB2_PW(1) NB2_PW(2) NB2_PW(3) NB2_PW(4) NB2_PW(5) NB2_PW(6) NB2_PW(7) NB2_PW(8) NB2_PW(9) NB2_PW(10) NB2_PW(11) NB2_PW(12) NB2_PW(13)
+            NB2_PW(14) NB2_PW(15) NB2_PW(16) NB2_PW(17) NB2_PW(18) NB2_PW(19) NB2_PW(20) NB2_PW(21) NB2_PW(22) NB2_PW(23) NB2_PW(24) NB2_PW(25) NB2_PW(26) NB2_PW(27)
+            default: break;
+          }
+#undef NB2_PW
+          static_assert(NB2_NE == 28, "one case per register");
+        } else
         if(bits != 0u) { ent_w[(unsigned)cnt * 64u] = bits; gmask |= 1ull << gcount; cnt++; }
         if(lane == 0) s_gSU[gcount] = uint2{(unsigned)S, used};
       }
@@ -1567,10 +1587,25 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     // inside the loop a global load would put a full memory round trip into every round (s_waitcnt vmcnt(0) also waits for the
     // row stores), LDS reads do not
     unsigned* s_ew = (unsigned*)s_buf;
+    if(REGP) {
+      // the non-empty words go to consecutive entries of the lane's column, their groups into the mask: an empty word's store is overwritten by the next one
+      int c = 0;
+      unsigned long long gm = 0;
+#pragma unroll
+      for(int i = 0; i < NB2_NE; i++) {
+        if(i >= gcount) break;                                   // (wave-uniform)
+        const unsigned w = pw[i];
+        s_ew[c * 64 + lane] = w;
+        c += w != 0u ? 1 : 0;
+        gm |= w != 0u ? 1ull << i : 0ull;
+      }
+      mycnt = c; groups = gm;
+      maxcnt_over = maxcnt_over || gcount > NB2_NE;             // (more groups than registers: the row kernel builds the lists)
+    }
     const int wmax = (int)wave_max_u((unsigned)mycnt);
     maxcnt_over = maxcnt_over || wmax > NB2_NE;               // (a lane with more non-empty words than the LDS list holds)
     const int maxcnt = min(wmax, NB2_NE);
-    for(int e0 = 0; e0 < maxcnt; e0 += 4) {
+    for(int e0 = 0; e0 < maxcnt && !REGP; e0 += 4) {
       unsigned tw[4];
 #pragma unroll
       for(int u = 0; u < 4; u++) { tw[u] = 0; if(e0 + u < mycnt) tw[u] = src_w[(unsigned)(e0 + u) * 64u]; }
@@ -1916,7 +1951,8 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       }
     }
     h->core.rows_built = false;
-    if(h->opt_build == 1) MMD_TRY(h->tile_words.ensure((size_t)nt * NB2_NG * 64 * (core_rows ? 2 : 1) + 64, false, h->stream));
+    // (the hit words of a tile wait in registers; only the two-list core/rest rows of EAM still park them in this scratch)
+    if(h->opt_build == 1) MMD_TRY(h->tile_words.ensure((NB2_REGPARK && !core_rows) ? (size_t)64 : (size_t)nt * NB2_NG * 64 * 2 + 64, false, h->stream));
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
