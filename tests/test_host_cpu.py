@@ -242,3 +242,45 @@ def test_register_budgets_of_the_hot_kernels():
         assert k["vgpr"] <= 96 and k["agpr"] == 0, k
     b = one("_Z12k_build_rowsILi0ELi0EE")
     assert b["vgpr"] <= 128 and b["agpr"] == 0 and b["lds"] <= 10240, b      # (agpr == 0: the MFMA accumulators are read by VALU instructions, -amdgpu-mfma-vgpr-form)
+
+
+def test_error_model_of_the_mfma_pretest():
+    """The neighbor build's MFMA pre-test (minimd_amd/csrc/neighbor.hip, comment in front of k_build_rows) trusts the sign of d = |b|^2 - 2 a.b - (cutneigh^2 - |a|^2), evaluated on
+    hi/lo half pairs, iff |d| >= E_i = 40 x 2^-24 x T_i. 24 of the 40 units are the allowance for the hardware's fp32 accumulation (measured on the GPU: tools/probes/mfma_f16_probe);
+    the other 16 must cover everything that happens BEFORE the matrix core: float rounding of the local coordinates, the fp32 |b|^2 chain, the threshold through float, the
+    hi/lo splits, the dropped a_lo . m_lo. That part is arithmetic and is checked here in numpy, with the kernel's operations restated step by step (RN conversions, fma = exact
+    product + one rounding) and the 13 products summed exactly: |d_model - d_exact| <= 16 x 2^-24 x T_i for pairs ON the cutoff sphere of every atom of long pencil tiles."""
+    rng = np.random.default_rng(3)
+    f32, f16, f64 = np.float32, np.float16, np.float64
+    cutneigh = f64(2.8)
+    cutsq = cutneigh * cutneigh
+    n = 200000
+    # tile atoms: a pencil piece 9.7 x 2.8 x 2.8 somewhere in a 134-wide box; partners on the cutoff sphere (+- 1e-6 relative)
+    origin = rng.uniform(0.0, 120.0, (n, 3))                                   # the tile's bounding-box centre (double; what the kernel subtracts)
+    a = origin + rng.uniform(-1.0, 1.0, (n, 3)) * np.array([4.85, 1.4, 1.4])
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    b = a + u * (cutneigh * (1.0 + rng.uniform(-1.0e-6, 1.0e-6, n)))[:, None]
+    ox = f32(origin).astype(f64)                                               # (the kernel's origin is a float promoted to real)
+    fa = f32(a - ox)                                                           # (float)(pme - o)
+    lf = f32(b - ox)
+
+    def fma32(x, y, z):                                                        # fmaf: exact product (24 + 24 bits fit a double), one rounding
+        return f32(x.astype(f64) * y.astype(f64) + z.astype(f64))
+    m = f32(-2.0) * lf
+    bb = fma32(lf[:, 2], lf[:, 2], fma32(lf[:, 1], lf[:, 1], f32(lf[:, 0] * lf[:, 0])))
+    mh = f16(m); ml = f16(m - f32(mh))
+    bbh = f16(bb); bbl = f16(bb - f32(bbh))
+    aa_d = (fa.astype(f64) ** 2).sum(axis=1)
+    thf = f32(cutsq - aa_d)
+    th = f16(thf); tl = f16(thf - f32(th))
+    ah = f16(fa); al = f16(fa - f32(ah))
+    F = lambda q: q.astype(f64)
+    d_model = (F(ah) * F(mh) + F(ah) * F(ml) + F(al) * F(mh)).sum(axis=1) + F(bbh) + F(bbl) - F(th) - F(tl)
+    d_exact = ((a - b) ** 2).sum(axis=1) - cutsq
+    cutp = f32(1.001) * f32(cutneigh) + f32(0.01)
+    s = np.abs(fa) + cutp
+    T = (s * s).sum(axis=1) + np.abs(thf) + f32(2.0) * (s * np.abs(fa)).sum(axis=1) + f32(cutsq)
+    unit = 2.0 ** -24 * T.astype(f64)
+    worst = float(np.max(np.abs(d_model - d_exact) / unit))
+    assert worst <= 16.0, worst
+    assert worst > 0.5, worst                                                  # (the model is not vacuous: the arithmetic does lose a few units)
