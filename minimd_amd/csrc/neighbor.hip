@@ -1175,15 +1175,6 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
     for(int j = 0; j < 4; j++) { const auto r = __builtin_amdgcn_permlane32_swap(hi4[j], lo4[j], false, false); o1[j] = r[0]; o2[j] = r[1]; }
     mfB1 = __builtin_bit_cast(nb2_h8, uint4{o1[0], o1[1], o1[2], o1[3]});
     mfB2 = __builtin_bit_cast(nb2_h8, uint4{o2[0], o2[1], o2[2], o2[3]});
-    if constexpr(CORE) {                  // the same operands with the core radius' threshold in k 11, 12
-      const float tcf = owned ? (float)((double)core_thr - aa_d) : -60000.0f;
-      const float tch = (float)(_Float16)tcf;
-      const unsigned c1 = nb2_pack_h2(fzi - b1.x, -tch), c2 = nb2_pack_h2(-(tcf - tch), 0.0f);
-      const auto r1 = __builtin_amdgcn_permlane32_swap(h1, c1, false, false);
-      const auto r2 = __builtin_amdgcn_permlane32_swap(h0, c2, false, false);
-      mfB1c = __builtin_bit_cast(nb2_h8, uint4{o1[0], r1[0], r2[0], o1[3]});
-      mfB2c = __builtin_bit_cast(nb2_h8, uint4{o2[0], r1[1], r2[1], o2[3]});
-    }
     const float cutp = 1.001f * (float)cutneigh + 0.01f;
     const float sx = fabsf(fxi) + cutp, sy = fabsf(fyi) + cutp, sz = fabsf(fzi) + cutp;
     const float Ti = sx * sx + sy * sy + sz * sz + fabsf(thf) + 2.0f * (sx * fabsf(fxi) + sy * fabsf(fyi) + sz * fabsf(fzi)) + (float)cutneighsq;
@@ -1192,6 +1183,17 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
 #else
     const float Ei = owned ? 40.0f * 5.96046448e-08f * Ti : 0.0f;
 #endif
+    if constexpr(CORE) {                  // the same operands with the core radius' threshold in k 11, 12
+      // (a pair inside the core radius at the build MUST land in the core part — CoreRows, mmd_internal.hpp —, one outside may: the threshold is raised by the
+      //  atom's error bound, so the accumulator's sign can only err towards "core")
+      const float tcf = owned ? (float)((double)core_thr + (double)Ei - aa_d) : -60000.0f;
+      const float tch = (float)(_Float16)tcf;
+      const unsigned c1 = nb2_pack_h2(fzi - b1.x, -tch), c2 = nb2_pack_h2(-(tcf - tch), 0.0f);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(h1, c1, false, false);
+      const auto r2 = __builtin_amdgcn_permlane32_swap(h0, c2, false, false);
+      mfB1c = __builtin_bit_cast(nb2_h8, uint4{o1[0], r1[0], r2[0], o1[3]});
+      mfB2c = __builtin_bit_cast(nb2_h8, uint4{o2[0], r1[1], r2[1], o2[3]});
+    }
     const auto re = __builtin_amdgcn_permlane32_swap(__float_as_uint(Ei), __float_as_uint(Ei), false, false);
     mfEA = __uint_as_float(re[0]); mfEB = __uint_as_float(re[1]);
   }
@@ -1291,7 +1293,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
             const real dx = pme.x - qx, dy = pme.y - qy, dz = pme.z - qz;
             const real rsq = dx * dx + dy * dy + dz * dz;
             if(sj >= 0 && rsq <= cutneighsq) ex |= 1u << nb2_mf_bit(c);
-            if(CORE && sj >= 0 && (float)rsq <= core_thr) exc |= 1u << nb2_mf_bit(c);
+            if(CORE && sj >= 0 && rsq <= (real)core_thr) exc |= 1u << nb2_mf_bit(c);         // (core_thr carries its own float margin)
           }
           bits = (bits & ~wmask) | (owned ? ex : 0u);
           if(CORE) bits_c = (bits_c & ~wmask) | (owned ? exc : 0u);
