@@ -106,12 +106,13 @@ class stdout_to_stderr:
         return False
 
 
-def perf_summary_cold(size):
+def perf_summary_cold(size, nsteps=None):
     """what a user of the drop-in executable sees: `miniMD_dp -i in.lj.miniMD -s <size> --half_neigh 0` as a fresh process (cold GPU clocks,
-    no equilibration, no warm-up, the deck's 100 steps) and the value of its own PERF_SUMMARY line = natoms*ntimes/t_total of
+    no equilibration, no warm-up, the deck's 100 steps — or `-n nsteps`: the reference's own published logs are 1000- and 10 000-step runs,
+    tests/reference_output/864k.lj:133) and the value of its own PERF_SUMMARY line = natoms*ntimes/t_total of
     Integrate::run (ref/ljs.cpp:470-495). Reported beside the steady-state `value`, never instead of it."""
     exe = os.path.join(REPO, "minimd_amd", "bin", "miniMD_dp")
-    cmd = [exe, "-i", "in.lj.miniMD", "-s", str(size), "--half_neigh", "0"]
+    cmd = [exe, "-i", "in.lj.miniMD", "-s", str(size), "--half_neigh", "0"] + (["-n", str(nsteps)] if nsteps else [])
     try:
         r = subprocess.run(cmd, cwd=os.path.join(REPO, "data"), capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if "PERF_SUMMARY" in l and not l.startswith("#")][0].split()
@@ -184,6 +185,8 @@ def main():
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each, back to back: the FIRST is `value` (the contract's "
                                                           "K steps), all of them are listed in `value_windows` so that a short window shows its spread")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold run of the drop-in executable (perf_summary_cold)")
+    ap.add_argument("--sustained-steps", type=int, default=2000, help="ONE further timed window of this many steps behind the --windows short ones (0: none): what ~0.5 s of "
+                                                                      "this load runs at, next to the K-step `value`")
     ap.add_argument("--no-loopback", action="store_true", help="skip the one-GPU measurement of the multi-rank code path (rank_path_loopback)")
     ap.add_argument("--loopback-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--equil", type=int, default=100, help="untimed equilibration steps before the warm-up (set-up, see the module docstring)")
@@ -341,6 +344,12 @@ def main():
 
     tm = sim.handle.timers()
     rs = sim.handle.run_stats()
+    # the device-clock stamps of the FIRST window's force launches (the window `value` is): read before the next run resets them
+    clk_n = sim.handle.counter("force_clock_launches")
+    k_ms_all = sim.handle.counter("force_clock_ns") * 1e-6 / clk_n if clk_n > 0 else None
+    clk_ns_s, clk_n_s = sim.handle.counter("force_clock_sampled_ns"), sim.handle.counter("force_clock_sampled_launches")
+    gaps = sim.handle.counter("force_clock_gaps")
+    overhead_ms = sim.handle.counter("force_clock_gap_ns") * 1e-6 / gaps if gaps > 0 else None
     # further windows of the same length, back to back (each fenced like the first; `value` is the first one alone)
     window_s = [dt]
     for _ in range(max(args.windows, 1) - 1):
@@ -354,6 +363,27 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tw = float(t.item())
         window_s.append(tw)
+    # sustained: ONE window of --sustained-steps steps (default 2000 = ~0.45 s at -s 80: 100 re-neighborings, 20 thermo rows — the reference's loop as its own
+    # 1000 / 10 000-step logs run it), fenced like the others; the force kernel's device-clock span at its start, middle and end shows what the chip's clocks do
+    sustained = None
+    if args.sustained_steps > 0:
+        fence()
+        ts0 = time.perf_counter()
+        sim.run_steps(args.sustained_steps)
+        fence()
+        ts = time.perf_counter() - ts0
+        if dist is not None:
+            t = torch.tensor([ts], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts = float(t.item())
+        tms = sim.handle.timers()
+        sustained = {"steps": args.sustained_steps, "seconds": ts, "ms_per_step": ts / args.sustained_steps * 1e3, "value": natoms * args.sustained_steps / ts / 1e6,
+                     "unit": "Matom-steps/s", "vs_value": (natoms * args.sustained_steps / ts) / (natoms * args.steps / dt),
+                     "phases_s": {k: tms[k] for k in ("total", "comm", "force", "neigh", "extra")},
+                     # device-clock span of the force launches (first workgroup's start to last workgroup's end): mean of the window's first 100 launches, median of
+                     # the kept ones (its first and last 128), mean of its last 100
+                     "force_kernel_span_ms": {"first_100": sim.handle.counter("force_clock_first_ns") * 1e-6, "median_kept": sim.handle.counter("force_clock_median_ns") * 1e-6,
+                                              "last_100": sim.handle.counter("force_clock_last_ns") * 1e-6}}
     nlocal, nghost, _ = sim.handle.counts()
     # per-rank view of the timed region (max over ranks of every phase, rank 0's own next to it): with these a SCALE line is
     # diagnosable from the record alone — where the time went, how often the host stalled the GPU, how many bytes the halos moved
@@ -370,17 +400,12 @@ def main():
     # packets on the stream) — `frac` is their average, the launch behind the neighbor build and the last one of the slice included; the event pairs on
     # every 7th launch (rocprof's notion of a kernel's duration: dispatch to completion signal) are reported next to it as the sampled figure
     k_ms_sampled = tm["force_kernel_ms"] / max(tm["force_launches"], 1)
-    clk_n = sim.handle.counter("force_clock_launches")
-    k_ms_all = sim.handle.counter("force_clock_ns") * 1e-6 / clk_n if clk_n > 0 else None
     # a launch's device-clock span (first workgroup's start to last workgroup's end) is shorter than the duration rocprofv3 reports for it (dispatch to
     # completion): by the completion of the launch + the dispatch of its successor, i.e. by the idle time between two launches that follow each other directly —
     # which the same stamps give (mean over the back-to-back pairs of the timed region). `frac` prices every launch at span + that gap: the all-launch figure in
     # the profiler's terms (cross-checked against a trace of the same process: profiles/r05_frac_crosscheck.txt). The event pairs of the sampled clock add
     # ~9 us of marker packets to the launches that carry them: `frac_sampled` is the lower bound they give.
-    clk_ns_s, clk_n_s = sim.handle.counter("force_clock_sampled_ns"), sim.handle.counter("force_clock_sampled_launches")
     k_ms_span_sampled = clk_ns_s * 1e-6 / clk_n_s if clk_n_s > 0 else None
-    gaps = sim.handle.counter("force_clock_gaps")
-    overhead_ms = sim.handle.counter("force_clock_gap_ns") * 1e-6 / gaps if gaps > 0 else None
     k_ms = (k_ms_all + overhead_ms) if (k_ms_all and overhead_ms is not None) else (k_ms_all or k_ms_sampled)
     achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
     achieved_sampled = bpa * nlocal / (k_ms_sampled * 1e-3) / 1e9 if k_ms_sampled > 0 else None
@@ -423,6 +448,8 @@ def main():
         "valid": invalid_reason is None, "reason": invalid_reason,
         # consecutive timed windows of `steps` steps each (max over ranks); value == value_windows[0]
         "value_windows": [natoms * args.steps / w / 1e6 for w in window_s],
+        # one long window behind them (see --sustained-steps); `value` stays the contract's K-step window
+        "sustained": sustained,
         "config": {"workload": "in.lj.miniMD -s %d per GPU (global %dx%dx%d cells, %d atoms), full neighbor list, DP, "
                                "reneigh 20, thermo 100; set-up: %d untimed equilibration steps + %.0f ms of clock warm-up before the warm-up steps" % (args.size, nx, ny, nz, natoms, args.equil, args.clock_warm_ms),
                    "parallelism": "spatial %dx%dx%d, %s" % (dims + ({"rccl": "RCCL p2p halos over xGMI", "host": "host-staged halos (debug transport)",
@@ -474,6 +501,7 @@ def main():
     if rank == 0:
         out["rank_path_loopback"] = rank_path_loopback(args.size, args.steps) if (world == 1 and not args.no_loopback and not args.no_cold) else None
         out["perf_summary_cold"] = perf_summary_cold(args.size) if (world == 1 and not args.no_cold) else None
+        out["perf_summary_cold_1000_steps"] = perf_summary_cold(args.size, 1000) if (world == 1 and not args.no_cold) else None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

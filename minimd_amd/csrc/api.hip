@@ -631,6 +631,23 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
                 h->force_ms_all * 1e-3 * (h->force_launches_all > 0 && ovf_calls > h->force_launches_all ? (double)ovf_calls / h->force_launches_all : 1.0);
   // TIME_COMM also counts the per-step halos (GPU time between their events; the forward halos scaled from the sampled steps to all of them)
   h->timer[1] += h->comm_ms * 1e-3 + h->halo_ms * 1e-3 * (halo_timed > 0 ? (double)halo_calls / (double)halo_timed : 1.0);
+  // The reference's buckets are host wall-clock intervals that follow each other: they PARTITION t_total, and its t_other = t_total - t_force - t_neigh - t_comm
+  // (ref/integrate.cpp:100-107, 155-207; ref/ljs.cpp:485-495) is never negative. Here FORCE / NEIGH / COMM are GPU times between events, and on several ranks they
+  // can overlap each other: the halo of an overlapped step runs on the communication stream UNDER the interior tiles; sampled pairs are scaled to all calls; ranks that share a
+  // GPU over the debug transport see each other's kernels inside their own pairs. The raw sums are kept (timer_raw, counters "timer_raw_*_us"); what is reported is their
+  // exclusive share of the wall clock: time counted twice is taken off COMM first (communication hidden under Force::compute is by definition not on the rank's critical
+  // path; what stays is the EXPOSED part), then — only if the compute buckets alone exceed the wall clock (shared GPU) — off FORCE and NEIGH in proportion.
+  for(int i = 0; i < 5; i++) h->timer_raw[i] = h->timer[i];
+  {
+    double& tot = h->timer[0]; double& comm = h->timer[1]; double& force = h->timer[2]; double& neigh = h->timer[3]; double& extra = h->timer[4];
+    double excess = comm + force + neigh - tot;
+    if(excess > 0) {
+      const double take = std::min(excess, comm);
+      comm -= take; excess -= take;
+      if(excess > 0 && force + neigh > 0) { const double sc = (tot - comm) / (force + neigh); force *= sc; neigh *= sc; }
+      if(extra > comm) extra = comm;             // (TIME_TEST is a part of TIME_COMM, ref/integrate.cpp:155-166)
+    }
+  }
   return 0;
 }
 
@@ -658,26 +675,42 @@ static int fclk_harvest(mmd_handle* h)
   if(h->fclk_harvested) return 0;
   h->fclk_harvested = true;
   h->fclk_ms = 0; h->fclk_launches = 0; h->fclk_ms_sampled = 0; h->fclk_launches_sampled = 0; h->fclk_gap_ms = 0; h->fclk_gaps = 0;
+  h->fclk_first_ms = h->fclk_median_ms = h->fclk_last_ms = 0;
   if(h->fclk_n > 0 && h->fclk.p) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     static thread_local std::vector<unsigned long long> hc;
-    const int nl = std::min(h->fclk_n, FCLK_SLOTS);
-    hc.resize((size_t)FCLK_STRIDE * nl);
+    const int nkept = std::min(h->fclk_n, FCLK_SLOTS);
+    hc.resize((size_t)FCLK_STRIDE * nkept);
     HIP_TRY(hipMemcpy(hc.data(), h->fclk.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // launch numbers whose records survive, in launch order: all of a short run; the first half + the last half (ring) of a long one
+    std::vector<long long> kept;
+    if(h->fclk_n <= FCLK_SLOTS) for(int k = 0; k < h->fclk_n; k++) kept.push_back(k);
+    else { for(int k = 0; k < FCLK_SLOTS / 2; k++) kept.push_back(k); for(long long k = (long long)h->fclk_n - FCLK_SLOTS / 2; k < h->fclk_n; k++) kept.push_back(k); }
+    std::vector<double> spans;
     unsigned long long prev_end = 0;
-    for(int k = 0; k < nl; k++) {
-      const unsigned long long* c = hc.data() + (size_t)FCLK_STRIDE * k;
+    long long prev_k = -2;
+    for(long long k : kept) {
+      const int slot = fclk_slot(k);
+      const unsigned long long* c = hc.data() + (size_t)FCLK_STRIDE * slot;
       unsigned long long e = 0;
       for(int q = 0; q < FCLK_TAIL; q++) e = std::max(e, c[8 + q]);
       // two launches that follow each other directly (plain steps on one rank): the time between the last workgroup of one and the first of the next is
       // the completion of the first + the dispatch of the second — what a profiler's per-kernel duration contains beyond the span
-      if(prev_end != 0 && c[0] > prev_end && (double)(c[0] - prev_end) / h->clk_rate_hz < 30.0e-6) { h->fclk_gap_ms += (double)(c[0] - prev_end) / h->clk_rate_hz * 1e3; h->fclk_gaps++; }
-      prev_end = e;
+      if(k == prev_k + 1 && prev_end != 0 && c[0] > prev_end && (double)(c[0] - prev_end) / h->clk_rate_hz < 30.0e-6) { h->fclk_gap_ms += (double)(c[0] - prev_end) / h->clk_rate_hz * 1e3; h->fclk_gaps++; }
+      prev_end = e; prev_k = k;
       if(c[0] != 0 && e > c[0]) {
         const double ms = (double)(e - c[0]) / h->clk_rate_hz * 1e3;
         h->fclk_ms += ms; h->fclk_launches++;
-        if(h->fclk_sampled[k]) { h->fclk_ms_sampled += ms; h->fclk_launches_sampled++; }
+        spans.push_back(ms);
+        if(h->fclk_sampled[slot]) { h->fclk_ms_sampled += ms; h->fclk_launches_sampled++; }
       }
+    }
+    if(!spans.empty()) {
+      const size_t m = std::min<size_t>(100, spans.size());
+      for(size_t i = 0; i < m; i++) { h->fclk_first_ms += spans[i] / m; h->fclk_last_ms += spans[spans.size() - 1 - i] / m; }
+      std::vector<double> sorted = spans;
+      std::sort(sorted.begin(), sorted.end());
+      h->fclk_median_ms = sorted[sorted.size() / 2];
     }
   }
   return 0;
@@ -696,10 +729,18 @@ extern "C" int mmd_get_counter(mmd_handle* h, const char* name, long long* value
   else if(!strcmp(name, "force_clock_gaps")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_gaps; }
   else if(!strcmp(name, "force_clock_sampled_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_ms_sampled * 1e6); }       // ... the same over the launches that also carried an event pair
   else if(!strcmp(name, "force_clock_sampled_launches")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_launches_sampled; }
+  else if(!strcmp(name, "force_clock_first_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_first_ms * 1e6); }       // ... mean span of the run's first (up to) 100 launches,
+  else if(!strcmp(name, "force_clock_median_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_median_ms * 1e6); }     // median of the kept ones (a long run keeps its first and last 128),
+  else if(!strcmp(name, "force_clock_last_ns")) { MMD_TRY(fclk_harvest(h)); *value = (long long)(h->fclk_last_ms * 1e6); }         // mean of its last (up to) 100
   else if(!strcmp(name, "force_clock_launches")) { MMD_TRY(fclk_harvest(h)); *value = h->fclk_launches; }            // ... and how many there were
   else if(!strcmp(name, "overlap_choice")) *value = h->overlap_choice;        // halo overlap chosen by measurement: -1 undecided, 0 without, 1 with (option overlap = -1)
   else if(!strcmp(name, "overlap_trial_off_ns")) *value = (long long)(h->overlap_trial_s[0] * 1e9);      // per step, summed over the ranks
   else if(!strcmp(name, "overlap_trial_on_ns")) *value = (long long)(h->overlap_trial_s[1] * 1e9);
+  else if(!strcmp(name, "timer_raw_comm_us")) *value = (long long)(h->timer_raw[1] * 1e6);      // last run: GPU time of the buckets BEFORE they were made to partition the wall clock
+  else if(!strcmp(name, "timer_raw_force_us")) *value = (long long)(h->timer_raw[2] * 1e6);
+  else if(!strcmp(name, "timer_raw_neigh_us")) *value = (long long)(h->timer_raw[3] * 1e6);
+  else if(!strcmp(name, "rccl_check_partners")) *value = h->rccl_check_partners;      // RCCL bring-up self-check: partners a verified pattern was exchanged with ...
+  else if(!strcmp(name, "rccl_check_us")) *value = (long long)(h->rccl_check_s * 1e6);      // ... and what it took
   else if(!strcmp(name, "dh_total_recv")) *value = h->dh.total_recv;
   else if(!strcmp(name, "dh_R")) *value = h->dh.R;
   else if(!strcmp(name, "dh_gmap_live")) *value = h->dh.gmap_live ? 1 : 0;

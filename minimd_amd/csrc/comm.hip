@@ -10,6 +10,13 @@
 // Halo element = real4 {x,y,z,(real)type} so a remote swap is received straight into x[firstrecv...]
 // (unpack elided).
 #include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <string>
+#include <thread>
 
 #include "device_utils.hpp"
 #include "mmd_internal.hpp"
@@ -73,6 +80,9 @@ extern "C" int mmd_comm_setup(mmd_handle* h, mmd_float cutneigh, int me, int npr
   for(int d = 0; d < 3; d++) { h->bg.sublo[d] = h->bg_ref.sublo[d] = h->lo[d]; h->bg.subhi[d] = h->bg_ref.subhi[d] = h->hi[d]; }      // (a Neighbor::setup that ran before this)
   for(auto& s : h->swaps) s.sendlist.release();
   h->swaps.clear();
+  // a set-up on a handle that has run before: nothing sized from the previous decomposition may survive it — the fixed-size messages of the direct
+  // borders / exchange are derived from the PREVIOUS counts on both sides of a pair, and the overlap choice was measured on the old grid
+  h->dh.prev_valid = false; h->dh.gmap_live = false; h->dh.ready = false; h->borders_general_done = false; h->ex_prev_valid = false; h->overlap_choice = -1;
   for(int d = 0; d < 3; d++) {
     for(int ineed = 0; ineed < 2 * h->need[d]; ineed++) {
       Swap s;
@@ -149,15 +159,140 @@ extern "C" int mmd_comm_unique_id(unsigned char id[128])
   return 0;
 }
 
+// ---- RCCL bring-up with a diagnosis instead of a hang ---------------------------------------------------------------------------------------------
+// The first multi-GPU lease is the first time ncclSend / ncclRecv run between two devices. A mis-wired node (a rank without its device, a dead xGMI link, a rank
+// that never arrives) shows as a process that sits in ncclCommInitRank or in its first grouped send/recv until somebody's time limit ends the lease. So:
+//  * ncclCommInitRank runs on a helper thread with a bounded wait (MMD_RCCL_TIMEOUT seconds, default 90);
+//  * right behind it ONE grouped send/recv of a known pattern with every distinct partner of Comm::setup's grid (the up to 26 neighbours of the direct halo) and
+//    ONE all-reduce, both verified, both with the same bounded wait on the stream;
+//  * every failure names rank, device (PCI bus id), the partners and what was seen, on stderr of the rank that saw it.
+// nranks == 1 (loop-back: bench.py's rank_path_loopback, the tests) runs the same code with itself as the only partner.
+namespace {
+constexpr int SC_N = 256;                       // ints per partner message
+inline int sc_value(int from, int to, int i) { return from * 1000003 + to * 101 + i * 7 + 13; }
+double sc_timeout_s()
+{
+  const char* e = getenv("MMD_RCCL_TIMEOUT");
+  const double v = e && *e ? atof(e) : 90.0;
+  return v > 0 ? v : 90.0;
+}
+// the stream drained within the limit?
+bool sc_wait(hipStream_t st, double seconds)
+{
+  const double t0 = mmd_wall();
+  for(;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if(q == hipSuccess) return true;
+    if(q != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+    if(mmd_wall() - t0 > seconds) { (void)hipGetLastError(); return false; }
+    usleep(200);
+  }
+}
+}  // namespace
+
+static int rccl_self_check(mmd_handle* h, ncclComm_t c, int rank, int nranks, const char* where)
+{
+  // distinct partners: the 26 grid neighbours when Comm::setup has run for this many ranks, else every other rank (up to 26), else the ring neighbours
+  std::vector<int> partners;
+  auto add = [&](int r) { if(r != rank && std::find(partners.begin(), partners.end(), r) == partners.end()) partners.push_back(r); };
+  if(nranks == 1) partners.push_back(0);
+  else if(h->nprocs == nranks && h->procgrid[0] * h->procgrid[1] * h->procgrid[2] == nranks) {
+    for(int a = -1; a <= 1; a++) for(int b = -1; b <= 1; b++) for(int d = -1; d <= 1; d++)
+      add(cart_rank(h->procgrid, h->myloc[0] + a, h->myloc[1] + b, h->myloc[2] + d));
+  } else if(nranks <= 27) { for(int r = 0; r < nranks; r++) add(r); }
+  else { add((rank + 1) % nranks); add((rank + nranks - 1) % nranks); }
+  std::sort(partners.begin(), partners.end());
+  const int np = (int)partners.size();
+  std::string plist;
+  for(int r : partners) plist += (plist.empty() ? "" : ",") + std::to_string(r);
+  const double limit = sc_timeout_s();
+  const double t0 = mmd_wall();
+  int* d_buf = nullptr;
+  double* d_red = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_buf, (size_t)2 * std::max(np, 1) * SC_N * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&d_red, 2 * sizeof(double)));
+  std::vector<int> hb((size_t)2 * std::max(np, 1) * SC_N, -1);
+  for(int k = 0; k < np; k++) for(int i = 0; i < SC_N; i++) hb[(size_t)k * SC_N + i] = sc_value(rank, partners[k], i);
+  HIP_TRY(hipMemcpyAsync(d_buf, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  auto fail = [&](const char* what) {
+    fprintf(stderr, "miniMD-HIP: RCCL bring-up FAILED on rank %d of %d (%s, %s): %s — partners %s; NCCL_DEBUG=INFO shows the transport RCCL chose per peer, "
+                    "MMD_TRANSPORT=tcp runs over the host mesh instead, MMD_RCCL_TIMEOUT sets this check's patience (now %g s)\n", rank, nranks, where, h->pci, what, plist.c_str(), limit);
+    fflush(stderr);
+    mmd_set_error("RCCL bring-up failed on rank %d of %d (%s): %s (partners %s)", rank, nranks, h->pci, what, plist.c_str());
+    (void)ncclCommAbort(c);                    // (kills whatever RCCL kernel still waits for its peer: the process can end with the message instead of hanging)
+    (void)hipFree(d_buf); (void)hipFree(d_red);
+    return -1;
+  };
+  // (1) one grouped send/recv with every distinct partner: same order on both sides of every pair (ascending partner rank)
+  NCCL_TRY(ncclGroupStart());
+  for(int k = 0; k < np; k++) {
+    NCCL_TRY(ncclSend(d_buf + (size_t)k * SC_N, SC_N, ncclInt, partners[k], c, h->stream));
+    NCCL_TRY(ncclRecv(d_buf + (size_t)(np + k) * SC_N, SC_N, ncclInt, partners[k], c, h->stream));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  if(!sc_wait(h->stream, limit)) return fail("the grouped ncclSend/ncclRecv with the partners did not complete (a partner never posted its side, or a link between two of the devices does not carry data)");
+  HIP_TRY(hipMemcpy(hb.data(), d_buf, hb.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for(int k = 0; k < np; k++)
+    for(int i = 0; i < SC_N; i++)
+      if(hb[(size_t)(np + k) * SC_N + i] != sc_value(partners[k], rank, i)) {
+        char b[200];
+        snprintf(b, sizeof(b), "message from rank %d arrived corrupted: word %d is %d, expected %d", partners[k], i, hb[(size_t)(np + k) * SC_N + i], sc_value(partners[k], rank, i));
+        return fail(b);
+      }
+  // (2) one all-reduce (the thermo sums' collective, ref/thermo.cpp:131-133)
+  const double mine[2] = {(double)(rank + 1), 1.0};
+  HIP_TRY(hipMemcpyAsync(d_red, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
+  NCCL_TRY(ncclAllReduce(d_red, d_red, 2, ncclDouble, ncclSum, c, h->stream));
+  if(!sc_wait(h->stream, limit)) return fail("ncclAllReduce over all ranks did not complete (some rank is not in the collective)");
+  double got[2] = {0, 0};
+  HIP_TRY(hipMemcpy(got, d_red, sizeof(got), hipMemcpyDeviceToHost));
+  if(got[0] != 0.5 * nranks * (nranks + 1.0) || got[1] != (double)nranks) {
+    char b[160];
+    snprintf(b, sizeof(b), "ncclAllReduce(sum) returned %.1f / %.1f, expected %.1f / %d", got[0], got[1], 0.5 * nranks * (nranks + 1.0), nranks);
+    return fail(b);
+  }
+  HIP_TRY(hipFree(d_buf));
+  HIP_TRY(hipFree(d_red));
+  h->rccl_check_partners = np;
+  h->rccl_check_s = mmd_wall() - t0;
+  return 0;
+}
+
 extern "C" int mmd_comm_init_rccl(mmd_handle* h, const unsigned char id[128], int rank, int nranks)
 {
-  if(!h || !id) { mmd_set_error("mmd_comm_init_rccl: bad arguments"); return -1; }
+  if(!h || !id || nranks < 1 || rank < 0 || rank >= nranks) { mmd_set_error("mmd_comm_init_rccl: bad arguments"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
+  if(hipDeviceGetPCIBusId(h->pci, (int)sizeof(h->pci), h->device) != hipSuccess) { (void)hipGetLastError(); snprintf(h->pci, sizeof(h->pci), "device %d", h->device); }
   ncclUniqueId u;
   memcpy(&u, id, 128);
-  ncclComm_t c;
-  NCCL_TRY(ncclCommInitRank(&c, nranks, u, rank));
-  h->rccl = (void*)c;
+  // ncclCommInitRank blocks until every rank of the communicator has arrived: on a helper thread, so that a rank that never comes ends in a message
+  struct Init { ncclComm_t c = nullptr; ncclResult_t r = ncclSuccess; std::atomic<int> done{0}; };
+  auto st = std::make_shared<Init>();
+  const int dev = h->device;
+  std::thread([st, u, rank, nranks, dev]() {
+    (void)hipSetDevice(dev);
+    st->r = ncclCommInitRank(&st->c, nranks, u, rank);
+    st->done.store(1, std::memory_order_release);
+  }).detach();
+  const double limit = sc_timeout_s(), t0 = mmd_wall();
+  while(!st->done.load(std::memory_order_acquire)) {
+    if(mmd_wall() - t0 > limit) {
+      fprintf(stderr, "miniMD-HIP: RCCL bring-up FAILED on rank %d of %d (%s): ncclCommInitRank did not return within %g s — not every rank of the communicator arrived "
+                      "(did all %d ranks start? same ncclUniqueId on all of them? one device per rank?); MMD_RCCL_TIMEOUT sets the patience\n", rank, nranks, h->pci, limit, nranks);
+      fflush(stderr);
+      mmd_set_error("RCCL bring-up: ncclCommInitRank did not return within %g s on rank %d of %d (%s)", limit, rank, nranks, h->pci);
+      return -1;
+    }
+    usleep(500);
+  }
+  if(st->r != ncclSuccess) {
+    fprintf(stderr, "miniMD-HIP: RCCL bring-up FAILED on rank %d of %d (%s): ncclCommInitRank: %s\n", rank, nranks, h->pci, ncclGetErrorString(st->r));
+    mmd_set_error("ncclCommInitRank failed on rank %d of %d (%s): %s", rank, nranks, h->pci, ncclGetErrorString(st->r));
+    return -1;
+  }
+  const char* skip = getenv("MMD_RCCL_SELFCHECK");
+  if(!(skip && !strcmp(skip, "0"))) MMD_TRY(rccl_self_check(h, st->c, rank, nranks, "first exchange"));
+  h->rccl = (void*)st->c;
   return 0;
 }
 

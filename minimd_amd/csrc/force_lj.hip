@@ -786,10 +786,13 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   SpecLaunch SP = list == nullptr ? h->spec : SpecLaunch{nullptr, nullptr, nullptr, nullptr};
   // the launch's own clock (whole-list launches inside a run; a launch cancelled by the build's verdict is stamped again by the one that replaces it)
   SP.clk = nullptr;
-  if(list == nullptr && h->in_run && h->opt_force_clock && h->fclk.p != nullptr && (h->fclk_n < FCLK_SLOTS || h->spec_clk_redo)) {
-    if(h->spec_clk_redo) { h->fclk_n--; h->spec_clk_redo = false; HIP_TRY(hipMemsetAsync(h->fclk.p + (size_t)FCLK_STRIDE * h->fclk_n, 0, FCLK_STRIDE * sizeof(unsigned long long), h->stream)); }
-    SP.clk = h->fclk.p + (size_t)FCLK_STRIDE * h->fclk_n;
-    h->fclk_sampled[h->fclk_n] = kev_a != nullptr;          // (this launch also carries the event pair of the sampled clock)
+  if(list == nullptr && h->in_run && h->opt_force_clock && h->fclk.p != nullptr) {
+    // (a run longer than FCLK_SLOTS launches keeps the stamps of its first FCLK_SLOTS / 2 and, in a ring, of its LAST FCLK_SLOTS / 2 launches: every word of a record is
+    //  a plain store of a later time than the one it replaces, so a re-used record needs no clearing)
+    if(h->spec_clk_redo) { h->fclk_n--; h->spec_clk_redo = false; HIP_TRY(hipMemsetAsync(h->fclk.p + (size_t)FCLK_STRIDE * fclk_slot(h->fclk_n), 0, FCLK_STRIDE * sizeof(unsigned long long), h->stream)); }
+    const int slot = fclk_slot(h->fclk_n);
+    SP.clk = h->fclk.p + (size_t)FCLK_STRIDE * slot;
+    h->fclk_sampled[slot] = kev_a != nullptr;          // (this launch also carries the event pair of the sampled clock)
     h->fclk_n++;
   }
   if(SP.gate != nullptr) { h->spec_launches++; h->spec_fused = fz == 1; }

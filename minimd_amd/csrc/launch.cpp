@@ -45,24 +45,39 @@ static bool env_int(const char* name, int* out)
   return true;
 }
 
+// what the last mmd_launch_env believed, in words: goes into the message of a rendezvous nobody else shows up for
+static char g_launch_belief[256] = "no launcher variables: single rank";
+
 extern "C" int mmd_launch_env(int* rank, int* nranks, int* local_rank, int* local_size, char* launcher, int launcher_len)
 {
   struct Src { const char* name; const char* rank; const char* size; const char* lrank; const char* lsize; };
+  // Slurm exports SLURM_PROCID=0 / SLURM_NTASKS=N to the batch shell of `sbatch -n N` as well: a bare ./miniMD started there is a singleton for MPI, and for
+  // us — the Slurm row counts only inside a job STEP (srun: numeric SLURM_STEP_ID) and takes its size from the step (SLURM_STEP_NUM_TASKS)
   static const Src srcs[] = {
       {"torchrun", "RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"},
       {"openmpi", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_SIZE"},
       {"pmi", "PMI_RANK", "PMI_SIZE", "MPI_LOCALRANKID", "MPI_LOCALNRANKS"},
       {"pmix", "PMIX_RANK", "PMIX_SIZE", "PMIX_LOCAL_RANK", "PMIX_LOCAL_SIZE"},
-      {"slurm", "SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID", "SLURM_NTASKS_PER_NODE"},
+      {"slurm", "SLURM_PROCID", "SLURM_STEP_NUM_TASKS", "SLURM_LOCALID", "SLURM_STEP_TASKS_PER_NODE"},
   };
   int r = 0, n = 1, lr = -1, ls = -1;
   const char* how = "single";
+  // explicit override: MMD_LAUNCHER=none (or MMD_NRANKS=1) = a singleton whatever the environment holds (a stale RANK / WORLD_SIZE, a batch shell);
+  // MMD_LAUNCHER=<row name> = believe that launcher's variables only
+  const char* want = getenv("MMD_LAUNCHER");
+  int forced_n = 0;
+  const bool single = (want && (!strcmp(want, "none") || !strcmp(want, "single"))) || (env_int("MMD_NRANKS", &forced_n) && forced_n == 1);
+  snprintf(g_launch_belief, sizeof(g_launch_belief), single ? "MMD_LAUNCHER=none / MMD_NRANKS=1: single rank" : "no launcher variables: single rank");
   for(const Src& s : srcs) {
-    int rr, nn;
+    if(single) break;
+    if(want && *want && strcmp(want, s.name)) continue;
+    int rr, nn, step;
+    if(!strcmp(s.name, "slurm") && !env_int("SLURM_STEP_ID", &step)) continue;      // (not inside srun: the batch shell's variables are not a launch)
     if(env_int(s.rank, &rr) && env_int(s.size, &nn)) {
       r = rr; n = nn; how = s.name;
       if(!env_int(s.lrank, &lr)) lr = -1;
       if(!env_int(s.lsize, &ls)) ls = -1;
+      snprintf(g_launch_belief, sizeof(g_launch_belief), "%s=%d and %s=%d (%s) — MMD_LAUNCHER=none runs a single rank regardless", s.rank, rr, s.size, nn, s.name);
       break;
     }
   }
@@ -114,7 +129,25 @@ struct mmd_mesh {
 };
 
 static const uint32_t MESH_MAGIC = 0x6d6d6468u;      // "mmdh"
-struct MeshHello { uint32_t magic; int32_t rank, nranks, port; };
+struct MeshHello { uint32_t magic; int32_t rank, nranks, port; uint32_t nonce; };
+// a number every rank of THIS job derives alike and another job on the same port almost surely does not: the launcher's job id (or, without one, the
+// rendezvous address itself), mixed with the world size
+static uint32_t job_nonce(const char* addr, int port, int nranks)
+{
+  unsigned h = 2166136261u;
+  const char* keys[] = {"SLURM_JOB_ID", "SLURM_STEP_ID", "OMPI_MCA_ess_base_jobid", "OMPI_MCA_orte_ess_jobid", "PMIX_NAMESPACE", "PMI_JOBID", "PBS_JOBID", "LSB_JOBID", "TORCHELASTIC_RUN_ID"};
+  for(const char* k : keys) { const char* e = getenv(k); if(e && *e) h = hash_str(e, h); }
+  char b[96];
+  snprintf(b, sizeof(b), "%s:%d/%d", addr && *addr ? addr : "127.0.0.1", port, nranks);
+  return hash_str(b, h);
+}
+// an accepted stream gets a few seconds to say who it is: a stranger that connects and sends nothing (a port scanner, another job that derived the same
+// port) is dropped instead of stalling the job's start-up
+static void set_rcv_timeout(int fd, int seconds)
+{
+  timeval tv{seconds, 0};
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+}
 struct MeshHdr { uint32_t magic, tag; uint64_t nbytes; };
 
 static int set_nonblock(int fd, bool on)
@@ -182,24 +215,27 @@ extern "C" int mmd_mesh_create(int rank, int nranks, const char* addr, int port,
   m->rank = rank; m->nranks = nranks;
   m->fd.assign(nranks, -1);
   if(nranks == 1) { *out = m; return 0; }
-  const double patience = 120.0;
+  double patience = 120.0;                // (MMD_MESH_PATIENCE seconds: how long a rank waits for the others)
+  { const char* e = getenv("MMD_MESH_PATIENCE"); if(e && *e && atof(e) > 0) patience = atof(e); }
   const int mport = port + 17;
-  // my own listener (ephemeral port): ranks above me connect to it
+  const uint32_t nonce = job_nonce(addr, port, nranks);
+  // my own listener (ephemeral port) for the ranks above me: opened on the interface my stream to rank 0 uses (below), not on every interface
   int ls = -1, my_port = 0;
-  if(rank > 0 && rank < nranks - 1) {
+  auto open_listener = [&](uint32_t local_ip) -> bool {
     ls = socket(AF_INET, SOCK_STREAM, 0);
     sockaddr_in sa;
     memset(&sa, 0, sizeof(sa));
-    sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = 0;
+    sa.sin_family = AF_INET; sa.sin_addr.s_addr = local_ip; sa.sin_port = 0;
     socklen_t sl = sizeof(sa);
     if(ls < 0 || bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || listen(ls, nranks) != 0 || getsockname(ls, (sockaddr*)&sa, &sl) != 0) {
       mmd_set_error("mesh: rank %d cannot open a listening socket: %s", rank, strerror(errno));
       if(ls >= 0) close(ls);
-      mmd_mesh_destroy(m);
-      return -1;
+      ls = -1;
+      return false;
     }
     my_port = ntohs(sa.sin_port);
-  }
+    return true;
+  };
   std::vector<uint32_t> ip(nranks, 0);
   std::vector<int32_t> ports(nranks, 0);
   if(rank == 0) {
@@ -208,8 +244,11 @@ extern "C" int mmd_mesh_create(int rank, int nranks, const char* addr, int port,
     setsockopt(s0, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
     sockaddr_in sa;
     memset(&sa, 0, sizeof(sa));
-    sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons((uint16_t)mport);
-    if(s0 < 0 || bind(s0, (sockaddr*)&sa, sizeof(sa)) != 0 || listen(s0, nranks) != 0) {
+    // listen where the ranks were told to meet (MASTER_ADDR, else loop-back) — on every interface only when that address is not one of this host's
+    if(!resolve(addr && *addr ? addr : "127.0.0.1", mport, &sa)) { memset(&sa, 0, sizeof(sa)); sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons((uint16_t)mport); }
+    bool bound = s0 >= 0 && bind(s0, (sockaddr*)&sa, sizeof(sa)) == 0;
+    if(!bound && s0 >= 0 && errno == EADDRNOTAVAIL) { sa.sin_addr.s_addr = htonl(INADDR_ANY); bound = bind(s0, (sockaddr*)&sa, sizeof(sa)) == 0; }
+    if(!bound || listen(s0, nranks) != 0) {
       mmd_set_error("mesh: rank 0 cannot listen on port %d (%s) — export MASTER_PORT to choose another one", mport, strerror(errno));
       if(s0 >= 0) close(s0);
       mmd_mesh_destroy(m);
@@ -217,17 +256,22 @@ extern "C" int mmd_mesh_create(int rank, int nranks, const char* addr, int port,
     }
     for(int k = 1; k < nranks; k++) {
       pollfd pf{s0, POLLIN, 0};
-      if(poll(&pf, 1, (int)(patience * 1000)) <= 0) { mmd_set_error("mesh: rank 0 waited %g s on port %d, %d of %d ranks arrived", patience, mport, k, nranks); close(s0); mmd_mesh_destroy(m); return -1; }
+      if(poll(&pf, 1, (int)(patience * 1000)) <= 0) {
+        mmd_set_error("mesh: rank 0 waited %g s on port %d and %d of %d ranks arrived — the size was taken from %s", patience, mport, k, nranks, g_launch_belief);
+        close(s0); mmd_mesh_destroy(m); return -1;
+      }
       sockaddr_in pa;
       socklen_t pl = sizeof(pa);
       const int cs = accept(s0, (sockaddr*)&pa, &pl);
       MeshHello hl;
-      if(cs < 0 || !read_all(cs, &hl, sizeof(hl)) || hl.magic != MESH_MAGIC || hl.nranks != nranks || hl.rank <= 0 || hl.rank >= nranks || m->fd[hl.rank] >= 0) {
+      if(cs >= 0) set_rcv_timeout(cs, 5);
+      if(cs < 0 || !read_all(cs, &hl, sizeof(hl)) || hl.magic != MESH_MAGIC || hl.nonce != nonce || hl.nranks != nranks || hl.rank <= 0 || hl.rank >= nranks || m->fd[hl.rank] >= 0) {
         // (a stranger on the port — another job that derived the same number, a port scanner: not one of mine)
         if(cs >= 0) close(cs);
         k--;
         continue;
       }
+      set_rcv_timeout(cs, 0);
       tune(cs);
       m->fd[hl.rank] = cs;
       ip[hl.rank] = pa.sin_addr.s_addr;
@@ -240,11 +284,18 @@ extern "C" int mmd_mesh_create(int rank, int nranks, const char* addr, int port,
       }
   } else {
     sockaddr_in sa;
-    if(!resolve(addr && *addr ? addr : "127.0.0.1", mport, &sa)) { mmd_set_error("mesh: cannot resolve '%s'", addr); if(ls >= 0) close(ls); mmd_mesh_destroy(m); return -1; }
+    if(!resolve(addr && *addr ? addr : "127.0.0.1", mport, &sa)) { mmd_set_error("mesh: cannot resolve '%s'", addr); mmd_mesh_destroy(m); return -1; }
     const int s = connect_retry(sa, patience);
-    MeshHello hl{MESH_MAGIC, rank, nranks, my_port};
+    if(s >= 0 && rank < nranks - 1) {
+      sockaddr_in me_sa;
+      socklen_t ml = sizeof(me_sa);
+      if(getsockname(s, (sockaddr*)&me_sa, &ml) != 0) me_sa.sin_addr.s_addr = htonl(INADDR_ANY);
+      if(!open_listener(me_sa.sin_addr.s_addr)) { close(s); mmd_mesh_destroy(m); return -1; }
+    }
+    MeshHello hl{MESH_MAGIC, rank, nranks, my_port, nonce};
     if(s < 0 || !write_all(s, &hl, sizeof(hl)) || !read_all(s, ip.data(), nranks * sizeof(uint32_t)) || !read_all(s, ports.data(), nranks * sizeof(int32_t))) {
-      mmd_set_error("mesh: rank %d could not reach rank 0 at %s:%d (export MASTER_ADDR / MASTER_PORT if the launcher does not)", rank, addr ? addr : "127.0.0.1", mport);
+      mmd_set_error("mesh: rank %d of %d could not reach rank 0 at %s:%d (export MASTER_ADDR / MASTER_PORT if the launcher does not) — rank and size were taken from %s", rank, nranks,
+                    addr ? addr : "127.0.0.1", mport, g_launch_belief);
       if(s >= 0) close(s);
       if(ls >= 0) close(ls);
       mmd_mesh_destroy(m);
@@ -257,7 +308,7 @@ extern "C" int mmd_mesh_create(int rank, int nranks, const char* addr, int port,
       memset(&pj, 0, sizeof(pj));
       pj.sin_family = AF_INET; pj.sin_addr.s_addr = ip[j]; pj.sin_port = htons((uint16_t)ports[j]);
       const int c = connect_retry(pj, patience);
-      MeshHello h2{MESH_MAGIC, rank, nranks, 0};
+      MeshHello h2{MESH_MAGIC, rank, nranks, 0, nonce};
       if(c < 0 || !write_all(c, &h2, sizeof(h2))) { mmd_set_error("mesh: rank %d could not reach rank %d", rank, j); if(c >= 0) close(c); if(ls >= 0) close(ls); mmd_mesh_destroy(m); return -1; }
       m->fd[j] = c;
     }
@@ -266,7 +317,9 @@ extern "C" int mmd_mesh_create(int rank, int nranks, const char* addr, int port,
       if(poll(&pf, 1, (int)(patience * 1000)) <= 0) { mmd_set_error("mesh: rank %d waited in vain for %d higher ranks", rank, need); close(ls); mmd_mesh_destroy(m); return -1; }
       const int cs = accept(ls, nullptr, nullptr);
       MeshHello h2;
-      if(cs < 0 || !read_all(cs, &h2, sizeof(h2)) || h2.magic != MESH_MAGIC || h2.nranks != nranks || h2.rank <= rank || h2.rank >= nranks || m->fd[h2.rank] >= 0) { if(cs >= 0) close(cs); continue; }
+      if(cs >= 0) set_rcv_timeout(cs, 5);
+      if(cs < 0 || !read_all(cs, &h2, sizeof(h2)) || h2.magic != MESH_MAGIC || h2.nonce != nonce || h2.nranks != nranks || h2.rank <= rank || h2.rank >= nranks || m->fd[h2.rank] >= 0) { if(cs >= 0) close(cs); continue; }
+      set_rcv_timeout(cs, 0);
       tune(cs);
       m->fd[h2.rank] = cs;
       need--;

@@ -39,6 +39,8 @@ typedef double4 real4;
 #define FCLK_SLOTS 256            // launches of a run whose device-clock stamps are kept (the rest of a longer run is not stamped)
 #define FCLK_TAIL 2048            // last-dispatched workgroups of a launch that store their end time (a slot of its own each: no same-address atomics)
 #define FCLK_STRIDE (FCLK_TAIL + 8)
+// record of the k-th stamped launch of a run: the first FCLK_SLOTS / 2 launches keep theirs, later ones share a ring of FCLK_SLOTS / 2 (the run's last launches survive)
+static inline int fclk_slot(long long k) { return k < FCLK_SLOTS / 2 ? (int)k : FCLK_SLOTS / 2 + (int)((k - FCLK_SLOTS / 2) % (FCLK_SLOTS / 2)); }
 
 // profiling-only phase switches of the tile kernels / the tile build ("ablate": results invalid). The shipped library is built
 // WITHOUT -DMMD_PROFILE: every switch folds to 0 at compile time and mmd_set_option("ablate") is refused; tools/build_variant.sh
@@ -249,6 +251,10 @@ struct mmd_handle {
   // transfer can pay for it — in RCCL loop-back on one GPU it does not)
   int opt_overlap = -1;
   int overlap_choice = -1;           // -1 not decided yet, 0 / 1
+  // RCCL bring-up self-check (mmd_comm_init_rccl): distinct partners exchanged with, seconds it took, PCI bus id of this rank's device
+  int rccl_check_partners = 0;
+  double rccl_check_s = 0;
+  char pci[32] = "?";
   // LJ full lists, overlapped step: 1 = the boundary tiles are launched on the COMMUNICATION stream right behind the transfer (they run under the tail of the
   // interior tiles, the compute stream only joins at the end of the step); 0 = on the compute stream behind a wait for the halo (round 4)
   int opt_overlap_join = 1;
@@ -353,6 +359,7 @@ struct mmd_handle {
   bool fclk_sampled[FCLK_SLOTS] = {false};   // which of the stamped launches also carried an event pair
   double fclk_ms_sampled = 0; int fclk_launches_sampled = 0;
   double fclk_gap_ms = 0; int fclk_gaps = 0;     // idle time between stamped launches that follow each other directly
+  double fclk_first_ms = 0, fclk_median_ms = 0, fclk_last_ms = 0;      // mean span of the run's first <= 100 stamped launches, median of all kept, mean of its last <= 100
   int opt_force_clock = 1;
   bool spec_clk_redo = false;          // the launch behind the build was cancelled: the launch that replaces it takes its clock slot
   long long force_sample_ctr = 0;      // the same, never reset: call number modulo the sampling period decides which launches carry the clock
@@ -392,6 +399,7 @@ struct mmd_handle {
   int* d_flags = nullptr;
   // ---- timers (ref/timer.h:35-40) + GPU events around the force kernel
   double timer[5] = {0, 0, 0, 0, 0};
+  double timer_raw[5] = {0, 0, 0, 0, 0};      // the same before mmd_integrate_run made them partition the wall clock
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   double force_ms = 0, comm_ms = 0;

@@ -121,6 +121,8 @@ def ref_runs(big):
             # BASELINE configs[4] at its real size in DOUBLE precision (16.4 M atoms, half lists; ~5 min on 8 threads): the row the
             # device's DP run of config E is compared with digit for digit (the reference's SP sums are useless at this size)
             ("lj_s160_half_n100", "dp", ["-i", "in.lj.miniMD", "-s", "160", "-n", "100", "--half_neigh", "1", "-t", "8"]),
+            # BASELINE configs[2] weak-scaled over 8 ranks (2x2x2 of -s 64 = 128^3 cells, 8.4 M atoms, 40 steps): the row the 8-rank EAM dress rehearsal is held against
+            ("eam_s128_full_n40", "dp", ["-i", "in.eam.miniMD", "-s", "128", "-n", "40", "--half_neigh", "0", "-t", "8"]),
         ]
         # (ref_runs.json also holds "lj_s144_full_n100", 11.9 M atoms: its rows were taken from a separate 9-minute run of
         #  oracle/_ref/miniMD_ref_dp -i in.lj.miniMD -s 144 -n 100 --half_neigh 0 -t 8 and are kept when this script rewrites the file)

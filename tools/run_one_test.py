@@ -86,7 +86,11 @@ def run_one(exe, nprocs, nt, size, nsteps, neighlist, ghostcomm, inp, quiet=Fals
     argv = [exe, "-t", str(nt), "-s", str(size), "-n", str(nsteps), "--half_neigh", str(neighlist), "-gn", str(ghostcomm), "--yaml_output", "0", "-dm",
             "-i", "in.%s.miniMD" % inp]
     cwd = os.path.join(REPO, "data")
-    launch_vars = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "PMI_RANK", "PMI_SIZE")
+    # every variable csrc/launch.cpp reads (mmd_launch_env, mmd_launch_rendezvous): the np = 1 entries must not inherit somebody's RANK / SLURM_* / PMIX_*
+    launch_vars = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE",
+                   "OMPI_COMM_WORLD_LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_SIZE", "PMI_RANK", "PMI_SIZE", "MPI_LOCALRANKID", "MPI_LOCALNRANKS", "PMIX_RANK", "PMIX_SIZE",
+                   "PMIX_LOCAL_RANK", "PMIX_LOCAL_SIZE", "PMIX_NAMESPACE", "PMI_JOBID", "SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID", "SLURM_NTASKS_PER_NODE",
+                   "SLURM_STEP_ID", "SLURM_STEP_NUM_TASKS", "SLURM_STEP_TASKS_PER_NODE", "SLURM_JOB_ID", "MMD_LAUNCHER", "MMD_NRANKS", "MMD_TRANSPORT")
     base_env = {k: v for k, v in os.environ.items() if k not in launch_vars}
     base_env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if nprocs == 1:
