@@ -93,9 +93,17 @@ def sim(out, args, precision, rccl=False):
     st = s.handle.run_stats()                                    # of Integrate::run (the last mmd_integrate_run of Sim.run)
     for c in ("exchange_fast", "exchange_overflows", "borders_fast", "borders_general", "borders_direct"):
         st[c] = s.handle.counter(c)
+    rows = s.rows()
+    steady = int(os.environ.get("MMD_TEST_STEADY", "0"))
+    if steady > 0:
+        # a further slice behind the run (its plans exist: fixed-size messages sized from the previous re-neighboring): the steady-state cost per re-neighboring
+        s.run_steps(steady)
+        st2 = s.handle.run_stats()
+        st["steady"] = {"steps": steady, "host_syncs": st2["host_syncs"], "bytes_sent": st2["bytes_sent"],
+                        "exchange_overflows": s.handle.counter("exchange_overflows"), "borders_general": s.handle.counter("borders_general")}
     dist.all_gather_object(stats, st)
     if rank == 0:
-        json.dump({"rows": s.rows(), "counts": counts, "natoms": s.natoms(), "stats": stats}, open(out, "w"))
+        json.dump({"rows": rows, "counts": counts, "natoms": s.natoms(), "stats": stats}, open(out, "w"))
     s.close()
 
 
