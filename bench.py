@@ -387,8 +387,11 @@ def main():
     nlocal, nghost, _ = sim.handle.counts()
     # per-rank view of the timed region (max over ranks of every phase, rank 0's own next to it): with these a SCALE line is
     # diagnosable from the record alone — where the time went, how often the host stalled the GPU, how many bytes the halos moved
-    mine = {"phases_s": {k: tm[k] for k in ("total", "comm", "force", "neigh", "extra")}, "host_syncs": rs["host_syncs"],
-            "transport_syncs": rs["transport_syncs"], "bytes_sent": rs["bytes_sent"], "nlocal": nlocal, "nghost": nghost}
+    mine = {"rank": rank, "phases_s": {k: tm[k] for k in ("total", "comm", "force", "neigh", "extra")}, "host_syncs": rs["host_syncs"],
+            "transport_syncs": rs["transport_syncs"], "bytes_sent": rs["bytes_sent"], "nlocal": nlocal, "nghost": nghost,
+            # since the handle was created: fall-backs of the fixed-size message paths, the overlap trial's verdict, the RCCL bring-up check (tools/rehearsal_report.py)
+            "counters": {c: sim.handle.counter(c) for c in ("exchange_fast", "exchange_overflows", "borders_direct", "borders_general", "overlap_choice", "overlap_trial_off_ns",
+                                                           "overlap_trial_on_ns", "rccl_check_partners", "rccl_check_us", "halo_in_x_steps")}}
     per_rank = [mine]
     if dist is not None:
         per_rank = [None] * world
@@ -491,6 +494,8 @@ def main():
                                 "max_rank": max(r["bytes_sent"] for r in per_rank) / max(args.steps, 1)},
         "atoms_per_rank": {"owned_min": min(r["nlocal"] for r in per_rank), "owned_max": max(r["nlocal"] for r in per_rank),
                            "ghost_max": max(r["nghost"] for r in per_rank)},
+        # every rank's own view of the timed window (multi-rank runs: tools/rehearsal_report.py holds it against DESIGN.md §5.5's expectations line by line)
+        "per_rank": per_rank if world > 1 else None,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -3,7 +3,8 @@
 # The multi-GPU evidence of BASELINE.json configs[3] (in.lj.miniMD -s 80 per rank, weak-scaled over the GPUs of one node, RCCL halos over xGMI) in ONE call on
 # whatever box it is given:
 #   1. bench.py --gpus N for every N of the list (N > visible GPUs: the ranks share GPUs over the debug transport and the line says "valid": false) ->
-#      gpurun_out/rehearsal/bench_nN.json + one summary line each: value, phases_s_max, host_syncs_per_rebuild, halo_bytes_per_step, transport, valid;
+#      gpurun_out/rehearsal/bench_nN.json + tools/rehearsal_report.py: per rank, DESIGN.md §5.5's expectation next to the observed value, PASS / LOOK per line;
+#      then the driver's own `bench.py --gpus 8 --steps 20 --warmup 5` and config D through the drop-in executable (8 plain ranks, 2x2x2, -s 80 per rank);
 #   2. the RCCL parity tests that wait for two visible GPUs (tests/test_gpu_more.py -k rccl_two_gpus; skipped, and reported as skipped, on one GPU);
 #   3. a kernel trace of a 2-rank run of the drop-in executable (one rocprofv3 per rank) -> per rank the kernels of a few plain steps and of one
 #      re-neighboring window (tools/rocpd_steps.py, tools/rocpd_timeline.py) in gpurun_out/rehearsal/timeline_rank*.txt.
@@ -19,17 +20,23 @@ for N in $LIST; do
   extra="--no-cold --no-loopback"; [ $N -gt 1 ] && extra="$extra --no-cpu-baseline"
   timeout -k 5 900 python bench.py --gpus $N --size $S --steps 100 --warmup 20 $extra > $O/bench_n$N.json 2> $O/bench_n$N.err
   rc=$?
-  python - $O/bench_n$N.json $N $rc <<'PY' | tee -a $O/summary.txt
-import json, sys
-try:
-    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
-    print("N=%s value %.1f Matom-steps/s  %.4f ms/step  valid %s  transport %s  phases_s_max %s  host_syncs_per_rebuild %.1f  halo B/step max rank %.0f  atoms/rank %s%s" % (
-        d["n_gpus"], d["value"], d["ms_per_step"], d["valid"], d["config"]["transport"], {k: round(v, 5) for k, v in d["phases_s_max"].items()}, d["host_syncs_per_rebuild"],
-        d["halo_bytes_per_step"]["max_rank"], d["atoms_per_rank"], ("  REASON: " + d["reason"]) if d.get("reason") else ""))
-except Exception as e:
-    print("N=%s FAILED (exit status %s): %r" % (sys.argv[2], sys.argv[3], e))
-PY
+  [ $rc -ne 0 ] && echo "N=$N: bench.py exit status $rc: $(tail -2 $O/bench_n$N.err | cut -c1-300)" | tee -a $O/summary.txt
+  # every rank's observed values next to DESIGN.md §5.5's expectations, PASS / LOOK per line
+  python tools/rehearsal_report.py $O/bench_n$N.json | tee -a $O/summary.txt
 done
+echo "--- the driver's own scaling command (python3 bench.py --gpus 8 --steps 20 --warmup 5)" | tee -a $O/summary.txt
+timeout -k 5 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 > $O/bench_driver_n8.json 2> $O/bench_driver_n8.err
+echo "exit status $?, $(grep -c '^{' $O/bench_driver_n8.json) JSON line(s): $(python -c "import json,sys; d=json.loads([l for l in open('$O/bench_driver_n8.json') if l.startswith('{')][-1]); print('value %.1f  valid %s  transport %s x %d  %s' % (d['value'], d['valid'], d['config']['transport'], d['config']['transport_ranks'], d.get('reason') or ''))" 2>&1 | cut -c1-400)" | tee -a $O/summary.txt
+echo "--- config D through the drop-in executable: 8 plain ranks, 2x2x2, -s $S per rank, the deck's 100 steps (PERF_SUMMARY + last thermo row; reference row at -s 80 per rank: 100 6.918446e-01 -5.655620e+00 7.666032e-01)" | tee -a $O/summary.txt
+EXE=$PWD/minimd_amd/bin/miniMD_dp
+PORT=$((25000 + RANDOM % 2000))
+for r in 0 1 2 3 4 5 6 7; do
+  (cd data && OMPI_COMM_WORLD_RANK=$r OMPI_COMM_WORLD_SIZE=8 OMPI_COMM_WORLD_LOCAL_RANK=$r MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT \
+     timeout -k 5 900 $EXE -i in.lj.miniMD -nx $((2 * S)) -ny $((2 * S)) -nz $((2 * S)) --half_neigh 0 > $OLDPWD/$O/exe8_rank$r.log 2>&1) &
+done
+wait
+grep -h "Transport\|MPI processes\|PERF_SUMMARY\|^100 " $O/exe8_rank0.log | grep -v "^#.*MPI_proc" | tee -a $O/summary.txt
+for r in 1 2 3 4 5 6 7; do grep -h "ERROR\|FAILED" $O/exe8_rank$r.log | sed "s/^/rank $r: /" | tee -a $O/summary.txt; done
 echo "--- RCCL parity between two devices" | tee -a $O/summary.txt
 timeout -k 5 1200 python -m pytest tests/test_gpu_more.py -m gpu -q -k "rccl_two_gpus" -rs 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" | tail -6 | tee -a $O/summary.txt
 echo "--- kernel trace of a 2-rank run of the drop-in executable (one rocprofv3 per rank, plain processes started the way mpirun starts them)" | tee -a $O/summary.txt
