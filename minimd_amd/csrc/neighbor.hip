@@ -1029,7 +1029,7 @@ __device__ __forceinline__ double nb2_readlane(double v, int l)
 __device__ __forceinline__ float nb2_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 template <int MODE, int CORE>
-__global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, const int* __restrict__ binned,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_build_rows(const real4* __restrict__ x, const int* __restrict__ binned,
                                                    const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
                                                    BinGeom g, int ntiles, int nlocal, int nall, real cutneigh, real cutneighsq, int maxneighs, int cstride,
                                                    const int* __restrict__ tile_block, const int* __restrict__ tile_first,
@@ -1045,7 +1045,9 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
   nall = deferred_count(nall, nlocal, nghost_dev);
   const bool cand_src_wanted = cand_src != nullptr;
-  __shared__ int rng_start[NB_MAX_ROWS], rng_len[NB_MAX_ROWS];
+  // chunk table of phase 1 (round 6): the candidate slices cut into 64-entry pieces, {first index into binned[], entries} of up to 64 pieces at a time
+  __shared__ __align__(16) int s_cstart[64], s_clen[64];
+  static_assert(NB_MAX_ROWS <= 64, "one lane per slice");
   // candidate buffer: x | y | z (floats; PF: relative to the tile's corner) | atom index as bit pattern. Once the last
   // buffer has been tested the same 7 KB hold the lanes' hit-word lists for the lock-step expansion (s_ew).
   constexpr bool DOTK = NB2_DOTF(MODE);
@@ -1078,22 +1080,21 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // a coordinate is far inside the margin of reach_x)
   const unsigned kx = float_key((float)pme.x);
   const float bx0 = key_float(wave_min_u(owned ? kx : 0xffffffffu)), bx1 = key_float(wave_max_u(owned ? kx : 0u));
+  int sl_start = 0, sl_len = 0;              // lane r: slice r of the candidate pencils (lanes >= nr: empty)
   {
     const real xlo = (real)bx0, xhi = (real)bx1;
     const real reach_x = cutneigh * (real)1.0005 + (real)1.0e-4 * g.binsize[0] + (real)1.0e-5 * (fabs((real)bx0) + fabs((real)bx1));
     const int fmaxx = 2 * NB_XF * g.nblk[0] - 1;
     const int f0 = min(max(fine_x_of(g, xlo - reach_x), 0), fmaxx), f1 = min(max(fine_x_of(g, xhi + reach_x), 0), fmaxx);
-    for(int r0 = 0; r0 < nr; r0 += 64) {
-      const int r = r0 + lane;
-      int len = 0, start = 0;
+    {
+      const int r = lane;
       if(r < nr) {
         const int z = bz + r / ny - g.reach[2], y = by + r % ny - g.reach[1];
         if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1] && own_mask != 0ull) {
           const int row = (z * g.nblk[1] + y) * g.nblk[0] * NB_SUB;          // first bin of that pencil; slice f starts at bin row + 4 f
-          start = bin_start[row + 4 * f0];
-          len = bin_start[row + 4 * f1 + 4] - start;
+          sl_start = bin_start[row + 4 * f0];
+          sl_len = bin_start[row + 4 * f1 + 4] - sl_start;
         }
-        rng_start[r] = start; rng_len[r] = len;
       }
     }
   }
@@ -1205,9 +1206,11 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   int gcount = 0;                          // groups tested so far
   int cnt = 0;                             // my non-empty hit words so far
   constexpr bool REGP = NB2_REGPARK && !CORE;
-  unsigned pw[NB2_NE];                     // REGP: my hit word of every group
-#pragma unroll
-  for(int i = 0; i < NB2_NE; i++) pw[i] = 0u;
+  // REGP: my hit word of every group, in ONE register tuple written through the wave-uniform group number (s_set_gpr_idx + v_mov: round 6 — the switch over
+  // 28 named registers it replaces compiled to a tree of scalar compares that copied half the tuple around per group: ~30 SALU + ~25 VALU instructions a group)
+  typedef unsigned nb2_pwv __attribute__((ext_vector_type(32)));
+  static_assert(NB2_NE <= 32, "one register per group");
+  nb2_pwv pw = {};
   // scratch of this tile: NB2_NG x 64 words; CORE: a second list of the same shape
   constexpr int WSTRIDE = NB2_NG * 64 * (CORE ? 2 : 1);
   unsigned* __restrict__ ent_w = tile_words + (size_t)tile * WSTRIDE + lane;
@@ -1224,6 +1227,18 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
   // ---- phase 2 + expansion over the buffered candidates
   auto flush = [&]() {
     const int fill8 = MFK ? (fill + 31) & ~31 : (fill + 7) & ~7;      // (MFK: whole groups of 32)
+    if constexpr(MFK) {
+      // pass 2 of the cull: {l, index} of the kept candidates -> the MFMA operand record {m_hi.xy | m_hi.z bb_hi | m_lo.xy | m_lo.z bb_lo} (m = -2 l, bb = |l|^2) in place,
+      // the index into its own array (entries past `fill` of the last trip convert whatever the buffer held: nobody reads them, the padding below overwrites its share)
+      for(int p = lane; p < fill; p += 64) {
+        const float4 r = ((const float4*)s_buf)[p];
+        const float mx = -2.0f * r.x, my = -2.0f * r.y, mz = -2.0f * r.z, bb = __builtin_fmaf(r.z, r.z, __builtin_fmaf(r.y, r.y, r.x * r.x));
+        const unsigned h0 = nb2_pack_h2(mx, my), h1 = nb2_pack_h2(mz, bb);
+        const nb2_f2 b0 = nb2_unpack_h2(h0), b1 = nb2_unpack_h2(h1);
+        ((uint4*)s_buf)[p] = uint4{h0, h1, nb2_pack_h2(mx - b0.x, my - b0.y), nb2_pack_h2(mz - b1.x, bb - b1.y)};
+        s_buf[NB2_IDX + p] = r.w;
+      }
+    }
     if(lane < fill8 - fill) {
       if(MFK) {                       // m = 0, |b|^2 = 60000: d > 0 against every atom
         ((uint4*)s_buf)[fill + lane] = uint4{0u, (unsigned)__builtin_bit_cast(unsigned short, (_Float16)60000.0f) << 16, 0u, 0u};
@@ -1484,14 +1499,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
           bits = bits_c;                                         // (n counts the core part below)
         } else
         if(REGP) {
-#define NB2_PW(i) case i: pw[i] = bits; break;
-          switch(gcount) {
-            NB2_PW(0) NB2_PW(1) NB2_PW(2) NB2_PW(3) NB2_PW(4) NB2_PW(5) NB2_PW(6) NB2_PW(7) NB2_PW(8) NB2_PW(9) NB2_PW(10) NB2_PW(11) NB2_PW(12) NB2_PW(13)
-            NB2_PW(14) NB2_PW(15) NB2_PW(16) NB2_PW(17) NB2_PW(18) NB2_PW(19) NB2_PW(20) NB2_PW(21) NB2_PW(22) NB2_PW(23) NB2_PW(24) NB2_PW(25) NB2_PW(26) NB2_PW(27)
-            default: break;
-          }
-#undef NB2_PW
-          static_assert(NB2_NE == 28, "one case per register");
+          pw[min(gcount, 31)] = bits;        // (unconditional: a guarded write makes the compiler copy the tuple and select 32 registers; groups >= NB2_NE raise maxcnt_over, their words are never read)
         } else
         if(bits != 0u) { ent_w[(unsigned)cnt * 64u] = bits; gmask |= 1ull << gcount; cnt++; }
         if(lane == 0) s_gSU[gcount] = uint2{(unsigned)S, used};
@@ -1507,26 +1515,39 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
 
   // ---- phase 1: stream the candidates, slice by slice (a slice = one contiguous run of binned[]: no per-element address
   // search; chunks are the 64-entry pieces of the slices, the last piece of a slice is partly empty)
-  int r = -1, off = 0, len_r = 0, start_r = 0;          // wave-uniform cursor over the slices
-  const int nr_eff = (ablate & 8) ? 0 : nr;
-  for(;;) {
+  // Round 6: no scalar cursor over the slices (it cost ~10 scalar instructions per piece and ~25 at every slice boundary): every slice knows how many 64-entry
+  // pieces it has, a prefix sum places them, and a window of 64 pieces at a time sits in LDS as {start, entries}; a batch reads its four descriptors with two
+  // broadcast ds_read_b128 and every lane forms its own address.
+  static_assert(NB2_BATCH == 4, "a batch reads its descriptors as two int4");
+  const int sl_pieces = (sl_len + 63) >> 6;
+  const int sl_first = wave_incl_scan(sl_pieces) - sl_pieces;
+  const int npieces = (ablate & 8) ? 0 : __builtin_amdgcn_readlane(sl_first + sl_pieces, 63);
+  // MFK: half extents of the owned atoms' box about the local origin (its centre up to float rounding)
+  const float hx = fmaxf(bx1 - (float)ox, (float)ox - bx0) * 1.000001f + 1.0e-30f, hy = fmaxf(by1 - (float)oy, (float)oy - by0) * 1.000001f + 1.0e-30f,
+              hz = fmaxf(bz1 - (float)oz, (float)oz - bz0) * 1.000001f + 1.0e-30f;
+  for(int pbase = 0; pbase < npieces; pbase += 64) {
+    __syncthreads();
+    s_clen[lane] = 0;
+    __syncthreads();
+    for(int k = 0; k < sl_pieces; k++) {
+      const unsigned c = (unsigned)(sl_first + k - pbase);
+      if(c < 64u) { s_cstart[c] = sl_start + 64 * k; s_clen[c] = min(64, sl_len - 64 * k); }
+    }
+    __syncthreads();
+    const int nwin = min(64, npieces - pbase);
+  for(int pc = 0; pc < nwin; pc += NB2_BATCH) {
     int jj[NB2_BATCH], aa[NB2_BATCH];
-    bool more = false;
+    {
+      const int4 st = *(const int4*)&s_cstart[pc], ln = *(const int4*)&s_clen[pc];
+      const int st4[4] = {st.x, st.y, st.z, st.w}, ln4[4] = {ln.x, ln.y, ln.z, ln.w};
 #pragma unroll
-    for(int u = 0; u < NB2_BATCH; u++) {
-      while(r < nr_eff && off >= len_r) {               // next non-empty slice (scalar unit)
-        r++; off = 0;
-        if(r < nr_eff) { len_r = __builtin_amdgcn_readfirstlane(rng_len[r]); start_r = __builtin_amdgcn_readfirstlane(rng_start[r]); }
-        else len_r = 0;
-      }
-      jj[u] = -1; aa[u] = -1;
-      if(r < nr_eff) {
-        more = true;
-        if(off + lane < len_r) { aa[u] = start_r + off + lane; jj[u] = binned[aa[u]]; }
-        off += 64;
+      for(int u = 0; u < NB2_BATCH; u++) {
+        const bool ok = lane < ln4[u];
+        const int a = st4[u] + lane;
+        const int jv = binned[ok ? a : 0];
+        aa[u] = ok ? a : -1; jj[u] = ok ? jv : -1;
       }
     }
-    if(!more) break;
     real4 pp[NB2_BATCH];
 #pragma unroll
     for(int u = 0; u < NB2_BATCH; u++) pp[u] = x[jj[u] >= 0 ? jj[u] : 0];
@@ -1535,28 +1556,35 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       const int j = jj[u];
       bool keep = j >= 0 && !(ablate & 16);
       const int cjv = j;
-      const float fx = (float)pp[u].x, fy = (float)pp[u].y, fz = (float)pp[u].z;
-      const float ddx = fmaxf(fmaxf(bx0 - fx, fx - bx1), 0.0f);
-      const float ddy = fmaxf(fmaxf(by0 - fy, fy - by1), 0.0f);
-      const float ddz = fmaxf(fmaxf(bz0 - fz, fz - bz1), 0.0f);
-      keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
-      if(MODE != 0) keep = keep && (fz >= zcull || (MODE == 1 && j >= nlocal));
+      float lx = 0, ly = 0, lz = 0;
+      if constexpr(MFK) {
+        // coordinates about the tile's centre serve the cull AND (pass 2, in flush) the candidate's record: distance to the box = |l| - half extent per dimension
+        lx = (float)(pp[u].x - ox); ly = (float)(pp[u].y - oy); lz = (float)(pp[u].z - oz);
+        const float ddx = fmaxf(fabsf(lx) - hx, 0.0f), ddy = fmaxf(fabsf(ly) - hy, 0.0f), ddz = fmaxf(fabsf(lz) - hz, 0.0f);
+        keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
+      } else {
+        const float fx = (float)pp[u].x, fy = (float)pp[u].y, fz = (float)pp[u].z;
+        const float ddx = fmaxf(fmaxf(bx0 - fx, fx - bx1), 0.0f);
+        const float ddy = fmaxf(fmaxf(by0 - fy, fy - by1), 0.0f);
+        const float ddz = fmaxf(fmaxf(bz0 - fz, fz - bz1), 0.0f);
+        keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
+        if(MODE != 0) keep = keep && (fz >= zcull || (MODE == 1 && j >= nlocal));
+      }
       const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
       if(m) {
         const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if(keep) {
-          const float lx = (float)(pp[u].x - ox), ly = (float)(pp[u].y - oy), lz = (float)(pp[u].z - oz);
-          if(MFK) {
-            const float mx = -2.0f * lx, my = -2.0f * ly, mz = -2.0f * lz, bb = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
-            const unsigned h0 = nb2_pack_h2(mx, my), h1 = nb2_pack_h2(mz, bb);
-            const nb2_f2 b0 = nb2_unpack_h2(h0), b1 = nb2_unpack_h2(h1);
-            ((uint4*)s_buf)[pos] = uint4{h0, h1, nb2_pack_h2(mx - b0.x, my - b0.y), nb2_pack_h2(mz - b1.x, bb - b1.y)};
-          } else
+          if constexpr(MFK) {
+            // pass 1 parks {l, index}; the f16 hi / lo record is made from it in flush(), 64 KEPT candidates per trip instead of 64 streamed ones
+            ((float4*)s_buf)[pos] = float4{lx, ly, lz, __int_as_float(cjv)};
+          } else {
+          lx = (float)(pp[u].x - ox); ly = (float)(pp[u].y - oy); lz = (float)(pp[u].z - oz);
           if(DOTK) {
             s_buf[pos] = -2.0f * lx; s_buf[NB2_BUF + pos] = -2.0f * ly; s_buf[2 * NB2_BUF + pos] = -2.0f * lz;
             s_buf[3 * NB2_BUF + pos] = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
           } else { s_buf[pos] = lx; s_buf[NB2_BUF + pos] = ly; s_buf[2 * NB2_BUF + pos] = lz; }
           s_buf[NB2_IDX + pos] = __int_as_float(cjv);
+          }
           const unsigned own = (unsigned)(aa[u] - ta);                   // the tile's own atoms are binned[ta .. ta+63]
           if(MODE != 0) s_own[pos] = own < 64u ? (unsigned char)own : (unsigned char)0xff;
           if((MODE == 0 || DOTK) && own < 64u) s_selfpos[own] = (unsigned short)pos;
@@ -1565,6 +1593,7 @@ __global__ __launch_bounds__(64) void k_build_rows(const real4* __restrict__ x, 
       }
     }
     if(fill > NB2_BUF - 64 * NB2_BATCH) flush();        // (one copy of the test code: flushed between batches only)
+  }
   }
   flush();
 
