@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   unsigned* __restrict__ ent2_w = ent_w + NB2_NG * 64;
   int cnt2 = 0, n2 = 0;
   bool any_ghost = false;
-  bool ghost_seen = false;                 // MFK: this lane gave a ghost a slot (any_ghost = one ballot at the end instead of one per group)
+  int ghost_top = -1;                      // MFK: largest atom index this lane gave a slot (any_ghost = one compare + ballot at the end instead of mask arithmetic per group)
 
   // ---- phase 2 + expansion over the buffered candidates
   auto flush = [&]() {
@@ -1478,7 +1478,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           if(slot < cstride - 1) {
             const int cj = __float_as_int(s_buf[NB2_IDX + gq + lane]);
             tile_cand[cbase + slot] = cj;
-            if(MFK) ghost_seen = ghost_seen || cj >= nlocal;
+            if(MFK) ghost_top = max(ghost_top, cj);
             // (one rank: the same list with a ghost named by its owner and image code, for tile kernels that stage ghosts from their owners)
             // (several ranks, ghost_image == nullptr: ghost_root is DirectHalo::gmap — the entry of the position buffer the per-step halo delivers the ghost to)
             if(cand_src != nullptr) cand_src[cbase + slot] = cj >= nlocal && cj < nall ? (ghost_image != nullptr ? (ghost_root[cj - nlocal] | ((ghost_image[cj - nlocal] + 1) << MMD_SRC_BITS)) : ghost_root[cj - nlocal]) : cj;
@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   // 128-byte line of nl16 and the padding comes for free. A lane's words are walked in group order; s_gS / s_gU give the slot
   // base and the union mask of a group.
   // (CORE: n = core entries, n2 = the rest; otherwise n = the row)
-  if(MFK) any_ghost = __builtin_amdgcn_ballot_w64(ghost_seen) != 0ull;
+  if(MFK) any_ghost = __builtin_amdgcn_ballot_w64(ghost_top >= nlocal) != 0ull;
   const int maxn = (int)wave_max_u((unsigned)(n + n2));
   const int kc = min(((int)wave_max_u((unsigned)n) + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD, maxneighs);
   const int kr = CORE ? min(((int)wave_max_u((unsigned)n2) + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD, maxneighs - kc) : 0;
@@ -1650,7 +1650,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // the group of the next entry = the lowest set bit of `groups` (entries were parked in group order)
     if(cn > 0) { w0 = s_ew[lane]; const uint2 su = s_gSU[__builtin_ctzll(groups)]; groups &= groups - 1; b0 = su.x; u0 = su.y; }
     for(int k = 0; k < krows && !(ablate & 1); k++) {
-      if(w0 == 0u && e + 1 < cn) {               // (entries are non-empty: one hop always lands on a set bit)
+      if((int)(w0 == 0u) & (int)(e + 1 < cn)) {  // (entries are non-empty: one hop always lands on a set bit; `&`: ONE exec region, not two nested ones)
         e++;
         w0 = s_ew[e * 64 + lane];
         const uint2 su = s_gSU[__builtin_ctzll(groups)];
@@ -1661,7 +1661,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const int bq = __builtin_ctz(w0 | 0x80000000u);
       w0 &= w0 - 1;
       const unsigned slot = b0 + (unsigned)__popc(u0 >> 1 >> bq);
-      rowp[(unsigned)(kfirst + k) * 64u] = v ? (unsigned short)(slot * NB_SLOT_BYTES) : dummy;
+      // (arithmetic select: the compiler wrapped `v ? slot : dummy` into an exec region of its own, three scalar instructions + a branch per round)
+      const unsigned dm = (unsigned)dummy;
+      rowp[(unsigned)(kfirst + k) * 64u] = (unsigned short)(dm + ((slot * NB_SLOT_BYTES - dm) & (0u - (unsigned)v)));
     }
   };
   expand(ent_w, gmask, cnt, 0, kc);
