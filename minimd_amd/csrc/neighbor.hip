@@ -1255,12 +1255,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // MFK: group and bit of the lane's own candidate record, once per buffer (the atom itself is a hit of its own lane: dropped in its group)
     const int self_g = selfpos >> 5;                                   // (0xffff: group 2047, never reached)
     const unsigned self_keep = ~(1u << nb2_mf_bit(selfpos & 31));
+    // MFK: the candidates' operand record of the NEXT group is read while this one is tested (one LDS round trip less in every group's chain; 4 VGPRs)
+    uint4 rec_next = uint4{0u, 0u, 0u, 0u};
+    if constexpr(MFK) { if(fill8 > 0) rec_next = ((const uint4*)s_buf)[lane & 31]; }
     for(int gq = 0; gq < fill8 && !(ablate & 2); gq += 32) {
       const int G = min(32, fill8 - gq);
       unsigned bits = 0, bits_hi = 0, bits_c = 0;
       if constexpr(MFK) {
         // (issuing a group's MFMAs one group ahead of the reads of their accumulators was built and measured 1.5 % slower: 119 instead of 108 VGPRs)
-        const uint4 rec = ((const uint4*)s_buf)[gq + (lane & 31)];
+        const uint4 rec = rec_next;
+        rec_next = ((const uint4*)s_buf)[min(gq + 32, fill8 - 32) + (lane & 31)];
         uint4 av = rec;
         av.y = (rec.y & mf_my) | (0x3c003c00u & ~mf_my);             // upper half: {m_hi.z, 1.0}
         av.z = (rec.z & mf_mz) | (0x3c003c00u & ~mf_mz);             //             {1.0, .}
@@ -1278,7 +1282,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for(int i = 0; i < 16; i++) w2 = nb2_shift_sign(w2, d2[i]);
 #pragma unroll
         for(int i = 0; i < 16; i += 2) m2 = __builtin_fminf(__builtin_fminf(m2, __builtin_fabsf(d2[i])), __builtin_fabsf(d2[i + 1]));
-        const bool amb = (int)(m1 < mfEA) | (int)(m2 < mfEB);
         const auto rw = __builtin_amdgcn_permlane32_swap(w1, w2, false, false);       // -> the two words of MY atom
         bits = (rw[0] << 16) | rw[1];
         if constexpr(CORE) {
@@ -1292,7 +1295,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const auto rc = __builtin_amdgcn_permlane32_swap(v1, v2, false, false);
           bits_c = (rc[0] << 16) | rc[1];
         }
-        const unsigned long long ambm = __builtin_amdgcn_ballot_w64(amb);
+        const unsigned long long ambm = __builtin_amdgcn_fcmpf(m1, mfEA, 4 /* ordered < */) | __builtin_amdgcn_fcmpf(m2, mfEB, 4);      // (lane masks straight from the compares)
         if(ambm != 0ull) {
           // some accumulator of the group is inside its atom's band: the pairs of that HALF of the group's candidates (the lower 32 lanes hold rows
           // 0-3, 8-11, ... = the upper 16 bits of a word, the upper 32 lanes the rest) with all 64 atoms are decided exactly from the global positions
@@ -1557,11 +1560,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       bool keep = j >= 0 && !(ablate & 16);
       const int cjv = j;
       float lx = 0, ly = 0, lz = 0;
+      unsigned long long mk = 0ull;
       if constexpr(MFK) {
         // coordinates about the tile's centre serve the cull AND (pass 2, in flush) the candidate's record: distance to the box = |l| - half extent per dimension
         lx = (float)(pp[u].x - ox); ly = (float)(pp[u].y - oy); lz = (float)(pp[u].z - oz);
         const float ddx = fmaxf(fabsf(lx) - hx, 0.0f), ddy = fmaxf(fabsf(ly) - hy, 0.0f), ddz = fmaxf(fabsf(lz) - hz, 0.0f);
-        keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
+        const float dd2 = ddx * ddx + ddy * ddy + ddz * ddz;
+        keep = keep && (dd2 <= cull);
+        // (the lane mask straight from the two compares: ballot(bool) of a combined condition compiles to v_cndmask + v_cmp_ne on top of them)
+        mk = __builtin_amdgcn_sicmp(j, -1, 38 /* signed > */) & __builtin_amdgcn_fcmpf(dd2, cull, 5 /* ordered <= */);
+        if(ablate & 16) mk = 0ull;
       } else {
         const float fx = (float)pp[u].x, fy = (float)pp[u].y, fz = (float)pp[u].z;
         const float ddx = fmaxf(fmaxf(bx0 - fx, fx - bx1), 0.0f);
@@ -1570,7 +1578,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         keep = keep && (ddx * ddx + ddy * ddy + ddz * ddz <= cull);
         if(MODE != 0) keep = keep && (fz >= zcull || (MODE == 1 && j >= nlocal));
       }
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+      const unsigned long long m = MFK ? mk : __builtin_amdgcn_ballot_w64(keep);
       if(m) {
         const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if(keep) {
