@@ -119,33 +119,18 @@ extern "C" int mmd_sync(mmd_handle* h)
 extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
 {
   if(!h || !name) { mmd_set_error("mmd_set_option: bad arguments"); return -1; }
-  if(!strcmp(name, "exact_div")) h->opt_exact_div = value;
-  else if(!strcmp(name, "time_force_events")) h->time_force_events = value != 0;
   else if(!strcmp(name, "tiles")) h->opt_tiles = value;
-  else if(!strcmp(name, "build")) h->opt_build = value;
-  else if(!strcmp(name, "upload_tiles")) h->opt_upload_tiles = value;
   else if(!strcmp(name, "eam_mlo")) h->opt_eam_mlo = value;
   else if(!strcmp(name, "ghost_resolve")) h->opt_ghost_resolve = value;
   else if(!strcmp(name, "time_force_sample")) h->opt_time_sample = value;
-  else if(!strcmp(name, "kernel_dummy")) h->opt_kernel_dummy = value;
-  else if(!strcmp(name, "fuse_final")) h->opt_fuse_final = value;
-  else if(!strcmp(name, "bin_reuse")) h->opt_bin_reuse = value;
   else if(!strcmp(name, "fold_reverse")) h->opt_fold_reverse = value;
-  else if(!strcmp(name, "eam_half_rows")) h->opt_eam_half_rows = value;
-  else if(!strcmp(name, "eam_fold_fp")) h->opt_eam_fold_fp = value;
-  else if(!strcmp(name, "async_counts")) h->opt_async_counts = value;
   else if(!strcmp(name, "lj_original")) h->opt_lj_original = value;
   else if(!strcmp(name, "core_pct")) h->opt_core_pct = value;
-  else if(!strcmp(name, "borders_fast")) h->opt_borders_fast = value;
   else if(!strcmp(name, "borders_est")) h->opt_borders_est = value;
-  else if(!strcmp(name, "spin_readback")) h->opt_spin_readback = value;
   else if(!strcmp(name, "spec")) h->opt_spec = value;
-  else if(!strcmp(name, "fold_pencil")) h->opt_fold_pencil = value;
   else if(!strcmp(name, "direct_halo")) h->dh.opt = value;
-  else if(!strcmp(name, "force_clock")) h->opt_force_clock = value;
-  else if(!strcmp(name, "overlap_join")) h->opt_overlap_join = value;
   else if(!strcmp(name, "direct_borders")) h->dh.opt_borders = value;
-  else if(!strcmp(name, "halo_recv")) h->dh.opt_recv = value;
+  else if(!strcmp(name, "halo_recv")) { if(value != 1 && value != 3) { mmd_set_error("mmd_set_option: halo_recv is 1 or 3"); return -1; } h->dh.opt_recv = value; }
   else if(!strcmp(name, "exchange_cap")) h->opt_exchange_cap = value;
   else if(!strcmp(name, "force_transport")) h->opt_force_transport = value;
   else if(!strcmp(name, "ablate")) {
@@ -157,9 +142,6 @@ extern "C" int mmd_set_option(mmd_handle* h, const char* name, int value)
   }
   else if(!strcmp(name, "fuse")) h->opt_fuse = value;
   else if(!strcmp(name, "overlap")) h->opt_overlap = value;
-  else if(!strcmp(name, "tile_waves")) h->opt_tile_waves = value;
-  else if(!strcmp(name, "tile_unroll")) h->opt_tile_unroll = value;
-  else if(!strcmp(name, "tile_read")) h->opt_tile_read = value;
   else if(!strcmp(name, "check_exchange")) h->opt_check_exchange = value;
   else if(!strcmp(name, "safe_exchange")) h->opt_safe_exchange = value;
   else if(!strcmp(name, "maxneighs")) h->maxneighs = (value + MMD_UNROLL - 1) / MMD_UNROLL * MMD_UNROLL;
@@ -262,7 +244,7 @@ static int force_compute_async(mmd_handle* h, int evflag, double* eng, double* v
     h->force_sample_ctr++;
     h->force_calls++;
   }
-  if(timed && h->time_force_events && h->style == 0 && !h->halfneigh && !h->halo_pending && mmd_lj_tiles_available(h)) {
+  if(timed && h->style == 0 && !h->halfneigh && !h->halo_pending && mmd_lj_tiles_available(h)) {
     // LJ over full lists in tile form is ONE launch: the pair is attached to that dispatch instead of bracketing it
     if(h->ev_used == h->ev_pool.size()) {
       EventPair p;
@@ -277,9 +259,9 @@ static int force_compute_async(mmd_handle* h, int evflag, double* eng, double* v
     h->launch_ev_a = h->launch_ev_b = nullptr;
     return r;
   }
-  if(timed && h->time_force_events) MMD_TRY(ev_begin(h));
+  if(timed) MMD_TRY(ev_begin(h));
   int r = h->style == 0 ? mmd_lj_compute(h, evflag, eng, vir) : mmd_eam_compute(h, evflag, eng, vir);
-  if(timed && h->time_force_events) MMD_TRY(ev_end(h));
+  if(timed) MMD_TRY(ev_end(h));
   return r;
 }
 
@@ -307,7 +289,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   h->force_ms_all = 0; h->force_launches_all = 0; h->halo_ms = 0;
   h->run_ntimes = ntimes;
   h->fclk_n = 0; h->fclk_ms = 0; h->fclk_launches = 0; h->fclk_harvested = true;
-  if(h->opt_force_clock && h->clk_rate_hz > 0 && h->style == 0 && !h->halfneigh) {
+  if(h->clk_rate_hz > 0 && h->style == 0 && !h->halfneigh) {
     MMD_TRY(h->fclk.ensure((size_t)FCLK_STRIDE * FCLK_SLOTS, false, h->stream));
     HIP_TRY(hipMemsetAsync(h->fclk.p, 0, (size_t)FCLK_STRIDE * std::min(FCLK_SLOTS, ntimes + 2) * sizeof(unsigned long long), h->stream));
   }
@@ -353,7 +335,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // two markers, ~5 us per step that a -s 32 run would notice
   // one rank, half lists with ghost newton in tile form: a ghost's share of a pair goes straight to its owner
   const bool fold = reverse && h->opt_fold_reverse && h->nprocs == 1 && !h->opt_force_transport && h->opt_fuse && h->style == 0;
-  const bool time_halo = h->time_force_events && (h->nprocs > 1 || h->opt_force_transport || (reverse && !fold));
+  const bool time_halo = (h->nprocs > 1 || h->opt_force_transport || (reverse && !fold));
   int evflag_pending = 0;
   const bool fuse_force = h->opt_fuse >= 2 && !reverse && !h->halfneigh;
   // one rank, LJ over full lists in tile form: no per-step ghost update at all (the tile kernel resolves ghosts itself)
@@ -378,8 +360,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   auto launch_force = [&](int n, int evflag) -> int {
     fused_force = fuse_force && !evflag && n + 1 < ntimes && (h->style == 0 ? mmd_lj_can_fuse_integrate(h) : mmd_eam_can_fuse_integrate(h));
     // the last step of a run (LJ tile kernel): finalIntegrate inside the force launch — no k_final_integrate pass over f and v behind it
-    final_fused = fuse_force && !evflag && n + 1 == ntimes && h->style == 0 && h->opt_fuse_final && mmd_lj_can_fuse_integrate(h);
-    if(fused_force) MMD_TRY(mmd_prepare_x_alt(h, h->opt_kernel_dummy != 0));
+    final_fused = fuse_force && !evflag && n + 1 == ntimes && h->style == 0 && mmd_lj_can_fuse_integrate(h);
+    if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
     h->fuse_now = fused_force ? 1 : (final_fused ? 2 : 0);
     h->resolve_now = h->ghosts_stale;
     h->fold_reverse_now = folded = fold && h->ghost_chain_ok && mmd_lj_half_tiles_available(h);
@@ -396,8 +378,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   // the launch behind the build: LJ over full lists in tile form on one rank, no halo overlap, lists of the previous build to size it from
   // (several ranks: the same, when the step's halo is not overlapped — the ghosts Comm::borders has just made are what this launch reads, the verdict covers the
   //  max-reduced overflow flag of the direct borders; the direct-halo plan is finished behind it, when the words have arrived)
-  const bool spec_static = h->opt_spec > 0 && h->style == 0 && !h->halfneigh && h->opt_spin_readback &&
-                           h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && !h->opt_check_exchange && h->lj_uniform;
+  const bool spec_static = h->opt_spec > 0 && h->style == 0 && !h->halfneigh &&
+                           h->opt_tiles && !h->opt_check_exchange && h->lj_uniform;
   for(int n = 0; n < ntimes; n++) {
     if(overlap_auto && h->overlap_choice < 0) {
       if(trial_phase == 0 && trial_armed) {
@@ -437,10 +419,10 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         if(lj_full) {
           // the interior tiles go onto the compute stream FIRST: enqueuing the halo (an ncclGroup costs the host ~15 us) must not hold them up
           ovf_calls++;
-          ovf_timed_now = h->time_force_events && timed_step;
+          ovf_timed_now = timed_step;
           if(ovf_timed_now) MMD_TRY(ovf_begin(h));
           fused_force = fuse_force && !ev_now && n + 1 < ntimes && mmd_lj_can_fuse_integrate(h);
-          if(fused_force) MMD_TRY(mmd_prepare_x_alt(h, h->opt_kernel_dummy != 0));
+          if(fused_force) MMD_TRY(mmd_prepare_x_alt(h));
           h->fuse_now = fused_force;
           const int rc0 = mmd_lj_compute_tiles_split(h, ev_now, 0);
           h->fuse_now = 0;
@@ -451,7 +433,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
         // (round 5) the boundary tiles go onto the communication stream, right behind the transfer: they start the moment the ghosts are there, under the tail of the
         // interior tiles, and read the received records where they landed (halo_recv 3: no unpack kernel either); the compute stream joins at the end of the step.
         // A thermo step keeps the round-4 form (its energy sum needs both launches finished).
-        joined = lj_full && h->opt_overlap_join && !ev_now;
+        joined = lj_full && !ev_now;
         if(joined) h->halo_in_x_allow = h->opt_fuse && h->opt_ghost_resolve;
         if(rc >= 0) rc = mmd_comm_communicate(h);
         h->halo_in_x_allow = false;
@@ -511,13 +493,13 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       // phase clocks: one rank with Atom::sort in the window and the production build — the first kernel of each phase (k_bin_count of the sort,
       // k_bin_count of the build) and k_tile_reduce stamp the device's wall clock into the build's result words; otherwise event pairs on the stream
       // (each record costs the stream a marker packet, ~5 us of idle GPU)
-      const bool dev_clock = h->clk_rate_hz > 0 && h->opt_spin_readback && h->nprocs == 1 && !h->opt_force_transport && sort_now && h->opt_async_counts &&
-                             h->nlocal > 0 && h->neigh_ready && h->opt_tiles && h->opt_build == 1 && h->tiles_ready && !h->opt_check_exchange;
+      const bool dev_clock = h->clk_rate_hz > 0 && h->nprocs == 1 && !h->opt_force_transport && sort_now &&
+                             h->nlocal > 0 && h->neigh_ready && h->opt_tiles && h->tiles_ready && !h->opt_check_exchange;
       h->clk_written = 0;
       h->clk_slot = dev_clock ? 0 : -1;
       int rc = dev_clock ? 0 : ev_begin(h, 2);
       // one rank: Comm::exchange is Atom::pbc alone; when Atom::sort follows, its binning pass wraps the atoms on the way
-      h->pbc_defer = sort_now && h->nprocs == 1 && h->opt_async_counts && h->nlocal > 0 && h->neigh_ready;
+      h->pbc_defer = sort_now && h->nprocs == 1 && h->nlocal > 0 && h->neigh_ready;
       if(rc >= 0) rc = mmd_comm_exchange(h);
       h->pbc_defer = false;
       if(rc >= 0 && sort_now) { rc = mmd_atom_sort(h); h->next_sort += h->sort_every; }

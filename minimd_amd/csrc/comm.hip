@@ -858,7 +858,7 @@ static int reduce_flag_max(mmd_handle* h, int* dflag)
 static int exchange_multi_fast(mmd_handle* h, int* resume_dim)
 {
   *resume_dim = 0;
-  if(h->nprocs == 1 || h->opt_safe_exchange || !h->opt_async_counts || !h->ex_prev_valid || !(h->rccl || h->host_sr)) return 0;
+  if(h->nprocs == 1 || h->opt_safe_exchange || !h->ex_prev_valid || !(h->rccl || h->host_sr)) return 0;
   int cap_s[3] = {0, 0, 0}, cap_r[3][2] = {{0, 0}, {0, 0}, {0, 0}};
   int arrivals_max = 0;
   for(int d = 0; d < 3; d++) {
@@ -1817,7 +1817,7 @@ int mmd_dh_exchange(mmd_handle* h, int what)
   if(in_x) h->halo_in_x_steps++;
   const int nsend_remote = D.peer_soff[D.npeer_s];
   MMD_TRY(h->buf_send.ensure(per * (size_t)nsend_remote + 16, false, h->stream));
-  if(!(D.opt_recv == 2 && h->rccl) && !in_x) MMD_TRY(h->buf_recv.ensure(per * (size_t)D.total_recv + 16, false, h->stream));
+  if(!in_x) MMD_TRY(h->buf_recv.ensure(per * (size_t)D.total_recv + 16, false, h->stream));
   if(D.total_send) {
     if(what == 0) hipLaunchKernelGGL(k_dh_pack_x, dim3(div_up(D.total_send, 256)), dim3(256), 0, h->stream, h->x.p, D.idx.p, D.total_send, M, (real4*)h->buf_send.p, h->nlocal);
     else hipLaunchKernelGGL(k_dh_pack_f, dim3(div_up(D.total_send, 256)), dim3(256), 0, h->stream, h->fp.p, D.idx.p, D.total_send, M, h->buf_send.p, h->nlocal);
@@ -1825,20 +1825,6 @@ int mmd_dh_exchange(mmd_handle* h, int what)
   }
   unsigned char* sbuf = (unsigned char*)h->buf_send.p;
   unsigned char* rbuf = in_x ? (unsigned char*)(h->x.p + D.R) : (unsigned char*)h->buf_recv.p;
-  // halo_recv 2: every list is a message of its own, received straight into the slots of its ghosts (no receive buffer, no k_dh_unpack: one dependent launch
-  // less per step; SURVEY K12 "unpack can be elided") — up to 26 sends + 26 receives in the group instead of one pair per distinct partner. Messages
-  // between the same two ranks are matched in issue order: ascending list number on both sides (target_l(A) = B <=> source_l(B) = A, same lengths).
-  const bool recv_direct = D.opt_recv == 2 && h->rccl != nullptr;
-  if(recv_direct) {
-    h->halo_bytes += (long long)((size_t)nsend_remote * esz);
-    ncclComm_t c = (ncclComm_t)h->rccl;
-    unsigned char* gdst = what == 0 ? (unsigned char*)(h->x.p + h->nlocal) : (unsigned char*)(h->fp.p + h->nlocal);
-    NCCL_TRY(ncclGroupStart());
-    for(int l = 0; l < 26; l++) if(D.lps[l] >= 0 && D.ns[l]) NCCL_TRY(ncclSend(sbuf + (size_t)D.sdst[l] * esz, (size_t)D.ns[l] * esz, ncclChar, D.target[l], c, h->stream));
-    for(int l = 0; l < 26; l++) if(D.lpr[l] >= 0 && D.nr[l]) NCCL_TRY(ncclRecv(gdst + (size_t)D.rbase[l] * esz, (size_t)D.nr[l] * esz, ncclChar, D.source[l], c, h->stream));
-    NCCL_TRY(ncclGroupEnd());
-    return 0;
-  }
   if(h->rccl) {
     h->halo_bytes += (long long)((size_t)nsend_remote * esz);
     ncclComm_t c = (ncclComm_t)h->rccl;
@@ -2039,7 +2025,7 @@ int mmd_comm_sendlists_ensure(mmd_handle* h)
 static int borders_direct(mmd_handle* h, bool defer)
 {
   DirectHalo& D = h->dh;
-  if(!D.opt_borders || !D.prev_valid || !dh_applies(h) || !h->borders_general_done || !h->opt_async_counts) return 0;
+  if(!D.opt_borders || !D.prev_valid || !dh_applies(h) || !h->borders_general_done) return 0;
   const bool forced = h->opt_force_transport != 0;
   const int nlocal = h->nlocal;
   dh_topology(h);
@@ -2069,7 +2055,7 @@ static int borders_direct(mmd_handle* h, bool defer)
   if(cap_send_total > 0x3fffffff || cap_recv_total > 0x3fffffff) return 0;
   const int est_ghost = (int)cap_recv_total;
   // halo_recv 3: the per-step halo of the partners lands behind the ghost slots of the position buffer (DirectHalo::gmap)
-  const bool want_gmap = D.opt_recv == 3 && h->style == 0 && !h->halfneigh && h->opt_tiles && h->opt_build == 1 && h->lj_uniform && h->opt_ghost_resolve &&
+  const bool want_gmap = D.opt_recv == 3 && h->style == 0 && !h->halfneigh && h->opt_tiles && h->lj_uniform && h->opt_ghost_resolve &&
                          (long long)nlocal + 2 * (long long)est_ghost + 16 < (1 << MMD_SRC_BITS);
   const int R = want_gmap ? ((nlocal + est_ghost + 1 + 3) & ~3) : 0;
   MMD_TRY(mmd_ensure_atoms(h, want_gmap ? R + est_ghost + 1 : nlocal + est_ghost + 1, true));
@@ -2166,7 +2152,7 @@ static int borders_fast_finish(mmd_handle* h);
 
 static int borders_device_resident(mmd_handle* h, bool defer)
 {
-  if(!h->opt_borders_fast || h->swaps.size() != 6) return 0;
+  if(h->swaps.size() != 6) return 0;
   // several ranks: every condition below is the same on all of them (options, topology, "a swap-by-swap borders has run before") — a
   // rank that owned no boundary atom or got no ghost last time (prev_nb, prev_nghost = 0: empty or sparse sub-domain) must still post the
   // fixed-size messages its partners wait for; its arrays get the +4096 floor of the estimates
@@ -2181,7 +2167,6 @@ static int borders_device_resident(mmd_handle* h, bool defer)
     any_remote = any_remote || r0;
   }
   if(any_remote && !(h->rccl || h->host_sr)) return 0;
-  if(any_remote && !h->opt_async_counts) return 0;
   const int nlocal = h->nlocal;
   // (opt_borders_est: per cent of the previous counts the arrays are sized for; tests shrink it to force the overflow fallback)
   const int est_ghost = h->opt_borders_est >= 100 ? (int)((long long)h->prev_nghost * h->opt_borders_est / 100) + 4096 : (int)((long long)h->prev_nghost * h->opt_borders_est / 100);
@@ -2202,7 +2187,7 @@ static int borders_device_resident(mmd_handle* h, bool defer)
   const int nt_own = div_up(nlocal, CP_TILE), nt_sw = div_up(est_nb + est_ghost, CP_TILE);
   MMD_TRY(h->flag_tmp.ensure((size_t)std::max(nt_own, 2 * nt_sw) + 8, false, h->stream));
   MMD_TRY(h->bstate.ensure(64, false, h->stream));
-  bool fused = !any_remote && h->opt_borders_fast >= 2;
+  bool fused = !any_remote;
   for(int q = 0; q < 6 && fused; q++) fused = h->swaps[q].dim == q / 2;
   if(fused) {
     // every swap a periodic self swap: count / scan / scatter over the 26 image lists (above)
@@ -2292,7 +2277,7 @@ static int borders_device_resident(mmd_handle* h, bool defer)
     // the ghost count from bst (deferred_count), the build's own read-back brings bst along (mmd_borders_deferred_finish)
     h->nghost = cap_ghost_eff;                                   // (a bound, for array sizes and grids only)
     h->nghost_dev = h->bstate.p + BST_GHOSTS + 6;
-    // (the dummy atom behind the last ghost is written by k_tile_fill of the neighbor build that follows)
+    // (the dummy atom behind the last ghost is written by k_pencil_fill of the neighbor build that follows)
     for(int k = 0; k < 2; k++) if(h->xalt_dummy_ptr[k] == (const void*)h->x.p) h->xalt_dummy_slot[k] = -1;
     return 2;
   }
@@ -2361,7 +2346,7 @@ int mmd_run_reserve(mmd_handle* h)
   MMD_TRY(h->atom_bin.ensure(need, false, h->stream));
   MMD_TRY(h->atom_rank.ensure(need, false, h->stream));
   MMD_TRY(h->binned.ensure(need, true, h->stream));        // (live: the tiles of the current lists name their atoms through it)
-  if(h->neigh_ready && h->opt_bin_reuse) MMD_TRY(h->bin_start_alt.ensure((size_t)h->bg.mbins + 8, false, h->stream));
+  if(h->neigh_ready) MMD_TRY(h->bin_start_alt.ensure((size_t)h->bg.mbins + 8, false, h->stream));
   if(h->neigh_ready) MMD_TRY(h->pencil_lohi.ensure((size_t)2 * h->bg.nblk[1] * h->bg.nblk[2] + 2, false, h->stream));
   return 0;
 }
@@ -2375,7 +2360,7 @@ extern "C" int mmd_comm_borders(mmd_handle* h)
   h->nghost_dev = nullptr;
   h->dh.ready = false; h->dh.pending = false;
   {
-    const bool defer = h->in_reneighbor && h->opt_async_counts && h->opt_tiles && h->opt_build == 1 && h->neigh_ready;
+    const bool defer = h->in_reneighbor && h->opt_tiles && h->neigh_ready;
     h->borders_direct_pending = false;
     h->sendlists_stale = false;
     h->dh.gmap_live = false; h->dh.x_unpack_pending = false;

@@ -1002,7 +1002,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   }
   MMD_TRY(h->fp.ensure((size_t)nall + 64, false, h->stream));
   h->fp_ghosts_stale = false;
-  if(eam_half_tiles_available(h) && !h->opt_eam_half_rows) {
+  if(eam_half_tiles_available(h)) {
     // ---- ForceEAM::compute_halfneigh (ref/force_eam.cpp:94-270) on the tile lists: the partner's share of every pair is summed in
     // LDS, one global atomic per owned candidate and tile (k_eam_density_tile<.,1>, k_eam_force_tile<.,0,1>)
     const int nt = h->ntiles, mlo = eam_mlo(h);
@@ -1148,7 +1148,7 @@ int mmd_eam_compute(mmd_handle* h, int evflag, double* eng, double* vir)
       box_p = h->box_dev.p;
     }
     const bool fold_fp = src_p != nullptr ||
-                         (h->opt_eam_fold_fp && (h->opt_eam_fold_fp >= 2 || nt <= 8192) && !h->halo_pending && h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport);
+                         (nt <= 8192 && !h->halo_pending && h->ghost_chain_ok && h->opt_fuse && !h->opt_force_transport);
     const int* fp_root = (fold_fp && src_p == nullptr) ? (const int*)h->ghost_root.p : (const int*)nullptr;
     auto density = [&](const int* list, int cnt) {
       if(cnt <= 0) return;

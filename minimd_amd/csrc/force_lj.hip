@@ -16,12 +16,9 @@
 #include <hip/hip_ext.h>
 #include "tile_lds.hpp"
 
-// 1/r^2: v_rcp_f64 + two Newton steps (<= 1 ulp class) instead of the 11-instruction IEEE divide;
-// exact division available through mmd_set_option("exact_div", 1) for verification.
-template <bool EXACT>
+// 1/r^2: v_rcp_f64 + two Newton steps (<= 1 ulp class) instead of the 11-instruction IEEE divide
 __device__ __forceinline__ double recip(double a)
 {
-  if(EXACT) return 1.0 / a;
   double r = __builtin_amdgcn_rcp(a);
   double e = __builtin_fma(-a, r, 1.0);
   r = __builtin_fma(e, r, r);
@@ -35,12 +32,8 @@ __device__ __forceinline__ double recip_fast(double a)
 {
   const double r = __builtin_amdgcn_rcp(a);
   const double e = __builtin_fma(-a, r, 1.0);
-#ifdef MMD_RCP_ONE_STEP
-  return __builtin_fma(r, e, r);                 // r (1 + e)
-#else
   const double t = __builtin_fma(e, e, e);       // e + e^2
   return __builtin_fma(r, t, r);                 // r (1 + e + e^2)
-#endif
 }
 __device__ __forceinline__ float recip_fast(float a)
 {
@@ -48,10 +41,8 @@ __device__ __forceinline__ float recip_fast(float a)
   const float e = __builtin_fmaf(-a, r, 1.0f);
   return __builtin_fmaf(e, r, r);
 }
-template <bool EXACT>
 __device__ __forceinline__ float recip(float a)
 {
-  if(EXACT) return 1.0f / a;
   float r = __builtin_amdgcn_rcpf(a);
   const float e = __builtin_fmaf(-a, r, 1.0f);
   return __builtin_fmaf(e, r, r);
@@ -78,7 +69,7 @@ struct LJTables {       // general (non-uniform) case: per type-pair tables stag
 #define LJ_UNR 4                 // unroll of the global-gather kernels (rows are padded to MMD_UNROLL >= this)
 
 // ---- full neighbor list: compute_fullneigh<EVFLAG> (ref/force_lj.cpp:366-449) -------------------------
-template <int EV, int UNIFORM, bool EXACT>
+template <int EV, int UNIFORM>
 __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__ x, const int* __restrict__ neigh,
                                                        const int* __restrict__ wave_max, int nlocal, int maxneighs,
                                                        LJParams P, LJTables T, real* __restrict__ f,
@@ -130,7 +121,7 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_full(const real4* __restrict__
       real cut, s6, c48e, eps;
       if(UNIFORM) { cut = P.cutforcesq; s6 = P.sigma6; c48e = c48; eps = P.epsilon; }
       else { const int tij = ti + (int)xj[u].w; cut = s_cut[tij]; s6 = s_s6[tij]; eps = s_eps[tij]; c48e = (real)48.0 * eps; }
-      const real sr2 = recip<EXACT>(rsq);
+      const real sr2 = recip(rsq);
       const real sr6 = sr2 * sr2 * sr2 * s6;
       real force = c48e * sr6 * (sr6 - (real)0.5) * sr2;
       const bool in = rsq < cut;
@@ -176,7 +167,11 @@ __host__ __device__ constexpr int lj_tile_sf_bytes(int waves) { return 3 * 64 * 
 // FUSE=1 appends finalIntegrate of this step and initialIntegrate of the next one (ref/integrate.cpp:46-68) for the
 // tile's atoms: v and the NEW positions go to v / xnew (a second position buffer: other tiles still read the old x),
 // the caller swaps the buffers. Same operations in the same order as k_final_initial_integrate => same bits.
-template <int EV, bool EXACT, int LJ_TILE_WAVES, int UNR, int RD, int FUSE>
+// The shape is fixed (round 6: the A/B knobs tile_waves / tile_unroll / tile_read / exact_div are gone, their numbers are in DESIGN_HISTORY.md): two wavefronts per tile, trips of
+// eight pairs, one reciprocal per FOUR pairs in double precision (one per pair in float), the three coordinates of a pair as three separate LDS reads in double precision
+// (the fused ds_read2_b64 runs at half the LDS rate) and as they come in float.
+constexpr int LJ_TILE_WAVES = 2, LJ_TILE_UNR = 8, LJ_TILE_RD = MMD_PRECISION == 2 ? 3 : 2;
+template <int EV, int FUSE>
 __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     const real4* __restrict__ x, const int* __restrict__ binned, const int* __restrict__ tile_first,
     const int* __restrict__ tile_cnt, const int* __restrict__ tile_max, const int* __restrict__ tile_cand, const int* __restrict__ tile_ncand, int cstride, int ntiles,
@@ -185,6 +180,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     double* __restrict__ partials, int ablate_arg, real* __restrict__ v, real4* __restrict__ xnew, real dt, real dtforce, GhostResolve G, SpecLaunch SP)
 {
   const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
+  constexpr int UNR = LJ_TILE_UNR;
   // A launch enqueued BEHIND a neighbor build whose results the host has not seen yet (mmd_internal.hpp: SpecLaunch): the build's own
   // verdict decides on the device whether this launch does anything at all, and the tile / ghost counts come from device memory
   if(SP.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) SP.clk[0] = wall_clock64();
@@ -284,7 +280,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
       for(int u = 0; u < U; u++) s[u] = (int)(((unsigned)(lane + 7 * (k + u)) & 255u) * (unsigned)(3 * sizeof(real)));
     }
 #pragma unroll
-    for(int u = 0; u < U; u++) lds_read3<((RD == 1 || RD == 3) ? 1 : 0)>((unsigned)s[u], xj[u], yj[u], zj[u]);
+    for(int u = 0; u < U; u++) lds_read3<(LJ_TILE_RD == 3 ? 1 : 0)>((unsigned)s[u], xj[u], yj[u], zj[u]);
     np += U * 64;
     if(k + U < k1) {
 #pragma unroll
@@ -293,7 +289,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
     // every multiply-add is written as an explicit fma: with -ffp-contract=fast the compiler would otherwise be
     // free to pick WHICH product of a sum it fuses, and the instantiations of this template must round alike
     // pairs are worked off in groups of four (register pressure: the second group's positions wait in their LDS-read registers)
-    constexpr bool BATCH = (RD == 2 || RD == 3) && !EXACT && (U % 4) == 0 && sizeof(real) == 8;
+    constexpr bool BATCH = (U % 4) == 0 && sizeof(real) == 8;
     constexpr int GRP = BATCH ? 4 : 1;
     static_for_groups<U, GRP>([&](auto g0c) {
       constexpr int g0 = decltype(g0c)::value;
@@ -316,7 +312,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
         sr2[GRP > 2 ? 2 : 0] = rsq[GRP > 3 ? 3 : 0] * rq; sr2[GRP > 3 ? 3 : 0] = rsq[GRP > 2 ? 2 : 0] * rq;
       } else {
 #pragma unroll
-        for(int q = 0; q < GRP; q++) sr2[q] = EXACT ? recip<true>(rsq[q]) : recip_fast(rsq[q]);
+        for(int q = 0; q < GRP; q++) sr2[q] = recip_fast(rsq[q]);
       }
 #pragma unroll
       for(int q = 0; q < GRP; q++) {
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(64 * LJ_TILE_WAVES) void k_lj_full_tile(
 
 // ---- half neighbor list: compute_halfneigh_threaded<EVFLAG,GHOST_NEWTON> (ref/force_lj.cpp:271-357) ------
 // f was zeroed over owned+ghost atoms beforehand; f_j is scattered with native FP atomics.
-template <int EV, int GN, int UNIFORM, bool EXACT>
+template <int EV, int GN, int UNIFORM>
 __global__ __launch_bounds__(MMD_BLOCK) void k_lj_half(const real4* __restrict__ x, const int* __restrict__ neigh,
                                                        const int* __restrict__ wave_max, int nlocal, int maxneighs,
                                                        LJParams P, LJTables T, real* __restrict__ f,
@@ -415,7 +411,7 @@ __global__ __launch_bounds__(MMD_BLOCK) void k_lj_half(const real4* __restrict__
       if(UNIFORM) { cut = P.cutforcesq; s6 = P.sigma6; eps = P.epsilon; }
       else { const int tij = ti + (int)xj[u].w; cut = s_cut[tij]; s6 = s_s6[tij]; eps = s_eps[tij]; }
       if(rsq < cut) {
-        const real sr2 = recip<EXACT>(rsq);
+        const real sr2 = recip(rsq);
         const real sr6 = sr2 * sr2 * sr2 * s6;
         const real force = (real)48.0 * sr6 * (sr6 - (real)0.5) * sr2 * eps;
         fx += dx * force; fy += dy * force; fz += dz * force;
@@ -726,16 +722,16 @@ extern "C" int mmd_force_lj_setup(mmd_handle* h, int ntypes, const mmd_float* cu
   return 0;
 }
 
-template <int EV, int UNIFORM, bool EXACT>
+template <int EV, int UNIFORM>
 static void launch_full(mmd_handle* h, int nblocks, const LJTables& T)
 {
-  hipLaunchKernelGGL((k_lj_full<EV, UNIFORM, EXACT>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
+  hipLaunchKernelGGL((k_lj_full<EV, UNIFORM>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
                      h->wave_max.p, h->nlocal, h->maxneighs, h->lj, T, h->f.p, h->partials.p, h->opt_ablate);
 }
-template <int EV, int GN, int UNIFORM, bool EXACT>
+template <int EV, int GN, int UNIFORM>
 static void launch_half(mmd_handle* h, int nblocks, const LJTables& T)
 {
-  hipLaunchKernelGGL((k_lj_half<EV, GN, UNIFORM, EXACT>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
+  hipLaunchKernelGGL((k_lj_half<EV, GN, UNIFORM>), dim3(xcd_grid(nblocks)), dim3(MMD_BLOCK), 0, h->stream, h->x.p, h->neigh.p,
                      h->wave_max.p, h->nlocal, h->maxneighs, h->lj, T, h->f.p, h->partials.p);
 }
 
@@ -758,14 +754,14 @@ int mmd_lj_tiles_available(mmd_handle* h)
 // half lists in tile form (k_lj_half_tile): uniform type tables, device-built list, positions + accumulators fit 64 KB of LDS
 int mmd_lj_half_tiles_available(mmd_handle* h)
 {
-  return h->style == 0 && h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && !h->opt_exact_div && !h->opt_lj_original &&
+  return h->style == 0 && h->halfneigh && h->tiles_ready && h->opt_tiles && h->lj_uniform && !h->opt_lj_original &&
          lj_half_tile_lds(h) <= 64 * 1024 && h->neigh_nlocal == h->nlocal;
 }
 
 // the production tile kernel can carry finalIntegrate(n) + initialIntegrate(n+1) (no energy/virial on that step)
 int mmd_lj_can_fuse_integrate(mmd_handle* h)
 {
-  return mmd_lj_tiles_available(h) && h->opt_tile_waves == 2 && h->opt_tile_unroll == 8 && (h->opt_tile_read == 0 || h->opt_tile_read == 2 || h->opt_tile_read == 3) && !h->opt_exact_div;
+  return mmd_lj_tiles_available(h);
 }
 
 // launch the tile kernel over `count` tiles: tile ids from `list` (device) or 0..count-1
@@ -774,7 +770,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   if(count <= 0) return 0;
   const size_t pos_bytes = lj_tile_pos_bytes(h);
   const int nlocal = h->nlocal;
-  const int ev = evflag ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
+  const int ev = evflag ? 1 : 0;
   bool launched = false;
   const int fz = h->fuse_now;                    // 0: force only, 1: + finalIntegrate + the next initialIntegrate, 2: + finalIntegrate (last step of a run)
   // the caller's event pair rides ON the dispatch (start/stop stamps of the kernel itself): timing a step's force kernel costs the
@@ -786,7 +782,7 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
   SpecLaunch SP = list == nullptr ? h->spec : SpecLaunch{nullptr, nullptr, nullptr, nullptr};
   // the launch's own clock (whole-list launches inside a run; a launch cancelled by the build's verdict is stamped again by the one that replaces it)
   SP.clk = nullptr;
-  if(list == nullptr && h->in_run && h->opt_force_clock && h->fclk.p != nullptr) {
+  if(list == nullptr && h->in_run && h->fclk.p != nullptr) {
     // (a run longer than FCLK_SLOTS launches keeps the stamps of its first FCLK_SLOTS / 2 and, in a ring, of its LAST FCLK_SLOTS / 2 launches: every word of a record is
     //  a plain store of a later time than the one it replaces, so a re-used record needs no clearing)
     if(h->spec_clk_redo) { h->fclk_n--; h->spec_clk_redo = false; HIP_TRY(hipMemsetAsync(h->fclk.p + (size_t)FCLK_STRIDE * fclk_slot(h->fclk_n), 0, FCLK_STRIDE * sizeof(unsigned long long), h->stream)); }
@@ -796,24 +792,15 @@ static int launch_tiles(mmd_handle* h, int evflag, const int* list, int count)
     h->fclk_n++;
   }
   if(SP.gate != nullptr) { h->spec_launches++; h->spec_fused = fz == 1; }
-#define TK(EVv, Xv, Wv, Uv, Rv, Fv) if(!launched && ev == EVv && ex == Xv && tw == Wv && tu == Uv && rd == Rv && fz == Fv) { launched = true;  \
-    hipExtLaunchKernelGGL((k_lj_full_tile<EVv, (Xv != 0), Wv, Uv, Rv, Fv>), dim3(xcd_grid(count)), dim3(64 * Wv),                    \
-                       pos_bytes + lj_tile_sf_bytes(Wv) + 16 * sizeof(double), h->stream, kev_a, kev_b, 0, h->x.p,                   \
+#define TK(EVv, Fv) if(!launched && ev == EVv && fz == Fv) { launched = true;                                                       \
+    hipExtLaunchKernelGGL((k_lj_full_tile<EVv, Fv>), dim3(xcd_grid(count)), dim3(64 * LJ_TILE_WAVES),                                \
+                       pos_bytes + lj_tile_sf_bytes(LJ_TILE_WAVES) + 16 * sizeof(double), h->stream, kev_a, kev_b, 0, h->x.p,        \
                        h->binned.p, h->tile_first.p, h->tile_cnt.p, h->tile_max.p, h->tile_cand.p, h->tile_ncand.p, h->tile_cstride, \
                        count, list, h->nl16.p, nlocal, nlocal + h->nghost, h->maxneighs, (int)pos_bytes, h->lj, h->f.p,              \
                        h->partials.p, h->opt_ablate, h->v.p, h->x_alt.p, h->dt, h->dtforce, G, SP); }
-  const int tw = h->opt_tile_waves, tu = h->opt_tile_unroll, rd = ex ? (h->opt_tile_read == 1 ? 1 : 0) : h->opt_tile_read;   // (exact division: one divide per pair)
-  TK(0, 0, 2, 8, 2, 1); TK(0, 0, 2, 8, 2, 2); TK(0, 0, 2, 8, 2, 0); TK(1, 0, 2, 8, 2, 0);                              // tile_read=2: one reciprocal per four pairs
-  TK(0, 0, 2, 8, 3, 1); TK(0, 0, 2, 8, 3, 2); TK(0, 0, 2, 8, 3, 0); TK(1, 0, 2, 8, 3, 0);                              // tile_read=3: the same with three separate 8-byte LDS reads per pair
-  TK(0, 0, 2, 8, 0, 1); TK(0, 0, 2, 8, 0, 2);                                                    // tile_read=0 (one reciprocal per pair), integrator fused / finalIntegrate fused
-  TK(0, 0, 2, 8, 0, 0); TK(1, 0, 2, 8, 0, 0); TK(0, 1, 2, 8, 0, 0); TK(1, 1, 2, 8, 0, 0);        // production shape (+ exact-division check)
-  TK(0, 0, 2, 8, 1, 0); TK(1, 0, 2, 8, 1, 0);
-  TK(0, 0, 4, 8, 0, 0); TK(1, 0, 4, 8, 0, 0);                                                    // tuning shapes
-  TK(0, 0, 1, 8, 0, 0); TK(1, 0, 1, 8, 0, 0);
-  TK(0, 0, 2, 4, 0, 0); TK(1, 0, 2, 4, 0, 0);
-  TK(0, 0, 4, 4, 0, 0); TK(1, 0, 4, 4, 0, 0);
+  TK(0, 1); TK(0, 2); TK(0, 0); TK(1, 0);          // force + integrator of the next step / + finalIntegrate (last step of a run) / force only / force + energy and virial
 #undef TK
-  if(!launched) { mmd_set_error("tile force kernel: unsupported tile_waves/tile_unroll/tile_read combination"); return -1; }
+  if(!launched) { mmd_set_error("tile force kernel: no instantiation for evflag %d with fused integrator %d", ev, fz); return -1; }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -861,7 +848,7 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     if(vir) *vir = 0;
     return 0;
   }
-  const int ev = evflag ? 1 : 0, uni = h->lj_uniform ? 1 : 0, ex = h->opt_exact_div ? 1 : 0;
+  const int ev = evflag ? 1 : 0, uni = h->lj_uniform ? 1 : 0;
   int nsum = nblocks;
   if(h->spec.gate != nullptr && (!mmd_lj_tiles_available(h) || evflag)) { mmd_set_error("Force::compute behind the build: only the gated tile launch may run there"); return -1; }
   if(mmd_lj_tiles_available(h)) {
@@ -871,8 +858,8 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
   } else if(!h->halfneigh) {
     MMD_TRY(mmd_ensure_rows(h));
     MMD_TRY(h->partials.ensure((size_t)2 * nblocks + 8, false, h->stream));
-#define F(EVv, Uv, Xv) if(ev == EVv && uni == Uv && ex == Xv) launch_full<EVv, Uv, (Xv != 0)>(h, nblocks, T)
-    F(0, 0, 0); F(0, 0, 1); F(0, 1, 0); F(0, 1, 1); F(1, 0, 0); F(1, 0, 1); F(1, 1, 0); F(1, 1, 1);
+#define F(EVv, Uv) if(ev == EVv && uni == Uv) launch_full<EVv, Uv>(h, nblocks, T)
+    F(0, 0); F(0, 1); F(1, 0); F(1, 1);
 #undef F
   } else if(mmd_lj_half_tiles_available(h)) {
     // half lists in tile form: on-chip scatter (k_lj_half_tile)
@@ -914,9 +901,8 @@ static int lj_compute(mmd_handle* h, int evflag, double* eng, double* vir)
     MMD_TRY(mmd_ensure_rows(h));
     MMD_TRY(mmd_zero_forces(h, nlocal + h->nghost));     // ref/force_lj.cpp:286-291
     const int gn = h->ghost_newton ? 1 : 0;
-#define H(EVv, Gv, Uv, Xv) if(ev == EVv && gn == Gv && uni == Uv && ex == Xv) launch_half<EVv, Gv, Uv, (Xv != 0)>(h, nblocks, T)
-    H(0, 0, 0, 0); H(0, 0, 0, 1); H(0, 0, 1, 0); H(0, 0, 1, 1); H(0, 1, 0, 0); H(0, 1, 0, 1); H(0, 1, 1, 0); H(0, 1, 1, 1);
-    H(1, 0, 0, 0); H(1, 0, 0, 1); H(1, 0, 1, 0); H(1, 0, 1, 1); H(1, 1, 0, 0); H(1, 1, 0, 1); H(1, 1, 1, 0); H(1, 1, 1, 1);
+#define H(EVv, Gv, Uv) if(ev == EVv && gn == Gv && uni == Uv) launch_half<EVv, Gv, Uv>(h, nblocks, T)
+    H(0, 0, 0); H(0, 0, 1); H(0, 1, 0); H(0, 1, 1); H(1, 0, 0); H(1, 0, 1); H(1, 1, 0); H(1, 1, 1);
 #undef H
   }
   HIP_TRY(hipGetLastError());

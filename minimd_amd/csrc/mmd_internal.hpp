@@ -159,9 +159,9 @@ struct DirectHalo {
   bool prev_valid = false;
   int ns_prev[26], nr_prev[26];
   int opt_borders = 1;        // 1: Comm::borders on several ranks as ONE exchange of the 26 lists where a previous plan exists; 0: swap by swap
-  int opt_recv = 3;           // per-step halo: 1 = one message per partner + k_dh_unpack; 2 = every list a message of its own, received straight into its ghost slots;
-                              // 3 = 1, and where the tile kernels can follow (LJ full lists, no overlap) the partners' messages land in the position buffer itself,
-                              // behind the ghost slots, and the boundary tiles read them there: no k_dh_unpack on the step
+  int opt_recv = 3;           // per-step halo: 1 = one message per partner + k_dh_unpack; 3 = the same, and where the tile kernels can follow (LJ full lists) the partners' messages
+                              // land in the position buffer itself, behind the ghost slots, and the boundary tiles read them there: no k_dh_unpack on the step
+                              // (2, round 5: every list a message of its own received straight into its ghost slots — 52 p2p operations per group, 6890 against 8710 Matom-steps/s: removed)
   // halo_recv 3: the position buffers are longer than owned + ghosts; entry R + o is record o of the per-step receive layout (one message per partner, in partner
   // order). gmap[g] (written by k_db_unpack) = where ghost g's position arrives: R + o, or its own slot nlocal + g for a list that stays on this rank; the build
   // writes the boundary tiles' candidate lists once more with every ghost named by gmap (tile_cand_src), and a step's force kernel stages from there.
@@ -212,7 +212,6 @@ struct mmd_handle {
   DevArr<int> tile_of_block, tile_block, tile_first, tile_max;
   DevArr<unsigned> pencil_lohi;           // per pencil: first / last (+1) bin holding an owned atom, collected by k_bin_sort when a build asks for it
   bool pencil_lohi_req = false, pencil_lohi_ready = false;
-  int opt_fold_pencil = 1;
   DevArr<int> pencil_range;               // per pencil (row of blocks along x): [first, last) entry of binned[] between its first and last owned bin
   DevArr<int> tile_cand, tile_ncand, tile_cnt;
   DevArr<int> tile_cand_src;              // one-rank runs: tile_cand with every ghost named by its owner + image code (GhostResolve, tile_lds.hpp)
@@ -257,21 +256,15 @@ struct mmd_handle {
   char pci[32] = "?";
   // LJ full lists, overlapped step: 1 = the boundary tiles are launched on the COMMUNICATION stream right behind the transfer (they run under the tail of the
   // interior tiles, the compute stream only joins at the end of the step); 0 = on the compute stream behind a wait for the halo (round 4)
-  int opt_overlap_join = 1;
   long long overlap_join_steps = 0;
   double overlap_trial_s[2] = {0, 0}; // per step, summed over the ranks: [0] without, [1] with overlap
   hipEvent_t ev_trial[3] = {nullptr, nullptr, nullptr};
   int tile_cstride = 0, tile_cmax = 0;
   DevArr<unsigned short> nl16;
   int opt_tiles = 1;
-  int opt_upload_tiles = 1;  // mmd_neighbor_upload also derives the tile form of the rows (0: uploaded lists stay on the row kernels)
-  int opt_build = 1;         // tile build kernel: 1 = one owned atom per lane (k_build_rows), 0 = one candidate per lane (k_build_tiles)
   int opt_force_transport = 0;   // testing: route self-swaps through the transport too (RCCL loop-back on one GPU)
-  int opt_tile_waves = 2, opt_tile_unroll = 8;   // tile-kernel shape (A/B knobs; defaults are the tuned ones)
   int opt_safe_exchange = 0;                      // Comm::do_safeexchange (ref/comm.h:87): Comm::exchange offers leavers to every rank within `need` sub-domains
   int opt_check_exchange = 0;                     // --check_exchange: warn when an atom moved further than a sub-domain
-  int opt_tile_read = MMD_PRECISION == 2 ? 3 : 2;  // LJ full-list tile kernel: 3 (DP default): one reciprocal per four pairs + three separate 8-byte LDS reads per pair; 2: the same with the
-                                                  // compiler's paired read (SP default: one reciprocal per pair there); 0: one reciprocal per pair; 1: 0 + separate reads (A/B knobs)
   int opt_fuse = 2;          // >=1: fused final+initial integrate, single-kernel ghost update on one rank; 2: integrator inside the LJ tile kernel
   int fuse_now = 0;          // transient: the next tile launch carries the integrator
   bool halo_pending = false; // transient: this step's position halo is in flight on the communication stream (ev_halo_done behind it)
@@ -324,29 +317,24 @@ struct mmd_handle {
   // one-rank half-list LJ steps with ghost newton: the tile kernel adds a ghost's share to its owner (no Comm::reverse_communicate)
   int opt_fold_reverse = 1;
   bool fold_reverse_now = false;
-  int opt_eam_fold_fp = 1;             // one rank, EAM full lists: ghosts' fp read through their owners in the force sweep, no fp halo launch
                                        // (1: small systems, where the saved launch shows — no difference at -s 64; 2: always; 0: never)
   bool fp_ghosts_stale = false;
   bool ghosts_uploaded = false;          // the ghost atoms came through mmd_atom_upload, not from this handle's Comm::borders (no send lists, no ghost_root)
   mmd_fp_halo_fn fp_halo_fn = nullptr;   // caller-supplied ForceEAM::communicate (mmd_force_eam_set_fp_halo)
   void* fp_halo_ctx = nullptr;
   std::vector<real> fp_stage;
-  int opt_eam_half_rows = 0;           // 1: EAM half lists on the global-atomic row kernels even where the tile kernels apply
   bool eam_half_attr_set = false;
   const int* nghost_dev = nullptr;     // != nullptr: one-rank borders enqueued, ghost count still on the device (nghost holds a bound)
   int bf_est_nb = 0;
   bool pbc_defer = false, pbc_pending = false;     // Atom::pbc folded into the binning pass of the Atom::sort that follows
   // the binning Atom::sort did inside this re-neighboring left the owned atoms in bin order and their counts in the histogram: the build's binning places the ghosts only (mmd_bin_atoms)
-  bool bin_owned_valid = false; int bin_owned_n = 0, bin_owned_mbins = 0; int opt_bin_reuse = 1; long long bin_reuses = 0;
+  bool bin_owned_valid = false; int bin_owned_n = 0, bin_owned_mbins = 0; long long bin_reuses = 0;
   int bin_count_clean = -1;            // mbins for which bin_count is known to be all zero (k_bin_sort leaves it so)
   int opt_core_pct = 30;               // EAM full lists on one rank: rows in two parts, the core part ends this many per cent into the skin (0: off)
   bool zero_f_in_integrate = false;    // Integrate::run, one-rank half lists: k_final_initial_integrate clears f behind itself
   int f_zeroed_n = 0;                  // f[0 .. 3*f_zeroed_n) is known to be zero (consumed by the next half-list Force::compute)
   int opt_lj_original = 0;             // --half_neigh -1: ForceLJ::compute_original (ref/force_lj.cpp:118-176) = the row kernel k_lj_half, not the tile kernel
-  int opt_async_counts = 1;            // re-neighboring: list sizes from the previous build, the counts return with the build's flags
   int ntiles_hint = 0;
-  int opt_fuse_final = 1;              // the last step of a run: finalIntegrate inside the LJ tile force launch (0: k_final_integrate behind it)
-  int opt_kernel_dummy = 1;            // the fused force kernels write the dummy atom of the position buffer they fill (0: a k_set_dummy launch whenever a re-neighboring has moved it)
   int opt_time_sample = 0;             // force-kernel clock on every n-th Force::compute of a run (0: every 7th)
   int force_calls = 0;                 // Force::compute calls of the current run that went through the sampled clock
   int run_ntimes = 0;                  // length of the current mmd_integrate_run
@@ -360,12 +348,11 @@ struct mmd_handle {
   double fclk_ms_sampled = 0; int fclk_launches_sampled = 0;
   double fclk_gap_ms = 0; int fclk_gaps = 0;     // idle time between stamped launches that follow each other directly
   double fclk_first_ms = 0, fclk_median_ms = 0, fclk_last_ms = 0;      // mean span of the run's first <= 100 stamped launches, median of all kept, mean of its last <= 100
-  int opt_force_clock = 1;
   bool spec_clk_redo = false;          // the launch behind the build was cancelled: the launch that replaces it takes its clock slot
   long long force_sample_ctr = 0;      // the same, never reset: call number modulo the sampling period decides which launches carry the clock
   bool resolve_now = false, ghosts_stale = false;
   hipEvent_t launch_ev_a = nullptr, launch_ev_b = nullptr;     // event pair the next tile-kernel launch attaches to its dispatch
-  int opt_borders_fast = 2, opt_borders_est = 150;    // device-resident borders: 0 off, 1 swap by swap (count / scatter pair per dimension), 2 + the three-launch form where every swap is a self swap; its sizing estimate in per cent of the previous counts
+  int opt_borders_est = 150;    // device-resident borders: 0 off, 1 swap by swap (count / scatter pair per dimension), 2 + the three-launch form where every swap is a self swap; its sizing estimate in per cent of the previous counts
   int prev_nb = 0, prev_nghost = 0;   // counts of the last Comm::borders (size the device-resident one-rank path of the next one)
   // ---- Integrate
   real dt = 0, dtforce = 0;
@@ -382,7 +369,6 @@ struct mmd_handle {
   int clk_written = 0;         // bit s: slot s was stamped in this re-neighboring; bit 2: the build published its words (incl. its own stamp)
   long long clk_last = 0;      // last stamp seen (stamps of one re-neighboring must lie behind it and ascend)
   double clk_rate_hz = 0;      // hipDeviceAttributeWallClockRate
-  int opt_spin_readback = 1;   // Integrate::run: the host polls pinned memory for the build's results instead of blocking on the stream
   // Force::compute of a re-neighboring step launched BEHIND the build, before its result words have reached the host (no idle GPU while the
   // host reads them and enqueues the kernel): Integrate::run leaves the launch as a closure, mmd_neighbor_build calls it between publishing
   // the words and polling for them; the kernel does nothing unless the build's verdict on the device says the lists fit (SpecLaunch)
@@ -413,9 +399,7 @@ struct mmd_handle {
   // the step loop and everything below it) and bytes this rank sent to OTHER ranks (halo, exchange, borders payloads + handshakes)
   long long host_syncs = 0, halo_bytes = 0;
   long long transport_syncs = 0;       // waits that belong to the host-staged TEST transport (device<->host staging of a message), not to the algorithm
-  bool time_force_events = true;
   // ---- options
-  int opt_exact_div = 0;
   int opt_force_block = MMD_BLOCK;
 };
 
@@ -439,7 +423,7 @@ int mmd_lj_tiles_available(mmd_handle* h);
 int mmd_lj_half_tiles_available(mmd_handle* h);
 int mmd_lj_can_fuse_integrate(mmd_handle* h);
 int mmd_eam_can_fuse_integrate(mmd_handle* h);
-int mmd_prepare_x_alt(mmd_handle* h, bool kernel_writes_dummy = false);        // second position buffer (capacity + dummy atom) for the fused force+integrate kernel
+int mmd_prepare_x_alt(mmd_handle* h);        // second position buffer (capacity + dummy atom) for the fused force+integrate kernel
 int mmd_lj_compute_tiles_split(mmd_handle* h, int evflag, int part);   // part 0: interior tiles, 1: boundary tiles + energy sum
 int mmd_order_tiles(mmd_handle* h);
 int mmd_ensure_rows(mmd_handle* h);       // materialise `neigh` from the tile form when a kernel needs it

@@ -314,7 +314,7 @@ int mmd_bin_atoms(mmd_handle* h, int count)
   // counts are known, so the second pass counts and places the ghosts only (`reuse`; the first pass leaves the owned counts in the histogram: `keep`)
   // and k_bin_sort writes the owned part of every bin from the first pass's starts — the same `binned`, 18 + 9 us less at -s 80.
   const bool reuse = count < 0 && h->bin_owned_valid && h->bin_owned_n == h->nlocal && h->bin_owned_mbins == g.mbins && !h->big_bins && h->nlocal > 0 && n > h->nlocal;
-  const bool keep = count >= 0 && count == h->nlocal && h->in_reneighbor && h->opt_bin_reuse && !h->big_bins && count > 0;
+  const bool keep = count >= 0 && count == h->nlocal && h->in_reneighbor && !h->big_bins && count > 0;
   h->bin_owned_valid = false;
   if(!reuse && h->bin_count_clean != g.mbins)            // (first use / new geometry / owned counts nobody used; afterwards k_bin_sort leaves the histogram zeroed)
     HIP_TRY(hipMemsetAsync(h->bin_count.p, 0, ((size_t)g.mbins + 1) * sizeof(int), h->stream));
@@ -517,37 +517,7 @@ __global__ __launch_bounds__(64, 2) void k_build(const real4* __restrict__ x, co
 }
 
 // ---------------------------------------------------------------------------------------------------
-// tiles: blocks that hold at least one owned atom are cut into groups of <= 64 consecutive binned entries
-// ---------------------------------------------------------------------------------------------------
-__global__ void k_tile_count(const int* __restrict__ binned, const int* __restrict__ bin_start, int nblocks, int nlocal,
-                             int* __restrict__ ntile_of_block)
-{
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if(b >= nblocks) return;
-  const int a0 = bin_start[b * NB_SUB], a1 = bin_start[b * NB_SUB + NB_SUB];
-  bool owned = false;
-  for(int a = a0; a < a1 && !owned; a++) owned = binned[a] < nlocal;
-  ntile_of_block[b] = owned ? (a1 - a0 + 63) >> 6 : 0;
-}
-__global__ void k_tile_fill(const int* __restrict__ bin_start, int nblocks, const int* __restrict__ tile_of_block,
-                            int* __restrict__ tile_block, int* __restrict__ tile_first, int* __restrict__ tile_cnt, int* __restrict__ flags, int cap,
-                            real4* __restrict__ x, int nlocal, int ghost_cap, const int* __restrict__ nghost_dev)
-{
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if(b == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[7] = 0; }     // (result flags of the build kernel and accumulators of k_tile_reduce, which follow on the stream)
-  // deferred one-rank borders: the dummy atom (far outside any cutoff, see k_set_dummy) goes behind the last ghost, whose number only the device knows yet
-  if(b == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
-  if(b >= nblocks) return;
-  const int t0 = tile_of_block[b], t1 = tile_of_block[b + 1];
-  const int a0 = bin_start[b * NB_SUB], a1 = bin_start[b * NB_SUB + NB_SUB];
-  for(int t = t0; t < t1 && t < cap; t++) {                     // (cap: the arrays may be sized from the previous build's count)
-    tile_block[t] = b;
-    tile_first[t] = a0 + (t - t0) * 64;
-    tile_cnt[t] = min(64, a1 - tile_first[t]);
-  }
-}
-// ---------------------------------------------------------------------------------------------------
-// Production tiles ("pencil tiles", k_build_rows): a pencil = one row of blocks along x (2x2 reference bins in cross-section); its
+// Tiles ("pencil tiles", k_build_rows): a pencil = one row of blocks along x (2x2 reference bins in cross-section); its
 // entries of `binned` are sorted by x to a quarter of a bin (NB_XF). The stretch from the pencil's first to its last bin that holds an
 // owned atom is cut into pieces of 64 entries: every tile but the last of a pencil is a FULL wavefront of atoms within ~1.2 block
 // lengths of x (at LJ liquid density a block holds 57 atoms: one-block tiles leave 11 % of the lanes empty).
@@ -578,7 +548,7 @@ __global__ void k_pencil_fill(const int* __restrict__ pencil_range, int npencils
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if(p == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[7] = 0; }     // (result flags of the build kernel and accumulators of k_tile_reduce, which follow on the stream)
-  if(p == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};    // the dummy atom, see k_tile_fill
+  if(p == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};    // the dummy atom (far outside any cutoff, see k_set_dummy) behind the last ghost, whose number only the device knows yet
   if(p >= npencils) return;
   const int t0 = tile_of_pencil[p], t1 = tile_of_pencil[p + 1];
   const int a0 = pencil_range[2 * p], a1 = pencil_range[2 * p + 1];
@@ -600,7 +570,7 @@ __global__ __launch_bounds__(256) void k_pencil_fill_scan(const int* __restrict_
   __shared__ int lds[17];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if(p == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[7] = 0; }
-  if(p == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};    // the dummy atom, see k_tile_fill
+  if(p == 0 && nghost_dev) x[nlocal + min(*nghost_dev, ghost_cap)] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};    // the dummy atom (far outside any cutoff, see k_set_dummy) behind the last ghost, whose number only the device knows yet
   auto range_of = [&](int pp, int& a0, int& a1) {
     a0 = 0; a1 = 0;
     if(pencil_lohi != nullptr) {
@@ -640,268 +610,6 @@ __global__ __launch_bounds__(256) void k_pencil_fill_scan(const int* __restrict_
   }
   // (every workgroup has read the counts in front of it before the last one finishes? No: the total goes to slot [npencils], which nobody sums)
   if(blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ntile_of_pencil[npencils] = before + tot;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Fused tile build (full lists): same register-transposed test as k_build, but
-//   * hits go to an LDS row buffer rows[k][lane-of-atom] as raw candidate slots (ds_write_b16, no global
-//     scatter: the scattered 4-byte stores of k_build were TA-bound, ~2 store instructions per 64 tests);
-//   * at the end of a tile the union of referenced candidates is compacted (ballot/mbcnt), written to
-//     tile_cand[] as global atom indices, and the rows are rewritten through an LDS remap table;
-//   * rows leave the CU as coalesced 128-byte lines, already padded with the dummy slot (= ncand).
-// The 32-bit reference-style rows are NOT produced here; mmd_ensure_rows() derives them on demand.
-// ---------------------------------------------------------------------------------------------------
-// MODE as in k_build: 0 full list, 1 half (owned j > i, every ghost), 2 half with ghost newton (every pair once globally).
-// For the half modes the candidate index itself carries the rule: a hit also needs cj > i, which is "j > i" for owned
-// candidates and always true for ghosts (their indices follow the owned atoms); with ghost newton the ghosts are flagged
-// per chunk and decided by the (z,y,x) order of ref/neighbor.cpp:155-157.
-template <int MODE>
-__global__ __launch_bounds__(64, 2) void k_build_tiles(const real4* __restrict__ x, const int* __restrict__ binned,
-                                                       const int* __restrict__ bin_start, const int* __restrict__ ghost_image,
-                                                       BinGeom g, int nblocks, int nlocal,
-                                                       int nall, real cutneighsq, int maxneighs, int cstride, const int* __restrict__ tile_of_block,
-                                                       int* __restrict__ numneigh, unsigned short* __restrict__ nl16,
-                                                       int* __restrict__ tile_cand, int* __restrict__ tile_ncand,
-                                                       int* __restrict__ tile_max, int* __restrict__ tile_ghost, unsigned short* __restrict__ tile_self,
-                                                       int* __restrict__ flags, unsigned long long* __restrict__ total_out, int ablate_arg)
-{
-  const int ablate = MMD_ABLATE(ablate_arg);     // profiling switches: compiled out of the shipped library (mmd_internal.hpp)
-  extern __shared__ __align__(16) unsigned char s_dyn[];
-  unsigned short* rows = (unsigned short*)s_dyn;              // [maxneighs][64]
-  __shared__ int rng_start[128], rng_pref[130];
-  __shared__ unsigned short remap[NB_CHUNKS * 64];
-  __shared__ int cnt[64], at_i[64];
-  __shared__ real at_x[64], at_y[64], at_z[64];
-  const int lane = threadIdx.x;
-  // plain block order here: blocks without owned atoms (ghost shell) exit at once, and round-robin placement
-  // balances that better than contiguous eighths (measured: 2.6 ms vs 2.96 ms per build at -s 80)
-  const int b = blockIdx.x;
-  if(b >= nblocks) return;
-  const int tile0 = tile_of_block[b], ntile_b = tile_of_block[b + 1] - tile0;
-  if(ntile_b == 0) return;                                    // no owned atom in this block (uniform exit)
-  const int a0 = bin_start[b * NB_SUB], a1 = bin_start[b * NB_SUB + NB_SUB];
-  const int bx = b % g.nblk[0], by = (b / g.nblk[0]) % g.nblk[1], bz = b / (g.nblk[0] * g.nblk[1]);
-  const int ny = 2 * g.reach[1] + 1, nz = 2 * g.reach[2] + 1;
-  const int nr = min(ny * nz, 128);
-  int carry = 0;
-  for(int r0 = 0; r0 < nr; r0 += 64) {
-    const int r = r0 + lane;
-    int len = 0, start = 0;
-    if(r < nr) {
-      const int z = bz + r / ny - g.reach[2], y = by + r % ny - g.reach[1];
-      if(z >= 0 && z < g.nblk[2] && y >= 0 && y < g.nblk[1]) {
-        const int x0 = max(bx - g.reach[0], 0), x1 = min(bx + g.reach[0], g.nblk[0] - 1);
-        const int row = (z * g.nblk[1] + y) * g.nblk[0];
-        start = bin_start[(row + x0) * NB_SUB];
-        len = bin_start[(row + x1) * NB_SUB + NB_SUB] - start;
-      }
-    }
-    const int incl = wave_incl_scan(len);
-    if(r < nr) { rng_start[r] = start; rng_pref[r] = carry + incl - len; }
-    carry += __shfl(incl, 63, 64);
-  }
-  if(lane == 0) rng_pref[nr] = carry;
-  __syncthreads();
-  const int total = rng_pref[nr];
-  if(ablate & 16) return;
-  // slot of this block's first atom in the candidate sequence (its own (y,z) row is slice rc)
-  const int rc = g.reach[2] * ny + g.reach[1];
-  const int self0 = rc < nr ? rng_pref[rc] + (a0 - rng_start[rc]) : 0;
-  if(total > NB_CHUNKS * 64 || rc >= nr) {                                // cannot hold the candidates in one register pass
-    if(lane == 0) atomicMax(&flags[3], 1);                    // host falls back to k_build + global rows
-    return;
-  }
-  // ---- transpose-load the candidates into registers. Slot t lives at binned[t + D(r)], r = slice of t:
-  // with few slices the offset is accumulated branch-free from wave-uniform (start, delta) pairs, so the 2x28
-  // dependent loads of a lane are all in flight together (a data-dependent search loop serialised them).
-  real cx[NB_CHUNKS], cy[NB_CHUNKS], cz[NB_CHUNKS];
-  int cj[NB_CHUNKS];
-  if(nr <= NB_FASTR) {
-    int pq[NB_FASTR], dq[NB_FASTR];
-#pragma unroll
-    for(int q = 0; q < NB_FASTR; q++) {
-      const int d_here = q < nr ? rng_start[q] - rng_pref[q] : 0;
-      const int d_prev = (q > 0 && q < nr) ? rng_start[q - 1] - rng_pref[q - 1] : 0;
-      pq[q] = q < nr ? rng_pref[q] : 0x7fffffff;
-      dq[q] = q < nr ? d_here - d_prev : 0;
-    }
-    int jj[NB_CHUNKS];
-#pragma unroll
-    for(int c = 0; c < NB_CHUNKS; c++) {
-      const int gt = c * 64 + lane;
-      int addr = gt;
-#pragma unroll
-      for(int q = 0; q < NB_FASTR; q++) addr += gt >= pq[q] ? dq[q] : 0;
-      jj[c] = gt < total ? binned[addr] : -1;
-    }
-#pragma unroll
-    for(int c = 0; c < NB_CHUNKS; c++) {
-      cj[c] = jj[c];
-      cx[c] = (real)1.0e15; cy[c] = (real)1.0e15; cz[c] = (real)1.0e15;
-      if(jj[c] >= 0) { const real4 p = x[jj[c]]; cx[c] = p.x; cy[c] = p.y; cz[c] = p.z; }
-    }
-  } else {
-    int r = 0;
-#pragma unroll
-    for(int c = 0; c < NB_CHUNKS; c++) {
-      const int gt = c * 64 + lane;
-      cx[c] = (real)1.0e15; cy[c] = (real)1.0e15; cz[c] = (real)1.0e15; cj[c] = -1;
-      if(gt < total) {
-        while(r + 1 < nr && rng_pref[r + 1] <= gt) r++;
-        const int j = binned[rng_start[r] + (gt - rng_pref[r])];
-        const real4 p = x[j];
-        cx[c] = p.x; cy[c] = p.y; cz[c] = p.z; cj[c] = j;
-      }
-    }
-  }
-  // ---- half-list rules folded into the candidate index (see the kernel comment)
-  unsigned lex = 0;                                           // chunks in which MY candidate is a ghost (MODE 2)
-  if(MODE == 2) {
-#pragma unroll
-    for(int c = 0; c < NB_CHUNKS; c++) {
-      if(cj[c] >= nlocal) lex |= 1u << c;                     // ghosts: (z,y,x) order of the positions decides (ref/neighbor.cpp:155-157)
-    }
-  }
-  const bool any_lex = MODE == 2 && __builtin_amdgcn_ballot_w64(lex != 0) != 0ull;
-  const int nchunks = (total + 63) >> 6;
-  // ---- conservative float bounding box of every chunk of 64 candidates; lane c keeps the box of chunk c.
-  // An owned atom farther than the cutoff (+0.1% margin for the float rounding) from a box skips that chunk
-  // with a scalar branch: ~60% of the (atom, chunk) passes disappear.
-  float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f, bz0 = 3.0e38f, bz1 = -3.0e38f;
-#pragma unroll
-  for(int c = 0; c < NB_CHUNKS; c++) {
-    if(c < nchunks && !(ablate & 4)) {
-      const bool valid = cj[c] >= 0;
-      const unsigned kx = float_key((float)cx[c]), ky = float_key((float)cy[c]), kz = float_key((float)cz[c]);
-      const float mnx = key_float(wave_min_u(valid ? kx : 0xffffffffu)), mxx = key_float(wave_max_u(valid ? kx : 0u));
-      const float mny = key_float(wave_min_u(valid ? ky : 0xffffffffu)), mxy = key_float(wave_max_u(valid ? ky : 0u));
-      const float mnz = key_float(wave_min_u(valid ? kz : 0xffffffffu)), mxz = key_float(wave_max_u(valid ? kz : 0u));
-      if(lane == c) { bx0 = mnx; bx1 = mxx; by0 = mny; by1 = mxy; bz0 = mnz; bz1 = mxz; }
-    }
-  }
-  const float cull = (float)cutneighsq * 1.001f + 1.0e-4f;
-
-  for(int tl = 0; tl < ntile_b; tl++) {
-    const int tile = tile0 + tl;
-    const int ta = a0 + tl * 64, te = min(ta + 64, a1);
-    // owned atoms of the tile: one coalesced load, then broadcast reads from LDS inside the atom loop
-    {
-      const int ii = ta + lane < te ? binned[ta + lane] : -1;
-      const real4 p = x[ii >= 0 ? ii : 0];
-      cnt[lane] = 0;
-      at_i[lane] = ii;
-      at_x[lane] = p.x; at_y[lane] = p.y; at_z[lane] = p.z;
-    }
-    __syncthreads();
-    for(int a = ta; a < te; a++) {
-      const int al = a - ta;
-      const int i = at_i[al];
-      if(i >= nlocal) continue;                               // ghosts get no row
-      const real xix = at_x[al], xiy = at_y[al], xiz = at_z[al];
-      // chunks whose box is within reach of this atom
-      const float fxi = (float)xix, fyi = (float)xiy, fzi = (float)xiz;
-      const float ddx = fmaxf(fmaxf(bx0 - fxi, fxi - bx1), 0.0f);
-      const float ddy = fmaxf(fmaxf(by0 - fyi, fyi - by1), 0.0f);
-      const float ddz = fmaxf(fmaxf(bz0 - fzi, fzi - bz1), 0.0f);
-      unsigned long long live = __builtin_amdgcn_ballot_w64(lane < nchunks && ddx * ddx + ddy * ddy + ddz * ddz <= cull);
-      if(ablate & 2) live = ~0ull >> (64 - nchunks);      // profiling: no culling
-      if(ablate & 1) live = 0;                            // profiling: no tests at all
-      int n = 0;
-      // dead chunks come in runs (candidates are ordered by rows of blocks): test 4 chunks with one scalar branch
-      // before looking at the single bits — most of the taken skip-branches (an instruction-fetch redirect each)
-      // disappear
-#pragma unroll
-      for(int c4 = 0; c4 < NB_CHUNKS; c4 += 4) {
-        if((live >> c4) & 0xFull) {
-#pragma unroll
-          for(int c = c4; c < c4 + 4; c++) {
-            if((live >> c) & 1ull) {
-              const real dx = xix - cx[c], dy = xiy - cy[c], dz = xiz - cz[c];
-              const real rsq = dx * dx + dy * dy + dz * dz;
-              // full lists: the atom itself (rsq = 0) is kept here and dropped at write-out: no index compare per
-              // pass, and the v_cmp result IS the hit mask
-              bool keep = rsq <= cutneighsq;
-              if(MODE != 0) {
-                bool rule = cj[c] > i;
-                if(MODE == 2 && any_lex && ((lex >> c) & 1u))
-                  rule = !(cz[c] < xiz || (cz[c] == xiz && cy[c] < xiy) || (cz[c] == xiz && cy[c] == xiy && cx[c] < xix));
-                keep = keep && rule;
-              }
-              const unsigned long long m = MODE == 0 ? __builtin_amdgcn_fcmp(rsq, cutneighsq, 5 /* ordered <= */)
-                                                     : __builtin_amdgcn_ballot_w64(keep);
-              if(m) {
-                // ordered append: rank of this lane among the hits, on top of the n found so far; a row that
-                // overflows keeps overwriting its last slot (the host grows maxneighs and rebuilds, ref :184-208)
-                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, n));
-                if(keep) rows[min(pos, maxneighs - 1) * 64 + al] = (unsigned short)(c * 64 + lane);
-                n += __popcll(m);
-              }
-            }
-          }
-        }
-      }
-      if(lane == 0) { cnt[al] = n; numneigh[i] = MODE == 0 ? max(n - 1, 0) : n; }      // full lists: n counts the atom itself
-    }
-    __syncthreads();
-    if(ablate & 8) continue;
-    // ---- union of the candidates referenced by this tile -> compact list + remap table. Every lane marks the
-    // slots of its own raw row (the atom itself included: it is a neighbor of its tile mates anyway)
-#pragma unroll
-    for(int c = 0; c < NB_CHUNKS; c++) if(c < nchunks) remap[c * 64 + lane] = 0;
-    __syncthreads();
-    const int myraw = min(cnt[lane], maxneighs);
-    for(int k = 0; k < myraw; k++) remap[rows[k * 64 + lane]] = 1;
-    __syncthreads();
-    int base = 0;
-    bool refs_ghost = false;
-    unsigned usedbits = 0;
-#pragma unroll
-    for(int c = 0; c < NB_CHUNKS; c++) if(c < nchunks) usedbits |= (unsigned)(remap[c * 64 + lane] != 0) << c;
-    __syncthreads();
-#pragma unroll
-    for(int c = 0; c < NB_CHUNKS; c++) {
-      if(c < nchunks) {
-        const bool bit = (usedbits >> c) & 1u;
-        refs_ghost = refs_ghost || (bit && cj[c] >= nlocal);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
-        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if(bit) {
-          tile_cand[(size_t)tile * cstride + pos] = cj[c];
-          remap[c * 64 + lane] = (unsigned short)pos;
-        } else if(MODE != 0) remap[c * 64 + lane] = 0xffff;
-        base += __popcll(m);
-      }
-    }
-    __syncthreads();
-    // half lists: where the atom itself sits in the tile's union (0xffff: no tile mate references it) — the half force
-    // kernel adds the atom's own force to that accumulator instead of issuing separate global atomics
-    if(MODE != 0) tile_self[(size_t)tile * 64 + lane] = ta + lane < te ? remap[self0 + tl * 64 + lane] : (unsigned short)0xffff;
-    // ---- coalesced write-out of the padded, remapped rows; the atom's own slot is skipped on the way
-    const int myn = MODE == 0 ? max(cnt[lane] - 1, 0) : cnt[lane];
-    const int maxn = wave_max_i(myn);
-    int kmax = (maxn + NB_ROW_PAD - 1) / NB_ROW_PAD * NB_ROW_PAD;     // rows padded to 4: the tile kernels run trips of 8 + one of 4
-    if(kmax > maxneighs) kmax = maxneighs;
-    const int selfslot = MODE == 0 ? self0 + tl * 64 + lane : -7;      // (half rows never hold the atom itself)
-    unsigned short* out = nl16 + ((size_t)tile * maxneighs) * 64 + lane;
-    int ko = 0;                                   // output row of this lane (lags k by one after its own slot)
-    for(int k = 0; k <= kmax; k++) {              // stored as the LDS byte offset of the {x,y,z} record (slot * 3 reals)
-      const int raw = k < myraw ? rows[k * 64 + lane] : -1;
-      const unsigned short v = (unsigned short)((raw >= 0 ? remap[raw] : (unsigned short)base) * NB_SLOT_BYTES);
-      if(raw != selfslot && ko < kmax) { out[(size_t)ko * 64] = v; ko++; }
-    }
-    const long long tsum = wave_sum((long long)myn);
-    const bool any_ghost = __builtin_amdgcn_ballot_w64(refs_ghost) != 0ull;
-    if(lane == 0) {
-      tile_max[tile] = kmax;
-      tile_ncand[tile] = base;
-      tile_cand[(size_t)tile * cstride + base] = nall;       // the dummy atom closes the list (cstride > NB_CHUNKS*64)
-      tile_ghost[tile] = any_ghost ? 1 : 0;
-      atomicMax(&flags[0], maxn);
-      atomicMax(&flags[2], base);
-      atomicAdd(total_out, (unsigned long long)tsum);
-    }
-    __syncthreads();
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1704,7 +1412,7 @@ __global__ __launch_bounds__(1024) void k_tile_reduce(const int* __restrict__ ti
                                                       unsigned long long* __restrict__ total_out, const int* __restrict__ ntiles_dev,
                                                       const int* __restrict__ bst)
 {
-  // a few workgroups, one slice of the tiles each, three atomics per workgroup into words k_tile_fill / k_pencil_fill zeroed
+  // a few workgroups, one slice of the tiles each, three atomics per workgroup into words k_pencil_fill zeroed
   // (one workgroup walking all 32 k tiles took 20 us)
   __shared__ int s_a[16], s_b[16];
   if(blockIdx.x == 0 && threadIdx.x == 0) *(long long*)(flags + 60) = wall_clock64();                   // end of the build phase (see k_bin_count)
@@ -1921,7 +1629,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
 {
   if(!h || !h->neigh_ready) { mmd_set_error("mmd_neighbor_build: call mmd_neighbor_setup first"); return -1; }
   HIP_TRY(hipSetDevice(h->device));
-  if(h->nghost_dev && !(h->opt_tiles && h->opt_build == 1 && h->nlocal > 0)) {       // only k_build_rows reads the deferred count
+  if(h->nghost_dev && !(h->opt_tiles && h->nlocal > 0)) {       // only k_build_rows reads the deferred count
     const int rc = mmd_borders_deferred_resolve(h);
     if(rc < 0) return rc;
   }
@@ -1929,7 +1637,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   const int nwaves = div_up(nlocal, 64);
   const BinGeom& g = h->bg;
   // (re-neighborings inside a run with the production build: the binning pass also collects what k_pencil_count would — one dependent launch less)
-  h->pencil_lohi_req = h->opt_tiles && nlocal > 0 && h->opt_build == 1 && h->opt_async_counts && h->ntiles_hint > 0 && h->opt_fold_pencil;
+  h->pencil_lohi_req = h->opt_tiles && nlocal > 0 && h->ntiles_hint > 0;
   MMD_TRY(mmd_bin_atoms(h, -1));
   MMD_TRY(h->numneigh.ensure((size_t)nlocal + 64, false, h->stream));
   const int nblocks = g.nblk[0] * g.nblk[1] * g.nblk[2];
@@ -1938,25 +1646,21 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
   h->rows_ready = false;
   h->rows_uploaded = false;
   h->neigh_nlocal = 0;
-  // ---- tile form: block-local 16-bit rows + per-tile candidate union, see k_build_tiles
+  // ---- tile form: 16-bit rows of LDS record offsets + per-tile candidate union, see k_build_rows
   bool want_tiles = h->opt_tiles && nlocal > 0;
   if(want_tiles) {
-    // production build: pencil tiles (64-atom pieces of a row of blocks); the candidate-per-lane build keeps one tile per block
-    const bool pencil = h->opt_build == 1;
-    const int nunits = pencil ? g.nblk[1] * g.nblk[2] : nblocks;
+    // pencil tiles: 64-atom pieces of a row of blocks
+    const int nunits = g.nblk[1] * g.nblk[2];
     MMD_TRY(h->tile_of_block.ensure((size_t)nblocks + 2, false, h->stream));
-    const bool lohi = pencil && h->pencil_lohi_ready && h->opt_async_counts && h->ntiles_hint > 0;           // (k_bin_sort collected the pencils' owned bins: no k_pencil_count)
+    const bool lohi = h->pencil_lohi_ready && h->ntiles_hint > 0;           // (k_bin_sort collected the pencils' owned bins: no k_pencil_count)
     h->pencil_lohi_ready = false;
-    if(pencil) {
-      MMD_TRY(h->pencil_range.ensure((size_t)2 * nunits + 2, false, h->stream));
-      if(!lohi) hipLaunchKernelGGL(k_pencil_count, dim3(nunits), dim3(64), 0, h->stream, h->binned.p, h->bin_start.p, nunits, g.nblk[0], nlocal, h->tile_of_block.p, h->pencil_range.p);
-    } else
-    hipLaunchKernelGGL(k_tile_count, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->binned.p, h->bin_start.p, nblocks, nlocal, h->tile_of_block.p);
+    MMD_TRY(h->pencil_range.ensure((size_t)2 * nunits + 2, false, h->stream));
+    if(!lohi) hipLaunchKernelGGL(k_pencil_count, dim3(nunits), dim3(64), 0, h->stream, h->binned.p, h->bin_start.p, nunits, g.nblk[0], nlocal, h->tile_of_block.p, h->pencil_range.p);
     // the tile count sizes the lists. Once a build has succeeded the previous count (+3 %) does that and the count itself
     // comes back with the build's result flags: one host synchronisation less per re-neighboring
     int nt = 0;
-    const bool nt_async = h->opt_build == 1 && h->opt_async_counts && h->ntiles_hint > 0;
-    const bool fill_scans = nt_async && pencil;           // (the fill kernel sums the counts itself: no scan launch)
+    const bool nt_async = h->ntiles_hint > 0;
+    const bool fill_scans = nt_async;           // (the fill kernel sums the counts itself: no scan launch)
     if(!fill_scans) MMD_TRY(mmd_exclusive_scan(h, h->tile_of_block.p, nunits, nt_async ? nullptr : &nt));
     if(nt_async) nt = h->ntiles_hint + h->ntiles_hint / 32 + 64;
     const int* nt_dev = nt_async ? h->tile_of_block.p + nunits : nullptr;
@@ -1978,7 +1682,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       h->core.margin = (real)((double)h->opt_core_pct * 0.01 * ((double)h->cutneigh - cutforce));
       if(h->core.margin > 0) h->core.radius = (real)(cutforce + (double)h->core.margin);
     }
-    const bool core_rows = h->opt_build == 1 && !h->halfneigh && h->core.radius > 0;
+    const bool core_rows = !h->halfneigh && h->core.radius > 0;
     float core_thr = 0;
     if(core_rows) {
       // classification threshold in the frame of the build's float pre-test (positions relative to the tile corner): 2^-19 of
@@ -1993,7 +1697,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     }
     h->core.rows_built = false;
     // (the hit words of a tile wait in registers; only the two-list core/rest rows of EAM still park them in this scratch)
-    if(h->opt_build == 1) MMD_TRY(h->tile_words.ensure((NB2_REGPARK && !core_rows) ? (size_t)64 : (size_t)nt * NB2_NG * 64 * 2 + 64, false, h->stream));
+    MMD_TRY(h->tile_words.ensure((NB2_REGPARK && !core_rows) ? (size_t)64 : (size_t)nt * NB2_NG * 64 * 2 + 64, false, h->stream));
     if(h->halfneigh) MMD_TRY(h->tile_self.ensure((size_t)nt * 64 + 64, false, h->stream));
     h->tile_cstride = NB_CHUNKS * 64 + 64;      // + room for the closing dummy entry, rows stay 256-byte aligned
     MMD_TRY(h->tile_cand.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
@@ -2001,7 +1705,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     // then stage ghosts from their owners' current positions without a look-up: GhostResolve, tile_lds.hpp)
     int* cand_src_p = nullptr;
     h->cand_src_ready = false;
-    if(h->opt_build == 1 && h->opt_ghost_resolve && (h->style == 0 || (h->eam_uniform && !h->halfneigh)) && h->nprocs == 1 && !h->opt_force_transport && (h->nghost_dev != nullptr || h->ghost_chain_ok) &&
+    if(h->opt_ghost_resolve && (h->style == 0 || (h->eam_uniform && !h->halfneigh)) && h->nprocs == 1 && !h->opt_force_transport && (h->nghost_dev != nullptr || h->ghost_chain_ok) &&
        !h->ghosts_uploaded && nlocal + h->nghost < (1 << MMD_SRC_BITS) && h->ghost_root.p != nullptr) {
       MMD_TRY(h->tile_cand_src.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
       cand_src_p = h->tile_cand_src.p;
@@ -2011,7 +1715,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     const int* src_root = (const int*)h->ghost_root.p;
     const int* src_image = (const int*)h->ghost_image.p;
     h->cand_src_halo = false;
-    if(cand_src_p == nullptr && h->dh.gmap_live && h->dh.opt_recv == 3 && h->opt_build == 1 && h->opt_ghost_resolve && h->style == 0 && !h->halfneigh && !h->ghosts_uploaded) {
+    if(cand_src_p == nullptr && h->dh.gmap_live && h->dh.opt_recv == 3 && h->opt_ghost_resolve && h->style == 0 && !h->halfneigh && !h->ghosts_uploaded) {
       MMD_TRY(h->tile_cand_src.ensure((size_t)nt * h->tile_cstride + 64, false, h->stream));
       cand_src_p = h->tile_cand_src.p;
       src_root = (const int*)h->dh.gmap.p; src_image = nullptr;
@@ -2020,29 +1724,15 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
     if(fill_scans)
       hipLaunchKernelGGL(k_pencil_fill_scan, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
                          h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev, lohi ? (const unsigned*)h->pencil_lohi.p : (const unsigned*)nullptr, (const int*)h->bin_start.p);
-    else if(pencil)
+    else
       hipLaunchKernelGGL(k_pencil_fill, dim3(div_up(nunits, 256)), dim3(256), 0, h->stream, h->pencil_range.p, nunits, g.nblk[0], h->tile_of_block.p, h->tile_block.p, h->tile_first.p,
                          h->tile_cnt.p, h->d_flags, nt, h->x.p, nlocal, h->nghost, h->nghost_dev);
-    else
-    hipLaunchKernelGGL(k_tile_fill, dim3(div_up(nblocks, 256)), dim3(256), 0, h->stream, h->bin_start.p, nblocks, h->tile_of_block.p, h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->d_flags, nt,
-                       h->x.p, nlocal, h->nghost, h->nghost_dev);
     HIP_TRY(hipGetLastError());
     bool order_here = false, reduce_in_publish = false;
     for(int attempt = 0; attempt < 8 && want_tiles; attempt++) {
       MMD_TRY(h->nl16.ensure((size_t)h->ntiles * h->maxneighs * 64 + 16 * 64, false, h->stream));   // (+ prefetch overrun of the last tile)
-      if(h->opt_build == 1 && attempt > 0) HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));     // (a relaunch with longer rows: k_pencil_fill's zeroes are used up)
-      if(h->opt_build != 1) {             // (the production kernel needs no zeroing: k_tile_fill / k_pencil_fill zero what it and k_tile_reduce accumulate)
-        HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));
-        HIP_TRY(hipMemsetAsync(h->d_result, 0, sizeof(double), h->stream));
-      }
-      const size_t lds = (size_t)h->maxneighs * 64 * sizeof(unsigned short);
+      if(attempt > 0) HIP_TRY(hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), h->stream));     // (a relaunch with longer rows: k_pencil_fill's zeroes are used up; the first launch needs no zeroing)
       const int tmode = !h->halfneigh ? 0 : (h->ghost_newton ? 2 : 1);
-#define LAUNCH_TILES(M)                                                                                                                 \
-  hipLaunchKernelGGL(k_build_tiles<M>, dim3(xcd_grid(nblocks)), dim3(64), lds, h->stream, h->x.p, h->binned.p, h->bin_start.p,          \
-                     h->ghost_image.p, g, nblocks, nlocal, nlocal + h->nghost, h->cutneighsq, h->maxneighs, h->tile_cstride,             \
-                     h->tile_of_block.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p, h->tile_max.p, h->tile_ghost.p,      \
-                     h->tile_self.p,                                                                                                     \
-                     h->d_flags, (unsigned long long*)h->d_result, h->opt_ablate)
 #define LAUNCH_ROWS(M) LAUNCH_ROWS2(M, 0)
 #define LAUNCH_ROWS2(M, CR)                                                                                                             \
   hipLaunchKernelGGL((k_build_rows<M, CR>), dim3(xcd_grid(h->ntiles)), dim3(64), 0, h->stream, h->x.p, h->binned.p, h->bin_start.p,     \
@@ -2050,9 +1740,9 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
                      h->tile_block.p, h->tile_first.p, h->tile_cnt.p, h->numneigh.p, h->nl16.p, h->tile_cand.p, h->tile_ncand.p,         \
                      h->tile_max.p, h->tile_ghost.p, h->tile_self.p, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_words.p, h->d_flags, h->opt_ablate, nt_dev, h->nghost_dev, \
                      core_thr, h->xbuild.p, h->tile_kcore.p, cand_src_p, src_root, h->style == 1 ? 1 : 0)
-      if(h->opt_build == 1) {             // one owned atom per lane (production)
+      {
         if(tmode == 0 && core_rows) LAUNCH_ROWS2(0, 1); else if(tmode == 0) LAUNCH_ROWS(0); else if(tmode == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
-        reduce_in_publish = h->opt_spin_readback && h->in_run && h->ntiles <= 4096;
+        reduce_in_publish = h->in_run && h->ntiles <= 4096;
         if(!reduce_in_publish)
         hipLaunchKernelGGL(k_tile_reduce, dim3(std::min(32, std::max(1, div_up(h->ntiles, 1024)))), dim3(1024), 0, h->stream, h->tile_rowmax.p, h->tile_rowsum.p, h->tile_ncand.p, h->ntiles,
                            h->d_flags, (unsigned long long*)(h->d_flags + 4), nt_dev, h->nghost_dev ? (const int*)h->bstate.p : (const int*)nullptr);
@@ -2064,15 +1754,9 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
           hipLaunchKernelGGL(k_tile_order_count, dim3(nb_o), dim3(256), 0, h->stream, h->tile_ghost.p, h->ntiles, nt_dev, h->flag_tmp.p);
           hipLaunchKernelGGL(k_tile_order_scatter, dim3(nb_o), dim3(256), 0, h->stream, h->tile_ghost.p, h->ntiles, nt_dev, h->flag_tmp.p, h->tile_order.p, h->d_flags);
         }
-      } else if(lds > 64 * 1024) {        // the candidate-per-lane form keeps maxneighs x 64 raw slots in LDS
-        want_tiles = false;
-        break;
-      } else {
-        if(tmode == 0) LAUNCH_TILES(0); else if(tmode == 1) LAUNCH_TILES(1); else LAUNCH_TILES(2);
       }
 #undef LAUNCH_ROWS
 #undef LAUNCH_ROWS2
-#undef LAUNCH_TILES
       HIP_TRY(hipGetLastError());
       // [0..3] results, [4..5] total, [6] tile count, [12] long-bin flag, [16..55] bst of a deferred one-rank borders
       int spec_cmax_used = 0, spec_calls_before = 0;
@@ -2080,7 +1764,7 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
       long long spec_ctr_before = 0;
       int verdict = 0;                    // 1: this step's Force::compute was launched behind the build and the build's verdict let it run
       bool spec_go = false;
-      if(h->opt_build == 1 && h->opt_spin_readback && h->in_run) {
+      if(h->in_run) {
         // inside Integrate::run the build's results are PUBLISHED into pinned host memory by a one-wavefront kernel and the host polls that
         // memory: a blocking stream wait costs the wake-up of a sleeping thread (~40 us between the copy and the next force kernel)
         // Force::compute of this step goes onto the stream BEFORE the host has the words (SpecLaunch, mmd_internal.hpp): sized for the
@@ -2125,10 +1809,9 @@ extern "C" int mmd_neighbor_build(mmd_handle* h)
         }
       } else {
       HIP_TRY(hipMemcpyAsync(h->h_flags, h->d_flags, (h->nghost_dev ? 56 : 16) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      if(h->opt_build != 1) HIP_TRY(hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(mmd_stream_sync(h));
       }
-      if(h->opt_build == 1) memcpy(h->h_result, h->h_flags + 4, sizeof(double));
+      memcpy(h->h_result, h->h_flags + 4, sizeof(double));
       // (a verdict of 1 means the gated force kernel is running on these lists: every rule below that sends the build around again is part
       //  of the verdict, so none of them can fire then — if one does, the two have come apart and the run must not go on)
 #define NB_REDO_GUARD() if(verdict) { mmd_set_error("neighbor build: verdict of the device and rules of the host disagree"); return -1; }
@@ -2570,7 +2253,7 @@ static int tiles_from_rows(mmd_handle* h)
   h->tiles_ready = false;
   h->cand_src_ready = false;
   const int nlocal = h->nlocal, nall = h->nlocal + h->nghost;
-  if(!h->opt_tiles || !h->opt_upload_tiles || !h->neigh_ready || nlocal == 0 || h->opt_build != 1) return 0;
+  if(!h->opt_tiles || !h->neigh_ready || nlocal == 0) return 0;
   const BinGeom& g = h->bg;
   if((2 * g.reach[1] + 1) * (2 * g.reach[2] + 1) > NB_MAX_ROWS) return 0;
   MMD_TRY(mmd_bin_atoms(h, -1));

@@ -149,7 +149,7 @@ __global__ void k_set_dummy(real4* x, int slot)
   x[slot] = real4{(real)1.0e15, (real)1.0e15, (real)1.0e15, (real)0};
 }
 
-int mmd_prepare_x_alt(mmd_handle* h, bool kernel_writes_dummy)
+int mmd_prepare_x_alt(mmd_handle* h)
 {
   MMD_TRY(h->x_alt.ensure((size_t)h->nmax + 1, false, h->stream));
   const int slot = h->nlocal + h->nghost;
@@ -159,12 +159,7 @@ int mmd_prepare_x_alt(mmd_handle* h, bool kernel_writes_dummy)
   if(q < 0) { q = h->xalt_dummy_next; h->xalt_dummy_next ^= 1; h->xalt_dummy_ptr[q] = h->x_alt.p; h->xalt_dummy_slot[q] = -1; }
   // (a launch behind the neighbor build: the ghost count is still on the device, the gated kernel writes the dummy atom itself)
   if(h->spec.gate != nullptr) { h->xalt_dummy_slot[q] = -1; return 0; }
-  if(kernel_writes_dummy) { h->xalt_dummy_slot[q] = slot; return 0; }       // (the fused force kernels do, with the rest of the buffer)
-  if(h->xalt_dummy_slot[q] != slot) {
-    hipLaunchKernelGGL(k_set_dummy, dim3(1), dim3(1), 0, h->stream, h->x_alt.p, slot);
-    HIP_TRY(hipGetLastError());
-    h->xalt_dummy_slot[q] = slot;
-  }
+  h->xalt_dummy_slot[q] = slot;             // (the fused force kernels write the dummy atom with the rest of the buffer they fill)
   return 0;
 }
 

@@ -102,7 +102,7 @@ def test_eam_force_half_matches_oracle(size, ntypes):
     assert np.abs(h.eam_fp() - fpo).max() <= 1e-12 * np.abs(fpo).max()
     eng3, vir3 = h.force_compute(0)                                   # (no energy/virial: another instantiation)
     assert np.abs(h.download(halfneigh=True)["f"] - fo).max() <= 1e-11 * np.abs(fo).max()
-    h.set_option("eam_half_rows", 1)                                  # the row kernels on the device-built list
+    h.set_option("tiles", 0)                                          # the row kernels on the device-built list
     eng4, vir4 = h.force_compute(1)
     assert abs(eng4 - eng) <= 1e-12 * abs(eng) and np.abs(h.download(halfneigh=True)["f"] - fo).max() <= 1e-11 * np.abs(fo).max()
     h.close(); o.close()
@@ -182,12 +182,12 @@ def test_run_lj_half_rows_match_reference(name):
     s.close()
 
 
-@pytest.mark.parametrize("build", [1, 0, -1])
+@pytest.mark.parametrize("build", [1, -1])
 def test_half_gn1_device_list_pairs_once(build):
     """our ghost-newton partitions (tiles: every pair on its lower atom in (z,y,x) order; row builders: owned j > i, ghosts by
     that order) differ from the reference's half-stencil bin rule (ref/neighbor.cpp:150-170 + its half stencil) but must store
     each pair once: the half-list forces after reverse communication equal the full-list forces, the list holds half the
-    full list's entries. build 1 = k_build_rows, 0 = k_build_tiles, -1 = k_build (no tiles)."""
+    full list's entries. build 1 = k_build_rows (tile form), -1 = k_build (option tiles 0: global rows)."""
     o = Oracle(["-s", 6, "-n", 20, "--half_neigh", 0])
     o.initial(); o.run()
     fo = o.f()
@@ -202,8 +202,6 @@ def test_half_gn1_device_list_pairs_once(build):
     h.force_lj_setup(*o.lj_tables())
     if build < 0:
         h.set_option("tiles", 0)
-    else:
-        h.set_option("build", build)
     h.exchange(); h.borders(); h.neighbor_build()
     assert h.neighbor_info()["total"] * 2 == int(o.numneigh().sum())
     nb, nn = h.neighbor_download()                    # the downloaded rows hold every pair once, too (tile builds: in the reference's partition)
@@ -495,7 +493,6 @@ def test_eam_ghosts_staged_from_their_owners_equal_the_halos(args, prec):
     for mode in (0, 1):
         s = m.Sim(["-i", "in.eam.miniMD"] + args + ["-n", 60, "--half_neigh", 0], precision=prec)
         s.handle.set_option("ghost_resolve", mode)
-        s.handle.set_option("eam_fold_fp", 0)
         s.initial(); s.run()
         d = s.handle.download()
         out[mode] = (s.rows(), d["x"].copy(), d["v"].copy(), d["f"].copy())
@@ -529,28 +526,27 @@ def test_reverse_communicate_folded_into_the_half_kernel(args):
 @pytest.mark.parametrize("half", [0, 1])
 def test_reneighboring_with_counts_left_on_the_device(half):
     """inside Integrate::run a one-rank re-neighboring reads no count before the neighbor build has run: list sizes come from the
-    previous build, the ghost and tile counts return with the build's result flags (option async_counts). Same rows, same final
-    state as the synchronous path; with estimates that are too small (borders_est 60 %) the swap-by-swap path redoes the borders."""
+    previous build, the ghost and tile counts return with the build's result flags. With estimates that are too small (borders_est 60 %) the
+    swap-by-swap path redoes the borders and the build runs again: same rows, same final state."""
     m = mm()
     out = {}
-    for mode in ("sync", "async", "async_overflow"):
+    for mode in ("async", "async_overflow"):
         s = m.Sim(["-s", 14, "-n", 100, "--half_neigh", half])
-        s.handle.set_option("async_counts", 0 if mode == "sync" else 1)
         if mode == "async_overflow":
             s.handle.set_option("borders_est", 60)
         s.initial(); s.run()
         d = s.handle.download()
         nl, ng, _ = s.handle.counts()
-        out[mode] = (s.rows(), nl, ng, s.handle.neighbor_info()["total"], d["x"][:nl].copy(), d["tag"].copy())
+        out[mode] = (s.rows(), nl, ng, s.handle.neighbor_info()["total"], d["x"][:nl].copy(), d["tag"].copy(), s.handle.counter("borders_general"))
         s.close()
-    for mode in ("async", "async_overflow"):
-        assert out[mode][1:4] == out["sync"][1:4]
-        if half:
-            rows_close(out[mode][0], out["sync"][0], 1e-10)          # (atomics: summation order)
-        else:
-            assert out[mode][0] == out["sync"][0]
-            np.testing.assert_array_equal(out[mode][4], out["sync"][4])
-            np.testing.assert_array_equal(out[mode][5], out["sync"][5])
+    assert out["async_overflow"][6] > out["async"][6]                # (the fall-back really ran)
+    assert out["async_overflow"][1:4] == out["async"][1:4]
+    if half:
+        rows_close(out["async_overflow"][0], out["async"][0], 1e-10)          # (atomics: summation order)
+    else:
+        assert out["async_overflow"][0] == out["async"][0]
+        np.testing.assert_array_equal(out["async_overflow"][4], out["async"][4])
+        np.testing.assert_array_equal(out["async_overflow"][5], out["async"][5])
 
 
 def test_eam_rows_in_two_parts_give_the_same_run():
@@ -1000,14 +996,14 @@ def test_integrator_inside_the_force_kernel_is_bit_identical(prec, deck):
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_final_integrate_inside_the_last_force_launch(prec):
-    """option fuse_final (default on): the last step of a run has no next step to fuse initialIntegrate with; its LJ tile force launch still carries
-    finalIntegrate (v += dtf f with the force in registers) and stores the forces — no k_final_integrate pass behind it. Same bits as the separate
-    kernel (ref/integrate.cpp:59-68), for a run cut into slices of 1, 7 and 20 steps (every slice ends with such a step; the re-neighboring at step 20
-    is the last step of a slice once, launched behind the build) and in one piece."""
+    """the last step of a run has no next step to fuse initialIntegrate with; its LJ tile force launch still carries finalIntegrate (v += dtf f with the
+    force in registers) and stores the forces — no k_final_integrate pass behind it. Same bits as the separate kernels (option fuse 1: ref/integrate.cpp:59-68
+    as launches of their own), for a run cut into slices of 1, 7 and 20 steps (every slice ends with such a step; the re-neighboring at step 20 is the last
+    step of a slice once, launched behind the build) and in one piece."""
     res = []
-    for ff, cuts in ((0, [47]), (1, [47]), (1, [1, 6, 13, 20, 7])):
+    for fuse, cuts in ((1, [47]), (2, [47]), (2, [1, 6, 13, 20, 7])):
         s = mm().Sim(["-s", "12", "-n", "47", "--half_neigh", "0"], precision=prec)
-        s.handle.set_option("fuse_final", ff)
+        s.handle.set_option("fuse", fuse)
         s.initial()
         for c in cuts:
             s.run_steps(c)
@@ -1023,49 +1019,21 @@ def test_final_integrate_inside_the_last_force_launch(prec):
 @pytest.mark.parametrize("args", [["-s", "14", "-n", "130", "--half_neigh", "0"], ["-s", "12", "-n", "90", "--half_neigh", "1"],
                                   ["-i", "in.eam.miniMD", "-s", "8", "-n", "70", "--half_neigh", "0"], ["-s", "6", "-b", "1", "-n", "50", "--half_neigh", "0"]])
 def test_build_binning_that_places_the_ghosts_only(args):
-    """option bin_reuse (default on): inside a re-neighboring the owned atoms are in bin order once Atom::sort has run, and the histogram still holds their
-    counts; the build's Neighbor::binatoms (ref/neighbor.cpp:215-268) then counts and places the ghosts only and writes the owned part of every bin from
-    the sort's bin starts. The same `binned`, so the same lists and the same bits as binning everything again (bin_reuse 0): full and half lists, EAM,
-    and `-b 1` (every atom in one bin: the long-bin path, which never reuses)."""
-    res = []
-    for br in (0, 1):
-        s = mm().Sim(args)
-        s.handle.set_option("bin_reuse", br)
-        s.initial(); s.run()
-        d = s.handle.download()
-        res.append((s.rows(), d["x"][:d["nlocal"]].copy(), d["v"].copy(), d["tag"].copy(), s.handle.neighbor_info()["total"], s.handle.counter("bin_reuses")))
-        s.close()
-    assert res[0][5] == 0
-    if "-b" in args:
-        assert res[1][5] == 0
-    else:
-        assert res[1][5] >= 3
-    assert res[0][4] == res[1][4]
-    if args[-1] == "1" and "--half_neigh" in args:            # (half lists: the forces are sums of atomics, equal to their order)
-        rows_close(res[0][0], res[1][0], 1e-10)
-        assert np.array_equal(res[0][3], res[1][3]) and np.allclose(res[0][1], res[1][1], rtol=0, atol=1e-9)
-    else:
-        assert res[0][0] == res[1][0]
-        for a_, b_ in zip(res[0][1:4], res[1][1:4]):
-            assert np.array_equal(a_, b_)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("args", [["-s", "12", "-n", "90", "--half_neigh", "0"], ["-i", "in.eam.miniMD", "-s", "8", "-n", "70", "--half_neigh", "0"]])
-def test_dummy_atom_written_by_the_fused_kernels(args):
-    """option kernel_dummy (default on): a fused force + integrate launch writes the dummy atom (the far-away partner of the padded list entries) of the
-    position buffer it fills; with 0 a k_set_dummy launch does, whenever a re-neighboring has moved the slot behind the last ghost. Same bits either way
-    over several re-neighborings (the ghost count changes at each of them), LJ and EAM."""
-    res = []
-    for kd in (0, 1):
-        s = mm().Sim(args)
-        s.handle.set_option("kernel_dummy", kd)
-        s.initial(); s.run()
-        d = s.handle.download()
-        res.append((s.rows(), d["x"][:d["nlocal"]].copy(), d["v"].copy()))
-        s.close()
-    assert res[0][0] == res[1][0]
-    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    """inside a re-neighboring the owned atoms are in bin order once Atom::sort has run, and the histogram still holds their counts; the build's
+    Neighbor::binatoms (ref/neighbor.cpp:215-268) then counts and places the ghosts only and writes the owned part of every bin from the sort's bin starts
+    (counter bin_reuses; `-b 1` = every atom in one bin: the long-bin path, which never reuses). The lists are those of binning everything: thermo rows and
+    neighbor totals of the oracle (round 4 compared the two binnings bit for bit while both existed)."""
+    s = mm().Sim(args)
+    s.initial(); s.run()
+    reuses, total = s.handle.counter("bin_reuses"), s.handle.neighbor_info()["total"]
+    rows = s.rows()
+    s.close()
+    assert reuses == 0 if "-b" in args else reuses >= 3
+    o = Oracle(args)
+    o.initial(); o.run()
+    assert total == int(o.numneigh().sum())
+    rows_close(rows, o.rows(), 1e-9)
+    o.close()
 
 
 @pytest.mark.gpu

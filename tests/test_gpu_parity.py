@@ -68,16 +68,14 @@ def test_lj_force_full_matches_oracle(size, ntypes):
     assert h.counter("tiles_ready") == 1 and h.counter("rows_uploaded") == 1 and h.neighbor_tile_stats()["tiles"] > 0
     for tiles in (1, 0):
         h.set_option("tiles", tiles)
-        for exact in (0, 1):
-            h.set_option("exact_div", exact)
-            eng, vir = h.force_compute(1)
-            f = h.download()["f"]
-            fo = o.f()
-            scale = np.abs(fo).max()
-            # tolerance: 1e-12 of the largest force component (FMA + Newton reciprocal vs strict IEEE order)
-            assert np.abs(f - fo).max() <= 1e-12 * scale
-            assert abs(eng - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl())
-            assert abs(vir - o.virial()) <= 1e-11 * max(1.0, abs(o.virial()))
+        eng, vir = h.force_compute(1)
+        f = h.download()["f"]
+        fo = o.f()
+        scale = np.abs(fo).max()
+        # tolerance: 1e-12 of the largest force component (FMA + Newton reciprocal vs strict IEEE order)
+        assert np.abs(f - fo).max() <= 1e-12 * scale
+        assert abs(eng - o.eng_vdwl()) <= 1e-12 * abs(o.eng_vdwl())
+        assert abs(vir - o.virial()) <= 1e-11 * max(1.0, abs(o.virial()))
     # what went in comes back out (rows as the reference has them, in its order)
     nb2, nn2 = h.neighbor_download()
     np.testing.assert_array_equal(nn2, o.numneigh())

@@ -15,25 +15,47 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(REPO, "tests", "golden")
 
 
-@pytest.mark.parametrize("prec", ["dp", "sp"])
-def test_every_tile_read_form_runs_to_the_last_step(prec):
-    """option tile_read 0..3 of the LJ full-list tile kernel (one reciprocal per pair / per four pairs, paired / separate LDS reads): the last step of a
-    run carries finalIntegrate inside the force launch (fuse_final), which needs the (tile_read, FUSE = 2) instantiation — tile_read 0 had none (round-4
-    advisor finding) and Integrate::run failed on its last step. Every form runs 47 steps in slices (each slice ends with such a step) and lands on the
-    same thermo rows (the forms differ in rounding only: ref/force_lj.cpp:366-449 computes the same pair terms)."""
-    rows = []
-    for rd in (3, 2, 1, 0):
-        s = mm().Sim(["-s", "10", "-n", "47", "--half_neigh", "0"], precision=prec)
-        s.handle.set_option("tile_read", rd)
+# every option mmd_set_option still knows that changes HOW a one-rank run is computed, never what: each legal value runs to the last step (sliced, so that
+# every slice ends with a finalIntegrate-only launch) and lands on the default's rows. (Round 6 cut the table from 40 entries to 20: what lost its A/B is gone —
+# tile_read, tile_waves, tile_unroll, exact_div, build 0, fuse_final, kernel_dummy, bin_reuse, async_counts, spin_readback, borders_fast, overlap_join, halo_recv 2, ...;
+# the remaining multi-rank knobs — overlap, direct_halo, direct_borders, halo_recv, borders_est, exchange_cap, force_transport, safe_exchange — have their tests below and
+# in test_gpu_more.py, maxneighs / eam_mlo / lj_original / check_exchange theirs in test_gpu_parity.py / test_gpu_more.py.)
+ONE_RANK_KNOBS = [("tiles", [0, 1]), ("fuse", [0, 1, 2]), ("ghost_resolve", [0, 1, 2]), ("spec", [0, 1, 16]), ("time_force_sample", [1, 3, 7]), ("check_exchange", [0, 1]),
+                  ("fold_reverse", [0, 1]), ("core_pct", [0, 2, 30])]
+
+
+@pytest.mark.parametrize("knob,values", ONE_RANK_KNOBS)
+def test_every_value_of_every_one_rank_knob_lands_on_the_defaults_rows(knob, values):
+    deck, half = ("in.eam.miniMD", 0) if knob == "core_pct" else ("in.lj.miniMD", 1 if knob == "fold_reverse" else 0)
+    args = ["-i", deck, "-s", "8" if "eam" in deck else "10", "-n", "47", "--half_neigh", str(half)]
+
+    def run(opt):
+        s = mm().Sim(args)
+        for k, v in opt.items():
+            s.handle.set_option(k, v)
         s.initial()
         for c in (1, 6, 20, 20):
             s.run_steps(c)
         s.handle.force_compute(1)
         d = s.handle.download()
-        rows.append((s.rows(), d["x"][:d["nlocal"]].copy()))
+        out = (s.rows(), d["x"][:d["nlocal"]].copy())
         s.close()
-    for other in rows[1:]:
-        assert np.allclose(rows[0][1], other[1], rtol=0, atol=1e-9 if prec == "dp" else 2e-3)
+        return out
+    base = run({})
+    for v in values:
+        got = run({knob: v})
+        # same physics: bit-identical where the summation order is the same, to rounding where it is not (half lists: atomics; core_pct: the order of a row's pairs)
+        assert [r[0] for r in got[0]] == [r[0] for r in base[0]]
+        rows_close(got[0], base[0], 1e-9)
+        assert np.allclose(got[1], base[1], rtol=0, atol=1e-8), (knob, v)
+
+
+def test_unknown_and_illegal_option_values_are_errors():
+    h = mm().Handle()
+    for name, v in (("tile_read", 0), ("build", 0), ("exact_div", 1), ("halo_recv", 2), ("no_such_option", 1)):
+        with pytest.raises(Exception):
+            h.set_option(name, v)
+    h.close()
 
 
 # ---- the launcher contract of the drop-in executable (ref/run_one_test:50, ref/ljs.cpp:63-68) ---------------------------------------------------
@@ -128,11 +150,11 @@ def _loopback(args, options, prec="dp"):
 
 
 @pytest.mark.parametrize("deck,half,gn", [("in.lj.miniMD", 0, 0), ("in.lj.miniMD", 1, 1), ("in.lj.miniMD", 1, 0), ("in.eam.miniMD", 0, 0)])
-@pytest.mark.parametrize("recv", [1, 2, 3])
+@pytest.mark.parametrize("recv", [1, 3])
 def test_direct_borders_equal_the_swap_by_swap_borders(deck, half, gn, recv):
     """option direct_borders (default on): from the second re-neighboring of a run on, the ghosts of a rank are made by ONE exchange of the 26 image lists
     (every owner decides from its own coordinates which later swaps forward its atoms) instead of the three dependent forwarding rounds of
-    ref/comm.cpp:700-883; halo_recv 2 receives every list of the per-step halo straight into its ghost slots; halo_recv 3 (default) leaves the partners'
+    ref/comm.cpp:700-883; halo_recv 1 unpacks the per-step halo with a kernel of its own; halo_recv 3 (default) leaves the partners'
     messages where they land, behind the ghost slots of the position buffer, and the LJ full-list force kernel stages the boundary tiles' ghosts from there
     (no k_dh_unpack on the step; the ghost slots are brought up to date when the run ends). Same ghosts in the same slots with the same
     positions, the same swap counts and — derived on demand from the slab bits that travelled along — the same six send lists; so the same rows, positions
@@ -225,11 +247,11 @@ def test_overlap_chosen_by_measurement_changes_nothing(deck, half):
 @pytest.mark.parametrize("prec", ["dp", "sp"])
 def test_boundary_tiles_on_the_communication_stream_change_nothing(prec):
     """overlap 1 on several ranks, LJ over full lists (here: RCCL loop-back): the boundary tiles are launched on the communication stream right behind the transfer
-    (overlap_join 1, default: they run under the tail of the interior tiles and read the received records where they landed; the compute stream joins at the end of the
-    step) instead of on the compute stream behind a wait (overlap_join 0, round 4). Same bits as the run without overlap, thermo step included."""
+    (they run under the tail of the interior tiles and read the received records where they landed; the compute stream joins at the end of the step; a thermo step keeps
+    the boundary tiles on the compute stream behind a wait: its energy sum needs both launches finished). Same bits as the run without overlap, thermo step included."""
     args = ["-s", "14", "-n", "130", "--half_neigh", "0"]
     res = {}
-    for name, opts in (("none", {"overlap": 0}), ("join", {"overlap": 1}), ("split", {"overlap": 1, "overlap_join": 0})):
+    for name, opts in (("none", {"overlap": 0}), ("join", {"overlap": 1})):
         s = mm().Sim(args, precision=prec)
         h = s.handle
         h.init_rccl(h.unique_id(), 0, 1)
@@ -240,9 +262,9 @@ def test_boundary_tiles_on_the_communication_stream_change_nothing(prec):
         d = h.download()
         res[name] = (s.rows(), d["x"].copy(), d["v"].copy(), d["f"].copy(), h.counter("overlap_join_steps"), h.counter("halo_in_x_steps"))
         s.close()
-    assert res["none"][4] == 0 and res["split"][4] == 0 and res["join"][4] > 100, [r[4:] for r in res.values()]
+    assert res["none"][4] == 0 and res["join"][4] > 100, [r[4:] for r in res.values()]
     assert res["join"][5] > 80             # (from the second re-neighboring on the joined steps need no unpack kernel)
-    for other in ("join", "split"):
+    for other in ("join",):
         assert res["none"][0] == res[other][0]
         for a_, b_ in zip(res["none"][1:4], res[other][1:4]):
             np.testing.assert_array_equal(a_, b_)

@@ -237,8 +237,8 @@ def test_register_budgets_of_the_hot_kernels():
         m = [k for k in ks if k.startswith(prefix)]
         assert len(m) == 1, (prefix, m)
         return ks[m[0]]
-    for fuse in (0, 1, 2):        # k_lj_full_tile<0, false, 2, 8, 3, FUSE>: force only / fused integrator / fused finalIntegrate
-        k = one("_Z14k_lj_full_tileILi0ELb0ELi2ELi8ELi3ELi%dEE" % fuse)
+    for fuse in (0, 1, 2):        # k_lj_full_tile<0, FUSE>: force only / fused integrator / fused finalIntegrate
+        k = one("_Z14k_lj_full_tileILi0ELi%dEE" % fuse)
         assert k["vgpr"] <= 96 and k["agpr"] == 0, k
     b = one("_Z12k_build_rowsILi0ELi0EE")
     assert b["vgpr"] <= 128 and b["agpr"] == 0 and b["lds"] <= 10240, b      # (agpr == 0: the MFMA accumulators are read by VALU instructions, -amdgpu-mfma-vgpr-form)

@@ -32,7 +32,7 @@ rm -rf gpurun_out/tl80 gpurun_out/tl32
 bash tools/gpu_loopback_timeline.sh 80 -1 tllb > /dev/null 2>&1
 cp gpurun_out/tllb/timeline.txt $O/timeline_rank_path_loopback_s80.txt
 rm -rf gpurun_out/tllb
-timeout 400 python tools/loopback_probe.py 80 "overlap=-1" "overlap=0" "overlap=1" "overlap=0,halo_recv=1" "overlap=0,halo_recv=2" "overlap=0,direct_borders=0,halo_recv=1" 2>&1 | grep "^-s" > $O/rank_path_loopback.txt
+timeout 400 python tools/loopback_probe.py 80 "overlap=-1" "overlap=0" "overlap=1" "overlap=0,halo_recv=1" "overlap=0,direct_borders=0,halo_recv=1" 2>&1 | grep "^-s" > $O/rank_path_loopback.txt
 # host-side pricing of two proposals on real tile lists; Force::compute on rows re-ordered by distance
 { timeout 300 python tools/window_probe.py in.lj.miniMD 80 1; timeout 300 python tools/window_probe.py in.eam.miniMD 64 0; } 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostn\|^Libr" > $O/window_probe.txt
 { timeout 300 python tools/sorted_rows_probe.py in.eam.miniMD 64; timeout 300 python tools/sorted_rows_probe.py in.lj.miniMD 80; } 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostn\|^Libr" > $O/sorted_rows_probe.txt

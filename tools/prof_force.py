@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Quick A/B timing of the hot kernels on the BASELINE workload (hipEvents on the compute stream).
-usage: python tools/prof_force.py [--size 80] [--steps 100] [--opts tiles=0,exact_div=1]"""
+usage: python tools/prof_force.py [--size 80] [--steps 100] [--ab tiles]"""
 import argparse
 import os
 import sys
@@ -36,21 +36,6 @@ if a.ab:
         for v in (1, 0):
             h.set_option(a.ab, v)
             print("round %d  %s=%d  force %.4f ms" % (rnd, a.ab, v, h.profile_kernel(0, a.reps)))
-if os.environ.get("TILEREAD"):
-    for rnd in range(3):
-        for v in (0, 2):
-            h.set_option("tile_read", v)
-            print("round %d  tile_read=%d  force %.4f ms" % (rnd, v, h.profile_kernel(0, a.reps)))
-    h.set_option("tile_read", 0)
-if os.environ.get("BUILDKERNELS"):
-    # A/B of the two tile-build kernels (build=1: one owned atom per lane, build=0: one candidate per lane)
-    for rnd in range(2):
-        for v in (0, 1):
-            h.set_option("build", v)
-            h.neighbor_build()
-            print("round %d  build=%d  neighbor build %.4f ms   tile stats %s  total %d" % (
-                rnd, v, h.profile_kernel(1, 12), h.neighbor_tile_stats(), h.neighbor_info()["total"]))
-    print("force after build=1: %.4f ms" % h.profile_kernel(0, a.reps))
 if os.environ.get("BUILDABLATE"):
     for ab in (0, 1, 2, 0):
         h.set_option("ablate", ab)
@@ -66,13 +51,6 @@ if os.environ.get("BUILDAB"):
             print("ablate=%d failed: %s" % (ab, e))
     h.set_option("ablate", 0)
     h.neighbor_build()
-if os.environ.get("SHAPES"):
-    h.set_option("tiles", 1)
-    for rnd in range(2):
-        for w, u in ((4, 4), (2, 4), (1, 8), (4, 8), (2, 8)):
-            h.set_option("tile_waves", w); h.set_option("tile_unroll", u)
-            print("round %d waves=%d unroll=%d  tile force %.4f ms" % (rnd, w, u, h.profile_kernel(0, a.reps)))
-    h.set_option("tile_waves", 2); h.set_option("tile_unroll", 8)
 if os.environ.get("ABLATE"):
     h.set_option("tiles", 1)
     for ab in (0, 1, 2, 3, 4, 8, 24, 0):
