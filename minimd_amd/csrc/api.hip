@@ -326,8 +326,9 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
   const bool overlap_auto = h->opt_overlap < 0 && multi;          // (-1: the form is chosen by measurement, collectively: mmd_internal.hpp)
   bool overlap = (h->opt_overlap > 0 && (multi || h->opt_overlap >= 2)) || (overlap_auto && h->overlap_choice == 1);     // (2: also on one rank — the ghost update under the interior tiles)
   // the trial of the automatic choice: B steps with, B steps without overlap behind a re-neighboring, no thermo step and no re-neighboring among them
+  // (armed by a re-neighboring, kept in the handle: a caller that drives the run in slices ending on the re-neighboring step — bench.py's 20-step slices — still gets its trial,
+  //  in the slice that follows; round-5 advisor)
   int trial_phase = 0, trial_left = 0;
-  bool trial_armed = false;
   const int trial_B = std::min(8, (h->neigh_every - 2) / 2);
   bool halo_pending = false, collect_pending = false, ovf_timed_now = false, joined = false;
   int core_next = 0;                 // CoreRows: what the next force call may assume about the displacement since the build
@@ -382,8 +383,8 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
                            h->opt_tiles && !h->opt_check_exchange && h->lj_uniform;
   for(int n = 0; n < ntimes; n++) {
     if(overlap_auto && h->overlap_choice < 0) {
-      if(trial_phase == 0 && trial_armed) {
-        trial_armed = false;
+      if(trial_phase == 0 && h->trial_armed) {
+        h->trial_armed = false;
         // (nothing rank-local may enter this condition: the trial ends in a collective, every rank has to run it on the same steps — a rank whose lists are
         //  not in tile form simply does not overlap during its trial steps)
         bool ok = trial_B >= 2 && n + 2 * trial_B <= ntimes;
@@ -475,7 +476,7 @@ extern "C" int mmd_integrate_run(mmd_handle* h, int first_step, int ntimes, int 
       }
     } else {
       h->ghosts_stale = false;                   // (borders rebuilds every ghost)
-      trial_armed = true;
+      h->trial_armed = true;
       const bool had_tiles = h->tiles_ready && h->neigh_nlocal == h->nlocal && h->nlocal > 0;
       if(h->opt_check_exchange && h->xold_n == h->nlocal) {    // ref/integrate.cpp:112-151 (warning text as there)
         double d_max = 0;

@@ -82,7 +82,7 @@ extern "C" int mmd_comm_setup(mmd_handle* h, mmd_float cutneigh, int me, int npr
   h->swaps.clear();
   // a set-up on a handle that has run before: nothing sized from the previous decomposition may survive it — the fixed-size messages of the direct
   // borders / exchange are derived from the PREVIOUS counts on both sides of a pair, and the overlap choice was measured on the old grid
-  h->dh.prev_valid = false; h->dh.gmap_live = false; h->dh.ready = false; h->borders_general_done = false; h->ex_prev_valid = false; h->overlap_choice = -1;
+  h->dh.prev_valid = false; h->dh.gmap_live = false; h->dh.ready = false; h->borders_general_done = false; h->ex_prev_valid = false; h->overlap_choice = -1; h->trial_armed = false;
   for(int d = 0; d < 3; d++) {
     for(int ineed = 0; ineed < 2 * h->need[d]; ineed++) {
       Swap s;

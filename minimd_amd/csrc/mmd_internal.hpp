@@ -250,6 +250,7 @@ struct mmd_handle {
   // transfer can pay for it — in RCCL loop-back on one GPU it does not)
   int opt_overlap = -1;
   int overlap_choice = -1;           // -1 not decided yet, 0 / 1
+  bool trial_armed = false;          // a re-neighboring has run since the last trial attempt: the next plain stretch of 2 x 8 steps (in this or the next mmd_integrate_run) is timed
   // RCCL bring-up self-check (mmd_comm_init_rccl): distinct partners exchanged with, seconds it took, PCI bus id of this rank's device
   int rccl_check_partners = 0;
   double rccl_check_s = 0;

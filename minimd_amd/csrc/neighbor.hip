@@ -873,6 +873,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   bool mf_range_bad = false;
   if constexpr(MFK) {
     mf_range_bad = 3.0f * Lb * Lb > 30000.0f;                   // |b|^2 must stay a finite half
+    {
+      // soundness of the per-atom band (round-5 advisor): a pair whose exact d exceeds the TILE-wide bound has the right sign whatever the magnitudes; one below it must lie
+      // within cut' of its atom for E_i to cover it — i.e. the tile-wide bound itself has to stay below cut'^2 - cutneighsq. Long tiles of near-empty pencils
+      // (La beyond ~55 at cutneigh 2.8) do not: the row kernel builds those
+      const float cutp_t = 1.001f * (float)cutneigh + 0.01f, st = La + cutp_t;
+      const float T_tile = 3.0f * st * st + ((float)cutneighsq + 3.0f * La * La) + 6.0f * st * La + (float)cutneighsq;
+      mf_range_bad = mf_range_bad || 40.0f * 5.96046448e-08f * T_tile > cutp_t * cutp_t - (float)cutneighsq;
+    }
     const unsigned h0 = nb2_pack_h2(fxi, fyi), h1 = nb2_pack_h2(fzi, 1.0f);
     const nb2_f2 b0 = nb2_unpack_h2(h0), b1 = nb2_unpack_h2(h1);
     const float thf = owned ? (float)((double)cutneighsq - aa_d) : -60000.0f;
