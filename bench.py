@@ -366,6 +366,8 @@ def main():
     # sustained: ONE window of --sustained-steps steps (default 2000 = ~0.45 s at -s 80: 100 re-neighborings, 20 thermo rows — the reference's loop as its own
     # 1000 / 10 000-step logs run it), fenced like the others; the force kernel's device-clock span at its start, middle and end shows what the chip's clocks do
     sustained = None
+    if invalid_reason is not None:
+        args.sustained_steps = min(args.sustained_steps, 200)          # (debug transport, ranks sharing GPUs: tens of ms per step — the long window proves nothing there)
     if args.sustained_steps > 0:
         fence()
         ts0 = time.perf_counter()
@@ -413,7 +415,7 @@ def main():
     achieved = bpa * nlocal / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
     achieved_sampled = bpa * nlocal / (k_ms_sampled * 1e-3) / 1e9 if k_ms_sampled > 0 else None
     traffic, traffic_source = None, None
-    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if world == 1 and args.size == 80 and os.path.exists(tpath):
             # HBM bytes per launch of the same kernel on the same workload from the committed rocprofv3 --pmc passes

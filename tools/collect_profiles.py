@@ -77,9 +77,9 @@ def row(label, kernel, stats_file, natoms, bytes_per_atom, pmc_file=None, pmc_ke
 
 
 N80, N64, N160, N32 = 2048000, 1048576, 16384000, 131072
-row("B LJ full -s 80 DP (fused integrator)", "k_lj_full_tile<0, false, 2, 8, 3, 1>", "kernel_stats_bench.md", N80, rf["bytes_per_atom"], "pmc_lj_full.txt", "k_lj_full_tile<0, false, 2, 8, 3, 1>", "the roofline kernel of bench.py")
-row("B LJ full -s 80 DP (force only)", "k_lj_full_tile<0, false, 2, 8, 3, 0>", "kernel_stats_bench.md", N80, rf["bytes_per_atom"], "pmc_lj_full.txt", "k_lj_full_tile<0, false, 2, 8, 3, 0>", "kernel-only launches (mmd_profile_kernel)")
-row("A LJ full -s 32 DP", "k_lj_full_tile<0, false, 2, 8, 3, 1>", "kernel_stats_A.md", N32, 4 * 76.3 + 60 + 0.365 * 28, note="2 081 pencil tiles: less than one full wave of workgroups")
+row("B LJ full -s 80 DP (fused integrator)", "k_lj_full_tile<0, 1>", "kernel_stats_bench.md", N80, rf["bytes_per_atom"], "pmc_lj_full.txt", "k_lj_full_tile<0, 1>", "the roofline kernel of bench.py")
+row("B LJ full -s 80 DP (force only)", "k_lj_full_tile<0, 0>", "kernel_stats_bench.md", N80, rf["bytes_per_atom"], "pmc_lj_full.txt", "k_lj_full_tile<0, 0>", "kernel-only launches (mmd_profile_kernel)")
+row("A LJ full -s 32 DP", "k_lj_full_tile<0, 1>", "kernel_stats_A.md", N32, 4 * 76.3 + 60 + 0.365 * 28, note="2 081 pencil tiles: less than one full wave of workgroups")
 row("B' LJ half -s 80 DP", "k_lj_half_tile<0, 1", "kernel_stats_Bh.md", N80, 269, "pmc_lj_half.txt", "k_lj_half_tile<0, 1", "LDS + L2 atomics, not HBM, bound it")
 row("C EAM -s 64 DP: density sweep", "k_eam_density_tile<0, 0", "kernel_stats_C.md", N64, 4 * 60.25 + 4 + 28 + 8 + 0.167 * 28, "pmc_eam.txt", "k_eam_density_tile<0, 0", "")
 row("C EAM -s 64 DP: force sweep (fused integrator)", "k_eam_force_tile<0, 1, 0", "kernel_stats_C.md", N64, 4 * 60.25 + 4 + 28 + 8 + 24 + 0.167 * 8, "pmc_eam.txt", "k_eam_force_tile<0, 1, 0", "both sweeps + fp halo: 592 B/atom; rows in two parts, core part on 18 of 20 steps")
@@ -94,9 +94,9 @@ hdr = ["# %s — per-kernel roofline table (8 TB/s HBM3E peak)" % tag, "",
        "| configuration | kernel | calls | avg us | B/atom | algorithmic MB | GB/s | of peak | HBM traffic (PMC) | note |", "|---|---|---:|---:|---:|---:|---:|---:|---:|---|"]
 open(os.path.join(dst, tag + "_roofline.md"), "w").write("\n".join(hdr + rows) + "\n")
 print("\n".join(hdr + rows))
-f_, w_ = pmc("pmc_lj_full.txt", "k_lj_full_tile<0, false, 2, 8, 3, 1>", "FETCH_SIZE"), pmc("pmc_lj_full.txt", "k_lj_full_tile<0, false, 2, 8, 3, 1>", "WRITE_SIZE")
+f_, w_ = pmc("pmc_lj_full.txt", "k_lj_full_tile<0, 1>", "FETCH_SIZE"), pmc("pmc_lj_full.txt", "k_lj_full_tile<0, 1>", "WRITE_SIZE")
 if f_ and w_:
-    json.dump({"kernel": "k_lj_full_tile<0,false,2,8,3,1> (LJ full-neighbor force + fused integrator), in.lj.miniMD -s 80, DP",
+    json.dump({"kernel": "k_lj_full_tile<0,1> (LJ full-neighbor force + fused integrator), in.lj.miniMD -s 80, DP",
                "FETCH_SIZE_KiB_per_launch": f_, "WRITE_SIZE_KiB_per_launch": w_,
                "hbm_bytes_per_launch": (2 * f_ + w_) * 1024,
                "note": "separate rocprofv3 --pmc passes (tools/pmc_force.sh); reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes), an upper bound for the gathers"},

@@ -6,7 +6,7 @@ import json
 import sys
 
 # per rank at -s 80 per rank: grid -> (halo bytes per step, ghosts)
-GRID = {1: (0.0, 277000), 2: (3.0e6, 277000), 4: (6.0e6, 277000), 8: (9.0e6, 277000)}
+GRID = {1: (0.0, 277000), 2: (3.15e6, 277000), 4: (6.0e6, 277000), 8: (9.0e6, 277000)}
 FORCE_MS, NEIGH_MS, WINDOW_COMM_MS = 0.170, 0.60, 0.27
 
 
