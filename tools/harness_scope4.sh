@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 {
 echo "# ref/run_tests scope 4, one-rank entries (10000 steps, sizes 10/16/20/30/40/60): tools/run_one_test.py <exe> 1 4 <size> 10000 <halfneigh> 0 <input>"
-echo "# one MI355X, minimd_amd/bin/miniMD_dp (round 5, final library: neighbor build with the MFMA pre-test), thermo block against tests/golden/reference_output.json, pass rule of ref/run_one_test:121-138"
+echo "# one MI355X, minimd_amd/bin/miniMD_dp (round 6, final library), thermo block against tests/golden/reference_output.json, pass rule of ref/run_one_test:121-138"
 for inp in lj eam; do for hn in 0 1; do echo; echo "## ${inp}_half${hn}"
   for s in 10 16 20 30 40 60; do timeout 120 python -u tools/run_one_test.py minimd_amd/bin/miniMD_dp 1 4 $s 10000 $hn 0 $inp 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl"; done
 done; done
