@@ -564,6 +564,7 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
     constexpr int U = decltype(nu)::value;
     real xj[U], yj[U], zj[U];
     int sc[U];
+    unsigned farbits = 0;            // LJH_PACK: pairs of this trip whose share does not fit the packed accumulator's field
 #pragma unroll
     for(int u = 0; u < U; u++) { sc[u] = s[u]; lds_read3<LJH_RD>((unsigned)s[u], xj[u], yj[u], zj[u]); }
     np += U * 64;
@@ -596,41 +597,60 @@ __global__ __launch_bounds__(128) void k_lj_half_tile(
 #pragma unroll
       for(int q = 0; q < GRP; q++) {
         const int u = g0 + q;
-        if(rsq[q] < P.cutforcesq) {                           // (also keeps the padded lanes off the dummy slot's accumulator)
-          const real sr2 = sr2v[q];
-          const real A = (sr2 * sr2) * sr2;
-          const real fs = (A * sr2) * fma_r(A, P.sigma6, (real)-0.5);          // force / c_out
-          const real px = dx[q] * fs, py = dy[q] * fs, pz = dz[q] * fs;
-          fx += px; fy += py; fz += pz;
-          // the partner's accumulator collects +p, negated at the flush (sc = slot * 3 reals in bytes -> slot * 3 doubles)
-          double* a = (double*)((unsigned char*)s_acc + sc[u] * (int)(sizeof(double) / sizeof(real)));
-          if(ablate & 4) {            // (profiling only: integer LDS atomics of the same width / of 32 bits)
-            atomicAdd((unsigned long long*)a + 0, (unsigned long long)__double_as_longlong((double)px)); atomicAdd((unsigned long long*)a + 1, (unsigned long long)__double_as_longlong((double)py));
-            atomicAdd((unsigned long long*)a + 2, (unsigned long long)__double_as_longlong((double)pz));
-          } else if(ablate & 8) {
+        // Round 6: the pair's arithmetic is branch-free (an out-of-range pair gets sr2 = 0: every product below is an exact zero) and only the LDS atomics sit in an
+        // exec region — one, not the three nested ones of `if(in) { ...; if(share fits) {...} else {...} }`, which cost ~19 scalar instructions per pair.
+        const bool in = rsq[q] < P.cutforcesq;                // (the atomics below stay off out-of-range pairs: keeps the padded lanes off the dummy slot's accumulator)
+        const real sr2 = keep_if(in, sr2v[q]);
+        const real A = (sr2 * sr2) * sr2;
+        const real fs = (A * sr2) * fma_r(A, P.sigma6, (real)-0.5);          // force / c_out
+        const real px = dx[q] * fs, py = dy[q] * fs, pz = dz[q] * fs;
+        fx += px; fy += py; fz += pz;
+        // the partner's accumulator collects +p, negated at the flush (sc = slot * 3 reals in bytes -> slot * 3 doubles)
+        double* a = (double*)((unsigned char*)s_acc + sc[u] * (int)(sizeof(double) / sizeof(real)));
+        if(ablate & 4) {            // (profiling only: integer LDS atomics of the same width / of 32 bits)
+          if(in) { atomicAdd((unsigned long long*)a + 0, (unsigned long long)__double_as_longlong((double)px)); atomicAdd((unsigned long long*)a + 1, (unsigned long long)__double_as_longlong((double)py));
+                   atomicAdd((unsigned long long*)a + 2, (unsigned long long)__double_as_longlong((double)pz)); }
+        } else if(ablate & 8) {
+          if(in) {
             if(ablate & 16) { unsafeAtomicAdd((float*)a + 0, (float)px); unsafeAtomicAdd((float*)a + 2, (float)py); unsafeAtomicAdd((float*)a + 4, (float)pz); }
             else { atomicAdd((unsigned*)a + 0, (unsigned)__float_as_int((float)px)); atomicAdd((unsigned*)a + 2, (unsigned)__float_as_int((float)py)); atomicAdd((unsigned*)a + 4, (unsigned)__float_as_int((float)pz)); }
-          } else
-          if(LJH_PACK && !(ablate & 1)) {
-            if(fmaxf(fabsf((float)px), fabsf((float)py)) < LJH_FIX_SHARE) {
-              atomicAdd((unsigned long long*)a, ljh_pack_xy((float)px, (float)py));
-              if(!(ablate & 32)) unsafeAtomicAdd(a + 1, (double)pz);          // (ablate: profiling only)
-            } else {                        // (a pair far up the repulsive wall: its partner's share leaves the chip directly)
-              int j = s_idx[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))];
-              if(GN && ghost_root != nullptr && j >= nlocal) j = ghost_root[j - nlocal];
-              if(GN || j < nlocal) {
-                unsafeAtomicAdd(f + 3 * (size_t)j + 0, (real)(-(px * c_out))); unsafeAtomicAdd(f + 3 * (size_t)j + 1, (real)(-(py * c_out)));
-                unsafeAtomicAdd(f + 3 * (size_t)j + 2, (real)(-(pz * c_out)));
-              }
-            }
-          } else
-          if(!(ablate & 1)) { unsafeAtomicAdd(a + 0, (double)px); unsafeAtomicAdd(a + 1, (double)py); unsafeAtomicAdd(a + 2, (double)pz); }   // (ablate: profiling only)
-          if(EV) {
-            real scale = (real)1.0;
-            if(!GN) scale = s_ghost[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))] ? (real)0.5 : (real)1.0;
-            const real sr6 = A * P.sigma6;
-            e_acc += (double)(scale * ((real)4.0 * sr6 * (sr6 - (real)1.0)) * P.epsilon);
-            v_acc += (double)(scale * rsq[q] * fs);
+          }
+        } else
+        if(LJH_PACK && !(ablate & 1)) {
+          // (a share that does not fit its fixed-point field — a pair far up the repulsive wall, practically never — is only MARKED here and leaves the chip behind the trip)
+          const bool fits = fmaxf(fabsf((float)px), fabsf((float)py)) < LJH_FIX_SHARE;
+          if(in && fits) {
+            atomicAdd((unsigned long long*)a, ljh_pack_xy((float)px, (float)py));
+            if(!(ablate & 32)) unsafeAtomicAdd(a + 1, (double)pz);          // (ablate: profiling only)
+          }
+          farbits |= (unsigned)(in && !fits) << u;
+        } else
+        if(!(ablate & 1)) { if(in) { unsafeAtomicAdd(a + 0, (double)px); unsafeAtomicAdd(a + 1, (double)py); unsafeAtomicAdd(a + 2, (double)pz); } }   // (ablate: profiling only)
+        if(EV) {
+          real scale = (real)1.0;
+          if(!GN) scale = s_ghost[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))] ? (real)0.5 : (real)1.0;
+          const real sr6 = A * P.sigma6;
+          e_acc += (double)(scale * ((real)4.0 * sr6 * (sr6 - (real)1.0)) * P.epsilon);
+          v_acc += (double)(scale * rsq[q] * fs);
+        }
+      }
+    }
+    if(LJH_PACK && __builtin_amdgcn_ballot_w64(farbits != 0u) != 0ull) {
+      // the marked pairs, again, one by one (same operations: the same share): straight to the partner's force in global memory
+#pragma unroll
+      for(int u = 0; u < U; u++) {
+        if((farbits >> u) & 1u) {
+          const real dx = xi.x - xj[u], dy = xi.y - yj[u], dz = xi.z - zj[u];
+          const real rsq = fma_r(dz, dz, fma_r(dy, dy, dx * dx));
+          const real sr2 = recip_fast(rsq);
+          const real A = (sr2 * sr2) * sr2;
+          const real fs = (A * sr2) * fma_r(A, P.sigma6, (real)-0.5);
+          const real px = dx * fs, py = dy * fs, pz = dz * fs;
+          int j = s_idx[(unsigned)sc[u] / (3u * (unsigned)sizeof(real))];
+          if(GN && ghost_root != nullptr && j >= nlocal) j = ghost_root[j - nlocal];
+          if(GN || j < nlocal) {
+            unsafeAtomicAdd(f + 3 * (size_t)j + 0, (real)(-(px * c_out))); unsafeAtomicAdd(f + 3 * (size_t)j + 1, (real)(-(py * c_out)));
+            unsafeAtomicAdd(f + 3 * (size_t)j + 2, (real)(-(pz * c_out)));
           }
         }
       }

@@ -226,3 +226,46 @@ def test_neighbor_sets_at_baseline_sizes_equal_the_oracles(size, half, prec):
     bad = np.nonzero((mine != theirs).any(axis=1))[0]
     assert len(bad) == 0, (len(bad), bad[:5])
     h.close(); o.close()
+
+
+# ---- half-list tile kernel: a share that does not fit the packed accumulator (single precision) ---------------------------------------------------
+@pytest.mark.parametrize("prec", ["sp", "dp"])
+def test_half_list_pair_far_up_the_repulsive_wall(prec):
+    """k_lj_half_tile adds a pair's share to the partner in LDS; in single precision x and y travel in ONE 64-bit fixed-point atomic whose fields hold |share| < 16
+    (force / c_out). A pair closer than ~0.8 sigma exceeds that: it is marked inside the trip and leaves the chip behind it, straight to the partner's force
+    (round 6: the marked pairs are re-evaluated behind the trip instead of branching per pair). One interior atom is pushed to 0.75 sigma of a neighbor (share ~38);
+    the device builds its half list on those positions and its forces equal the oracle's ForceLJ::compute_halfneigh (ref/force_lj.cpp:271-357) on the same list."""
+    import numpy as np
+    from test_gpu_parity import mm
+    from oracle_lib import Oracle
+    o = Oracle(["-s", 6, "-n", 20, "--half_neigh", 1, "-gn", 0], precision=prec)
+    o.initial(); o.run()
+    nl, x, typ = o.nlocal(), o.x().copy(), o.type()
+    nall = len(x)
+    box = o.box()
+    prd = np.array(box[0:3])
+    cn = float(o.param("cutneigh"))
+    inner = np.nonzero(((x[:nl] > cn + 1.0) & (x[:nl] < prd - cn - 1.0)).all(axis=1))[0]          # atoms without periodic images: moving them moves no ghost
+    a = int(inner[0])
+    d = np.linalg.norm(x[:nl] - x[a], axis=1); d[a] = 1e9
+    d[[i for i in range(nl) if i not in set(inner.tolist())]] = 1e9
+    b = int(np.argmin(d))
+    u = (x[a] - x[b]) / np.linalg.norm(x[a] - x[b])
+    x[a] = x[b] + 0.75 * u
+    h = mm().Handle(prec)
+    h.set_box(box[0:3], [box[3], box[5], box[7]], [box[4], box[6], box[8]])
+    h.set_mass(o.param("mass"))
+    h.upload(x, np.zeros((nl, 3)), typ, o.tag(), nlocal=nl)
+    h.neighbor_setup(o.nbins(), cn, 1, 0, o.ntypes())
+    h.force_lj_setup(*o.lj_tables())
+    h.neighbor_build()
+    assert h.neighbor_tile_stats()["tiles"] > 0
+    nb, nn = h.neighbor_download()
+    fo, _eo, _vo = o.lj_force_half(x, typ, nl, nall, nb, nn, *o.lj_tables(), 0, 0)
+    h.force_compute(0)
+    f = h.download(halfneigh=True)["f"][:nl]
+    fmax = np.abs(fo[:nl]).max()
+    assert fmax > 500.0                                         # (the pair is there: 48 x 38)
+    tol = 1e-11 if prec == "dp" else 2e-5
+    assert np.abs(f - fo[:nl]).max() <= tol * fmax
+    h.close(); o.close()
