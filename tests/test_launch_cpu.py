@@ -140,3 +140,22 @@ def test_a_silent_stranger_does_not_stall_the_rendezvous(port):
     o1, e1 = p1.communicate(timeout=120)
     silent.close()
     assert p0.returncode == 0 and p1.returncode == 0 and "mesh up 0" in o0 and "mesh up 1" in o1, (e0[-1500:], e1[-1500:])
+
+
+def test_rehearsal_report_reads_a_multi_rank_bench_line():
+    """tools/rehearsal_report.py on the bench line of the 8-rank dress rehearsal kept under profiles/ (one GPU, debug transport): the geometry lines of every rank
+    PASS (owned atoms, ghosts, halo bytes per step, synchronisations per re-neighboring, no overflow, direct borders, buckets partitioning the wall clock), the
+    transport / timing lines say LOOK — the page a first multi-GPU lease is read with."""
+    import importlib.util
+    import io
+    spec = importlib.util.spec_from_file_location("rehearsal_report", os.path.join(REPO, "tools", "rehearsal_report.py"))
+    rr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rr)
+    out = io.StringIO()
+    ok = rr.report(os.path.join(REPO, "profiles", "r06_rehearsal_bench_n8.json"), out)
+    text = out.getvalue()
+    assert ok is False and text.count(" rank ") == 8
+    for what in ("owned atoms", "ghost atoms", "halo bytes per step", "host syncs per re-neighboring   ", "exchange: fixed-size messages overflowed", "borders as one exchange", "buckets partition the wall clock"):
+        rows = [l for l in text.splitlines() if l.strip().startswith(what)]
+        assert len(rows) == 8 and all(l.rstrip().endswith("PASS") for l in rows), (what, rows[:2])
+    assert "halos over RCCL (valid)" in text and [l for l in text.splitlines() if "halos over RCCL" in l][0].rstrip().endswith("LOOK")
